@@ -1,0 +1,279 @@
+/*
+ * tr_shade.h — C ABI of the MI355X-native transmission / volume PBR shading path.
+ *
+ * This is the drop-in boundary for the hot path of expenses/transmission-renderer:
+ *   opaque colour pass  ->  opaque-framebuffer mip chain  ->  transmissive pass
+ * (reference: src/main.rs:1969-2124 schedules it, shader/src/lib.rs:37-249 are the
+ * per-pixel entry points, glam-pbr/src/lib.rs is the math).  The reference has no FFI
+ * of its own: its boundary is the Vulkan descriptor/push-constant ABI of the two
+ * fragment entry points.  Every struct below mirrors one of those wire structs byte
+ * for byte (offsets verified against the OpMemberDecorate Offset words of
+ * compiled-shaders/normal/fragment_transmission.spv), and every function replaces one
+ * step of `record()`; the reference interface each one replaces is cited.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; device pointers are raw `void*` owned by the caller
+ *   - every launch takes a `hipStream_t` passed as `void*` and is asynchronous
+ *   - every function returns a tr_status (0 = OK); no exceptions cross the boundary
+ *   - one host thread per context; no global state beyond the opaque tr_context
+ *   - there is NO CPU fallback: without a HIP device the context cannot be created
+ */
+#ifndef TR_SHADE_H
+#define TR_SHADE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TR_ABI_VERSION 1u
+
+/* ------------------------------------------------------------------ status */
+typedef int32_t tr_status;
+enum {
+    TR_OK = 0,
+    TR_ERR_INVALID_ARGUMENT = 1,
+    TR_ERR_NO_DEVICE = 2,        /* no HIP device / runtime error at context creation */
+    TR_ERR_HIP = 3,              /* a HIP runtime call failed; see tr_last_hip_error */
+    TR_ERR_TABLES_MISSING = 4,   /* a pass was launched before its tables were set  */
+    TR_ERR_OUT_OF_MEMORY = 5,
+    TR_ERR_UNSUPPORTED = 6
+};
+
+/* ------------------------------------------------- wire structs (reference) */
+
+/* shared-structs/src/lib.rs:8-16 `PushConstants` (96 B). proj_view is column-major. */
+typedef struct tr_push_constants {
+    float    proj_view[16];                    /* @0  */
+    float    view_position[3];                 /* @64 (Vec3A: 16-byte slot) */
+    float    _pad0;
+    uint32_t framebuffer_size[2];              /* @80 */
+    uint64_t acceleration_structure_address;   /* @88 (unused: no ray tracing on CDNA) */
+} tr_push_constants;
+
+/* shared-structs/src/lib.rs:31-41 `LightClusterCoefficients` (20 B, padded to 32 in Uniforms). */
+typedef struct tr_light_cluster_coefficients {
+    float    z_near;            /* @0  */
+    float    z_far;             /* @4  */
+    float    scale;             /* @8  */
+    float    bias;              /* @12 */
+    uint32_t num_depth_slices;  /* @16 */
+    uint32_t _pad[3];
+} tr_light_cluster_coefficients;
+
+/* shared-structs/src/lib.rs:18-29 `Uniforms` (96 B). */
+typedef struct tr_uniforms {
+    tr_light_cluster_coefficients light_clustering_coefficients; /* @0  */
+    float    sun_dir[3];                /* @32 */
+    float    _pad0;
+    float    sun_intensity[3];          /* @48 */
+    float    _pad1;
+    float    cluster_size_in_pixels[2]; /* @64 */
+    uint32_t num_clusters[2];           /* @72 */
+    uint32_t debug_clusters;            /* @80 */
+    uint32_t ggx_lut_texture_index;     /* @84 (kept for layout; the LUT is bound via tr_upload_ggx_lut) */
+    uint32_t _pad2[2];
+} tr_uniforms;
+
+/* shared-structs/src/lib.rs:141-153 `Textures` (9 x i32, -1 = none). */
+typedef struct tr_textures {
+    int32_t diffuse;
+    int32_t metallic_roughness;
+    int32_t normal_map;
+    int32_t emissive;
+    int32_t occlusion;
+    int32_t transmission;
+    int32_t thickness;
+    int32_t specular;
+    int32_t specular_colour;
+} tr_textures;
+
+/* shared-structs/src/lib.rs:155-173 `MaterialInfo` (stride 160 B). */
+typedef struct tr_material_info {
+    tr_textures textures;            /* @0   */
+    float metallic_factor;           /* @36  */
+    float roughness_factor;          /* @40  */
+    float alpha_clipping_cutoff;     /* @44  */
+    float diffuse_factor[4];         /* @48  */
+    float emissive_factor[3];        /* @64  */
+    float _pad0;
+    float normal_map_scale;          /* @80  (never read by the reference shaders) */
+    float occlusion_strength;        /* @84  (never read by the reference shaders) */
+    float index_of_refraction;       /* @88  */
+    float transmission_factor;       /* @92  */
+    float thickness_factor;          /* @96  */
+    float attenuation_distance;      /* @100 (+INF = no attenuation) */
+    float _pad1[2];
+    float attenuation_colour[3];     /* @112 */
+    float _pad2;
+    float specular_factor;           /* @128 */
+    float _pad3[3];
+    float specular_colour_factor[3]; /* @144 */
+    float _pad4;
+} tr_material_info;
+
+/* shared-structs/src/lib.rs:70-78 `Light` (stride 48 B). */
+typedef struct tr_light {
+    float position_and_spotlight_epsilon[4];          /* @0  */
+    float colour_emission_and_falloff_distance_sq[4]; /* @16 */
+    float spotlight_direction_and_outer_angle[4];     /* @32 (w == 0 => point light) */
+} tr_light;
+
+/* shared-structs/src/lib.rs:282-288 `ClusterAabb` (32 B, view space). */
+typedef struct tr_cluster_aabb {
+    float min[3];
+    float _pad0;
+    float max[3];
+    float _pad1;
+} tr_cluster_aabb;
+
+/* shared-structs/src/lib.rs:322 */
+#define TR_MAX_LIGHTS_PER_CLUSTER 128u
+
+/* ----------------------------------------------- G-buffer ("TGB-v1" planes) */
+/*
+ * What the rasteriser hands the two fragment entry points (interpolated `position`,
+ * `normal`, `uv`, flat `material_id`, flat `model_scale`, `frag_coord.z`;
+ * shader/src/lib.rs:38-55, 165-181) laid out as structure-of-arrays planes in HBM,
+ * row-major, plane index (y - origin_y)*width + (x - origin_x) for frame pixel (x, y).  The
+ * frame size is push_constants.framebuffer_size; colour targets are always whole-frame buffers
+ * (pitch = framebuffer_size.x).  All pointers are device pointers.
+ */
+typedef struct tr_gbuffer {
+    const void* pos_depth;   /* float4: world position xyz, w = frag_coord.z (reversed-Z depth) */
+    const void* nrm_scale;   /* float4: interpolated (un-normalised) normal xyz, w = model_scale */
+    const void* uv;          /* float2: texture coordinates                                     */
+    const void* material_id; /* uint32: index into materials; TR_NOT_COVERED = no fragment here */
+    uint32_t    width;       /* plane size in pixels                                            */
+    uint32_t    height;
+    uint32_t    origin_x;    /* frame position of plane element (0,0): a rank that shades one    */
+    uint32_t    origin_y;    /* screen tile holds only that tile's planes (0,0 = whole frame)    */
+} tr_gbuffer;
+
+#define TR_NOT_COVERED 0xFFFFFFFFu
+
+/* Half-open pixel rectangle [x0,x1) x [y0,y1) in frame coordinates: the screen tile one rank
+ * shades.  Must lie inside both the frame and the G-buffer planes. */
+typedef struct tr_rect {
+    uint32_t x0, y0, x1, y1;
+} tr_rect;
+
+/* Colour-target storage format. The reference's targets are R16G16B16A16_SFLOAT
+ * (src/render_passes.rs:27-41, src/main.rs:2370); RGBA32F exists for parity tests
+ * that want to see the value before the half rounding. */
+typedef enum tr_format {
+    TR_FORMAT_RGBA16F = 0,
+    TR_FORMAT_RGBA32F = 1
+} tr_format;
+
+/*
+ * Opaque-colour pyramid (`opaque_sampled_hdr_framebuffer`, src/main.rs:383-402): one
+ * device allocation of RGBA16F texels, levels tightly packed one after another
+ * (level l is max(width>>l,1) x max(height>>l,1), row-major).  Level count follows
+ * mip_levels_for_size (src/main.rs:2590-2592).
+ */
+#define TR_MAX_MIP_LEVELS 16u
+typedef struct tr_pyramid {
+    void*    texels;                             /* device pointer, RGBA16F */
+    uint32_t width, height, levels;
+    uint32_t level_offset[TR_MAX_MIP_LEVELS];    /* in texels, from `texels` */
+} tr_pyramid;
+
+typedef struct tr_context tr_context; /* opaque */
+
+/* ------------------------------------------------------------------ context */
+
+/* Replaces Vulkan instance/device bring-up (src/main.rs:114-275) for this path. */
+tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx);
+tr_status tr_context_destroy(tr_context* ctx);
+
+const char* tr_status_string(tr_status status);
+/* hipError_t of the last failing HIP call on this context (0 if none). */
+int32_t     tr_last_hip_error(const tr_context* ctx);
+uint32_t    tr_abi_version(void);
+
+/* mip_levels_for_size (src/main.rs:2590-2592) and the packed layout above.
+ * `texels` is left NULL; total size in bytes is returned through out_bytes. */
+tr_status tr_pyramid_layout(uint32_t width, uint32_t height, tr_pyramid* out_pyramid, size_t* out_bytes);
+
+/* -------------------------------------------------------------------- tables */
+
+/* materials[] storage buffer (set 0 binding 2; src/main.rs:715-760, filled by
+ * src/model_loading.rs:231-333).  Host pointer; copied and pre-digested on `stream`. */
+tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials_host, uint32_t count, void* stream);
+
+/* lights[] storage buffer (set 2 binding 0; src/main.rs:450-496). Host pointer. */
+tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_t count, void* stream);
+
+/* cluster_light_counts / light_indices (set 2 bindings 1,2; src/main.rs:485-496):
+ * device pointers, `num_clusters_total` u32 counts and num_clusters_total*128 u32
+ * indices.  The context borrows them (e.g. the output of tr_assign_lights_to_clusters). */
+tr_status tr_set_cluster_tables(tr_context* ctx, const void* cluster_light_counts_dev,
+                                const void* light_indices_dev, uint32_t num_clusters_total);
+
+/* ggx_lut.png as uploaded by src/main.rs:295-330 (R8G8B8A8_UNORM, row 0 first). Host pointer. */
+tr_status tr_upload_ggx_lut(tr_context* ctx, const uint8_t* rgba8_host, uint32_t width, uint32_t height, void* stream);
+
+/* -------------------------------------------------------------------- passes */
+
+/*
+ * "main opaque" colour pass: `fragment` (shader/src/lib.rs:164-249) for every covered
+ * pixel of `rect`; the same value goes to hdr_out and to level 0 of the pyramid
+ * (lib.rs:247-248).  Pixels with material_id == TR_NOT_COVERED get the clear colour
+ * (0,0,0,1) (src/main.rs:1592-1601).  hdr_out: width*height texels of `format`;
+ * opaque_mip0_out is always RGBA16F (may be NULL to skip the second write).
+ */
+tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* gbuffer, const tr_uniforms* uniforms,
+                          const tr_push_constants* push, void* hdr_out, tr_format format,
+                          void* opaque_mip0_out, tr_rect rect, void* stream);
+
+/* "opaque framebuffer mipchain": generate_mips (src/main.rs:2046-2064): levels 1.. from level 0,
+ * each level a LINEAR blit of the previous one, fp32 accumulate, RTNE store to RGBA16F. */
+tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* pyramid, void* stream);
+
+/*
+ * "opaque transmissive objects": `fragment_transmission` (shader/src/lib.rs:37-162) for
+ * every covered pixel of `rect`, overwriting hdr_inout (no blending, depth EQUAL:
+ * src/pipelines.rs:338-347); uncovered pixels keep their value (attachment LOAD,
+ * src/render_passes.rs:135-152).
+ */
+tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* gbuffer, const tr_uniforms* uniforms,
+                                const tr_push_constants* push, const tr_pyramid* pyramid,
+                                void* hdr_inout, tr_format format, tr_rect rect, void* stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#ifdef __cplusplus
+#define TR_STATIC_ASSERT(c, m) static_assert(c, m)
+#else
+#define TR_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#endif
+TR_STATIC_ASSERT(sizeof(tr_push_constants) == 96, "PushConstants is 96 B");
+TR_STATIC_ASSERT(offsetof(tr_push_constants, view_position) == 64, "view_position @64");
+TR_STATIC_ASSERT(offsetof(tr_push_constants, framebuffer_size) == 80, "framebuffer_size @80");
+TR_STATIC_ASSERT(offsetof(tr_push_constants, acceleration_structure_address) == 88, "as address @88");
+TR_STATIC_ASSERT(sizeof(tr_uniforms) == 96, "Uniforms is 96 B");
+TR_STATIC_ASSERT(offsetof(tr_uniforms, sun_dir) == 32, "sun_dir @32");
+TR_STATIC_ASSERT(offsetof(tr_uniforms, sun_intensity) == 48, "sun_intensity @48");
+TR_STATIC_ASSERT(offsetof(tr_uniforms, cluster_size_in_pixels) == 64, "cluster_size_in_pixels @64");
+TR_STATIC_ASSERT(offsetof(tr_uniforms, num_clusters) == 72, "num_clusters @72");
+TR_STATIC_ASSERT(offsetof(tr_uniforms, debug_clusters) == 80, "debug_clusters @80");
+TR_STATIC_ASSERT(offsetof(tr_uniforms, ggx_lut_texture_index) == 84, "ggx_lut_texture_index @84");
+TR_STATIC_ASSERT(sizeof(tr_material_info) == 160, "MaterialInfo stride is 160 B");
+TR_STATIC_ASSERT(offsetof(tr_material_info, metallic_factor) == 36, "metallic_factor @36");
+TR_STATIC_ASSERT(offsetof(tr_material_info, diffuse_factor) == 48, "diffuse_factor @48");
+TR_STATIC_ASSERT(offsetof(tr_material_info, emissive_factor) == 64, "emissive_factor @64");
+TR_STATIC_ASSERT(offsetof(tr_material_info, normal_map_scale) == 80, "normal_map_scale @80");
+TR_STATIC_ASSERT(offsetof(tr_material_info, index_of_refraction) == 88, "index_of_refraction @88");
+TR_STATIC_ASSERT(offsetof(tr_material_info, attenuation_distance) == 100, "attenuation_distance @100");
+TR_STATIC_ASSERT(offsetof(tr_material_info, attenuation_colour) == 112, "attenuation_colour @112");
+TR_STATIC_ASSERT(offsetof(tr_material_info, specular_factor) == 128, "specular_factor @128");
+TR_STATIC_ASSERT(offsetof(tr_material_info, specular_colour_factor) == 144, "specular_colour_factor @144");
+TR_STATIC_ASSERT(sizeof(tr_light) == 48, "Light stride is 48 B");
+TR_STATIC_ASSERT(sizeof(tr_cluster_aabb) == 32, "ClusterAabb is 32 B");
+
+#endif /* TR_SHADE_H */

@@ -1,0 +1,764 @@
+/*
+ * tr_oracle.c — see tr_oracle.h.  TEST INFRASTRUCTURE: the checker, never the product.
+ *
+ * Scalar IEEE fp32 (`real` = float; see tr_oracle.h for the fp64 conditioning twin), one operation per
+ * source operation of the reference, in the
+ * reference's association order (glam 0.19 scalar Vec3: dot = (x*x'+y*y')+z*z',
+ * normalize = v * (1/sqrt(len^2)), lerp = a + (b-a)*t; confirmed against the op order of
+ * compiled-shaders/normal/fragment_transmission.spv by oracle/spirv_ref).
+ * Must be compiled with -ffp-contract=off and without -ffast-math.
+ */
+#include "tr_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(O_REAL_DOUBLE)
+#define R(x) x
+#define R_SQRT sqrt
+#define R_POW pow
+#define R_LOG log
+#define R_EXP exp
+#define R_LOG2 log2
+#define R_FLOOR floor
+#define R_MAX fmax
+#define R_MIN fmin
+#define R_COS cos
+#define R_SIN sin
+#define R_TAN tan
+#else
+#define R(x) x##f
+#define R_SQRT sqrtf
+#define R_POW powf
+#define R_LOG logf
+#define R_EXP expf
+#define R_LOG2 log2f
+#define R_FLOOR floorf
+#define R_MAX fmaxf
+#define R_MIN fminf
+#define R_COS cosf
+#define R_SIN sinf
+#define R_TAN tanf
+#endif
+
+/* ------------------------------------------------------------------ vec3 */
+static inline o_vec3 v3(real x, real y, real z) { o_vec3 r = {x, y, z}; return r; }
+static inline o_vec3 v3_splat(real s) { return v3(s, s, s); }
+static inline o_vec3 v3_add(o_vec3 a, o_vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline o_vec3 v3_sub(o_vec3 a, o_vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline o_vec3 v3_mul(o_vec3 a, o_vec3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline o_vec3 v3_scale(o_vec3 a, real s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline o_vec3 v3_div(o_vec3 a, real s) { return v3(a.x / s, a.y / s, a.z / s); }
+static inline o_vec3 v3_neg(o_vec3 a) { return v3(-a.x, -a.y, -a.z); }
+static inline o_vec3 v3_add_s(o_vec3 a, real s) { return v3(a.x + s, a.y + s, a.z + s); }
+/* 1.0 - v */
+static inline o_vec3 v3_one_minus(o_vec3 a) { return v3(R(1.0) - a.x, R(1.0) - a.y, R(1.0) - a.z); }
+static inline real v3_dot(o_vec3 a, o_vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline o_vec3 v3_normalize(o_vec3 a) {
+    real len = R_SQRT(v3_dot(a, a));
+    real recip = R(1.0) / len;
+    return v3_scale(a, recip);
+}
+static inline o_vec3 v3_lerp(o_vec3 a, o_vec3 b, real t) { return v3_add(a, v3_scale(v3_sub(b, a), t)); }
+static inline real v3_max_element(o_vec3 a) { return R_MAX(a.x, R_MAX(a.y, a.z)); }
+
+/* glam-pbr/src/lib.rs:25-27 */
+static inline real o_clamp(real value, real mn, real mx) { return R_MIN(R_MAX(value, mn), mx); }
+
+/* Rust `f32 as u32`: saturating, NaN -> 0 */
+static inline uint32_t f32_as_u32(real f) {
+    if (!(f > R(0.0))) return 0u;
+    if (f >= R(4294967296.0)) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+#define O_EPSILON R(1.1920929e-07) /* core::f32::EPSILON */
+#define O_PI R(3.14159265358979323846)
+#define O_FRAC_1_PI R(0.318309886183790671538)
+
+/* ------------------------------------------------------------- glam-pbr */
+
+/* glam-pbr/src/lib.rs:12-23 */
+void o_light_direction_and_attenuation(o_vec3 fragment_position, o_vec3 light_position,
+                                       o_vec3* direction, real* distance, real* attenuation) {
+    o_vec3 vector = v3_sub(light_position, fragment_position);
+    real distance_sq = v3_dot(vector, vector);
+    real dist = R_SQRT(distance_sq);
+    *direction = v3_div(vector, dist);
+    *distance = dist;
+    *attenuation = R(1.0) / distance_sq;
+}
+
+/* glam-pbr/src/lib.rs:93-98 `Dot::new` */
+real o_dot_clamped(o_vec3 a, o_vec3 b) { return R_MAX(v3_dot(a, b), O_EPSILON); }
+
+/* glam-pbr/src/lib.rs:62-68 `Halfway::new` */
+static inline o_vec3 o_halfway(o_vec3 view, o_vec3 light) { return v3_normalize(v3_add(view, light)); }
+
+/* glam-pbr/src/lib.rs:101-109 */
+real o_d_ggx(real noh, real actual_roughness) {
+    real alpha_roughness_sq = actual_roughness * actual_roughness;
+    real f = (noh * noh) * (alpha_roughness_sq - R(1.0)) + R(1.0);
+    return alpha_roughness_sq / (O_PI * f * f);
+}
+
+/* glam-pbr/src/lib.rs:114-133 */
+real o_v_smith_ggx_correlated(real nov, real nol, real actual_roughness) {
+    real a2 = actual_roughness * actual_roughness;
+    real ggx_v = nol * R_SQRT(nov * nov * (R(1.0) - a2) + a2);
+    real ggx_l = nov * R_SQRT(nol * nol * (R(1.0) - a2) + a2);
+    real ggx = ggx_v + ggx_l;
+    if (ggx > R(0.0)) return R(0.5) / ggx;
+    return R(0.0);
+}
+
+/* glam-pbr/src/lib.rs:137-139 */
+o_vec3 o_fresnel_schlick(real voh, o_vec3 f0, o_vec3 f90) {
+    real p = R_POW(R(1.0) - voh, R(5.0));
+    return v3_add(f0, v3_scale(v3_sub(f90, f0), p));
+}
+
+/* glam-pbr/src/lib.rs:190-195 */
+real o_to_dielectric_f0(real ior) {
+    real root = (ior - R(1.0)) / (ior + R(1.0));
+    return root * root;
+}
+
+/* glam-pbr/src/lib.rs:425-430 */
+static o_vec3 o_calculate_combined_f0(o_material_params m) {
+    o_vec3 dielectric_specular_f0 =
+        v3_scale(v3_scale(m.specular_colour, o_to_dielectric_f0(m.index_of_refraction)), m.specular_factor);
+    return v3_lerp(dielectric_specular_f0, m.diffuse_colour, m.metallic);
+}
+
+/* glam-pbr/src/lib.rs:432-435 */
+static o_vec3 o_calculate_combined_f90(o_material_params m) {
+    return v3_lerp(v3_splat(m.specular_factor), v3_splat(R(1.0)), m.metallic);
+}
+
+/* glam-pbr/src/lib.rs:200-233 */
+o_vec3 o_transmission_btdf(o_material_params m, o_vec3 normal, o_vec3 view, o_vec3 light) {
+    real actual_roughness = m.perceptual_roughness * m.perceptual_roughness;             /* :149-151 */
+    real ior = m.index_of_refraction;
+    real transmission_roughness = actual_roughness * o_clamp(ior * R(2.0) - R(2.0), R(0.0), R(1.0)); /* :144-146 */
+
+    /* light.0 + 2.0 * normal.0 * (-light.0).dot(normal.0) */
+    real d = v3_dot(v3_neg(light), normal);
+    o_vec3 light_mirrored = v3_normalize(v3_add(light, v3_scale(v3_scale(normal, R(2.0)), d)));
+
+    o_vec3 halfway = o_halfway(view, light_mirrored);
+    real noh = o_dot_clamped(normal, halfway);
+    real voh = o_dot_clamped(view, halfway);
+    real nov = o_dot_clamped(normal, view);
+    real nol_m = o_dot_clamped(normal, light_mirrored);
+
+    real distribution = o_d_ggx(noh, transmission_roughness);
+    real geometric_shadowing = o_v_smith_ggx_correlated(nov, nol_m, transmission_roughness);
+
+    o_vec3 f0 = o_calculate_combined_f0(m);
+    o_vec3 f90 = o_calculate_combined_f90(m);
+    o_vec3 fresnel = o_fresnel_schlick(voh, f0, f90);
+
+    /* (1.0 - fresnel) * distribution * geometric_shadowing * diffuse_colour */
+    return v3_mul(v3_scale(v3_scale(v3_one_minus(fresnel), distribution), geometric_shadowing), m.diffuse_colour);
+}
+
+/* glam-pbr/src/lib.rs:248-256 */
+o_vec3 o_refract(o_vec3 incident, o_vec3 normal, real ior) {
+    real eta = R(1.0) / ior;
+    real n_dot_i = v3_dot(normal, incident);
+    real k = R(1.0) - eta * eta * (R(1.0) - n_dot_i * n_dot_i);
+    return v3_sub(v3_scale(incident, eta), v3_scale(normal, eta * n_dot_i + R_SQRT(k)));
+}
+
+/* glam-pbr/src/lib.rs:275-290 */
+o_vec3 o_apply_volume_attenuation(o_vec3 transmitted_light, real transmission_distance,
+                                  real attenuation_distance, o_vec3 attenuation_colour) {
+    if (attenuation_distance == INFINITY) return transmitted_light;
+    o_vec3 lnc = v3(R_LOG(attenuation_colour.x), R_LOG(attenuation_colour.y), R_LOG(attenuation_colour.z));
+    o_vec3 attenuation_coefficient = v3_div(v3_neg(lnc), attenuation_distance);
+    o_vec3 e = v3_scale(v3_neg(attenuation_coefficient), transmission_distance);
+    o_vec3 transmittance = v3(R_EXP(e.x), R_EXP(e.y), R_EXP(e.z));
+    return v3_mul(transmittance, transmitted_light);
+}
+
+/* glam 0.19 Mat4 * Vec4: ((X*x + Y*y) + Z*z) + W*w per component, column-major m */
+static inline void mat4_mul_vec4(const real m[16], const real v[4], real out[4]) {
+    for (int r = 0; r < 4; ++r) {
+        real acc = m[0 + r] * v[0];
+        acc = m[4 + r] * v[1] + acc;
+        acc = m[8 + r] * v[2] + acc;
+        acc = m[12 + r] * v[3] + acc;
+        out[r] = acc;
+    }
+}
+
+/* glam-pbr/src/lib.rs:292-354 */
+o_vec3 o_ibl_volume_refraction(const o_ibl_volume_refraction_params* p,
+                               o_framebuffer_sampler fb, void* fb_user,
+                               o_ggx_lut_sampler lut, void* lut_user) {
+    o_material_params m = p->material_params;
+    real ior = m.index_of_refraction;
+
+    /* get_volume_transmission_ray :258-268 */
+    o_vec3 refraction = o_refract(v3_neg(p->view), p->normal, ior);
+    real ray_length = p->thickness * p->model_scale;
+    o_vec3 ray = v3_scale(v3_normalize(refraction), ray_length);
+    o_vec3 refracted_ray_exit = v3_add(p->position, ray);
+
+    real e4[4] = {refracted_ray_exit.x, refracted_ray_exit.y, refracted_ray_exit.z, R(1.0)};
+    real dc[4];
+    mat4_mul_vec4(p->proj_view_matrix, e4, dc);
+    o_vec2 screen = {dc[0] / dc[3], dc[1] / dc[3]};
+    o_vec2 tex = {(screen.x + R(1.0)) / R(2.0), (screen.y + R(1.0)) / R(2.0)};
+
+    /* (framebuffer_size_x as f32).log2() * perceptual_roughness.apply_ior(ior).0 :334-335 */
+    real rough_ior = m.perceptual_roughness * o_clamp(ior * R(2.0) - R(2.0), R(0.0), R(1.0)); /* :157-159 */
+    real framebuffer_lod = R_LOG2((real)p->framebuffer_size_x) * rough_ior;
+
+    o_vec3 transmitted_light = fb(fb_user, tex, framebuffer_lod);
+    o_vec3 attenuated = o_apply_volume_attenuation(transmitted_light, ray_length,
+                                                   p->attenuation_distance, p->attenuation_colour);
+
+    real normal_dot_view = v3_dot(p->normal, p->view); /* unclamped :345 */
+    o_vec2 brdf = lut(lut_user, normal_dot_view, m.perceptual_roughness);
+
+    o_vec3 f0 = o_calculate_combined_f0(m);
+    o_vec3 f90 = o_calculate_combined_f90(m);
+    o_vec3 specular_colour = v3_add(v3_scale(f0, brdf.x), v3_scale(f90, brdf.y));
+
+    return v3_mul(v3_mul(v3_one_minus(specular_colour), attenuated), m.diffuse_colour);
+}
+
+/* glam-pbr/src/lib.rs:377-423 (diffuse_brdf :356-360, specular_brdf :362-375 inlined) */
+o_brdf_result o_basic_brdf(o_vec3 normal, o_vec3 light, o_vec3 light_intensity, o_vec3 view,
+                           o_material_params m) {
+    real actual_roughness = m.perceptual_roughness * m.perceptual_roughness;
+
+    o_vec3 halfway = o_halfway(view, light);
+    real noh = o_dot_clamped(normal, halfway);
+    real nov = o_dot_clamped(normal, view);
+    real nol = o_dot_clamped(normal, light);
+    real voh = o_dot_clamped(view, halfway);
+
+    o_vec3 c_diff = v3_lerp(m.diffuse_colour, v3_splat(R(0.0)), m.metallic);
+
+    o_vec3 f0 = o_calculate_combined_f0(m);
+    o_vec3 f90 = o_calculate_combined_f90(m);
+    o_vec3 fresnel = o_fresnel_schlick(voh, f0, f90);
+
+    /* diffuse_brdf: (1.0 - fresnel.max_element()) * FRAC_1_PI * base */
+    o_vec3 dbrdf = v3_scale(c_diff, (R(1.0) - v3_max_element(fresnel)) * O_FRAC_1_PI);
+    /* specular_brdf: (D * V) * fresnel */
+    real dv = o_d_ggx(noh, actual_roughness) * o_v_smith_ggx_correlated(nov, nol, actual_roughness);
+    o_vec3 sbrdf = v3_scale(fresnel, dv);
+
+    o_brdf_result r;
+    r.diffuse = v3_mul(v3_scale(light_intensity, nol), dbrdf);
+    r.specular = v3_mul(v3_scale(light_intensity, nol), sbrdf);
+    return r;
+}
+
+/* glam-pbr/src/lib.rs:454-465 */
+o_vec3 o_compute_f0(real metallic, real ior, o_vec3 diffuse_colour) {
+    real dielectric_f0 = o_to_dielectric_f0(ior);
+    return v3_add(v3_splat((R(1.0) - metallic) * dielectric_f0), v3_scale(diffuse_colour, metallic));
+}
+
+/* ---------------------------------------------------------- shared-structs */
+
+/* shared-structs/src/lib.rs:44-52 */
+void o_light_cluster_coefficients_new(real z_near, real z_far, uint32_t slices,
+                                      tr_light_cluster_coefficients* out) {
+    memset(out, 0, sizeof(*out));
+    out->z_near = z_near;
+    out->z_far = z_far;
+    out->num_depth_slices = slices;
+    out->scale = (real)slices / R_LOG2(z_far / z_near);
+    out->bias = -((real)slices * R_LOG2(z_near) / R_LOG2(z_far / z_near));
+}
+
+/* shared-structs/src/lib.rs:54-63 */
+uint32_t o_get_depth_slice(const tr_light_cluster_coefficients* c, real frag_depth) {
+    real depth_range = R(2.0) * (R(1.0) - frag_depth) - R(1.0);
+    real linear = R(2.0) * c->z_near * c->z_far / (c->z_far + c->z_near - depth_range * (c->z_far - c->z_near));
+    return f32_as_u32(R_MAX(R_LOG2(linear) * c->scale + c->bias, R(0.0)));
+}
+
+/* shared-structs/src/lib.rs:129-138 */
+real o_spotlight_factor(const tr_light* l, o_vec3 direction_to_light) {
+    o_vec3 spot_dir = v3(l->spotlight_direction_and_outer_angle[0], l->spotlight_direction_and_outer_angle[1],
+                         l->spotlight_direction_and_outer_angle[2]);
+    real theta = v3_dot(v3_neg(direction_to_light), spot_dir);
+    real outer_angle = l->spotlight_direction_and_outer_angle[3];
+    real epsilon = l->position_and_spotlight_epsilon[3];
+    return R_MAX((theta - R_COS(outer_angle)) / epsilon, R(0.0));
+}
+
+/* ------------------------------------------------------------ host helpers */
+
+/* src/main.rs:2590-2592 */
+uint32_t o_mip_levels_for_size(uint32_t w, uint32_t h) {
+    uint32_t m = w < h ? w : h;
+    return f32_as_u32(R_LOG2((real)m)) + 1u;
+}
+
+/* src/main.rs:39-54 */
+void o_perspective_matrix_reversed(uint32_t w, uint32_t h, real out[16]) {
+    const real z_near = R(0.01), z_far = R(500.0);
+    real aspect_ratio = (real)w / (real)h;
+    real vertical_fov = R(59.0) * (O_PI / R(180.0));
+    real focal_length = R(1.0) / R_TAN(vertical_fov / R(2.0));
+    real a = z_near / (z_far - z_near);
+    real b = z_far * a;
+    memset(out, 0, 16 * sizeof(real));
+    out[0] = focal_length / aspect_ratio;
+    out[5] = -focal_length;
+    out[10] = a;
+    out[11] = -R(1.0);
+    out[14] = b;
+}
+
+/* src/main.rs:2715-2722 */
+void o_sun_as_normal(real pitch, real yaw, real out[3]) {
+    out[0] = R_COS(pitch) * R_SIN(yaw);
+    out[1] = R_SIN(pitch);
+    out[2] = R_COS(pitch) * R_COS(yaw);
+}
+
+/* ------------------------------------------------------------------- half */
+
+uint16_t o_f32_to_f16(real fr) {
+    float f = (float)fr;
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t mant = x & 0x007FFFFFu;
+    int32_t exp = (int32_t)((x >> 23) & 0xFF);
+    if (exp == 0xFF) return (uint16_t)(sign | 0x7C00u | (mant ? (0x0200u | (mant >> 13)) : 0u));
+    int32_t e = exp - 127 + 15;
+    if (e >= 0x1F) return (uint16_t)(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        mant |= 0x00800000u;
+        uint32_t shift = (uint32_t)(14 - e);
+        uint32_t half_mant = mant >> shift;
+        uint32_t rem = mant & ((1u << shift) - 1u);
+        uint32_t halfway = 1u << (shift - 1u);
+        if (rem > halfway || (rem == halfway && (half_mant & 1u))) half_mant++;
+        return (uint16_t)(sign | half_mant);
+    }
+    uint32_t half = ((uint32_t)e << 10) | (mant >> 13);
+    uint32_t rem = mant & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++; /* may carry into exponent -> inf: correct */
+    return (uint16_t)(sign | half);
+}
+
+real o_f16_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t mant = h & 0x3FFu;
+    uint32_t x;
+    if (exp == 0) {
+        if (mant == 0) {
+            x = sign;
+        } else {
+            int e = -1;
+            do { e++; mant <<= 1; } while (!(mant & 0x400u));
+            x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((mant & 0x3FFu) << 13);
+        }
+    } else if (exp == 0x1F) {
+        x = sign | 0x7F800000u | (mant << 13);
+    } else {
+        x = sign | ((exp - 15 + 127) << 23) | (mant << 13);
+    }
+    float f;
+    memcpy(&f, &x, 4);
+    return (real)f;
+}
+
+/* --------------------------------------------------------------- sampling */
+
+void o_pyramid_layout(uint32_t w, uint32_t h, o_pyramid* out, uint64_t* total_texels) {
+    memset(out, 0, sizeof(*out));
+    out->width = w;
+    out->height = h;
+    out->levels = o_mip_levels_for_size(w, h);
+    if (out->levels > TR_MAX_MIP_LEVELS) out->levels = TR_MAX_MIP_LEVELS;
+    uint64_t off = 0;
+    for (uint32_t l = 0; l < out->levels; ++l) {
+        uint32_t lw = (w >> l) ? (w >> l) : 1u, lh = (h >> l) ? (h >> l) : 1u;
+        out->level_offset[l] = (uint32_t)off;
+        off += (uint64_t)lw * lh;
+    }
+    if (total_texels) *total_texels = off;
+}
+
+static inline uint32_t level_dim(uint32_t d, uint32_t l) { return (d >> l) ? (d >> l) : 1u; }
+
+/* One bilinear tap of one level.  Vulkan "texel filtering", VK_FILTER_LINEAR, CLAMP_TO_EDGE:
+ * x = u*w - 0.5, i0 = floor(x), i1 = i0+1 (both clamped), weight frac(x).  (unpinned: the
+ * spec allows >= 8-bit fixed-point weights; restated with exact fp32 weights, lerp form.) */
+static void bilinear_index(real coord, uint32_t dim, uint32_t* i0, uint32_t* i1, real* frac) {
+    real x = coord * (real)dim - R(0.5);
+    /* clamp to [-1, dim]: identical result for every finite coord, defined for NaN/inf */
+    x = R_MIN(R_MAX(x, -R(1.0)), (real)dim);
+    real fl = R_FLOOR(x);
+    *frac = x - fl;
+    int32_t a = (int32_t)fl;
+    int32_t b = a + 1;
+    int32_t mx = (int32_t)dim - 1;
+    if (a < 0) a = 0;
+    if (a > mx) a = mx;
+    if (b < 0) b = 0;
+    if (b > mx) b = mx;
+    *i0 = (uint32_t)a;
+    *i1 = (uint32_t)b;
+}
+
+static o_vec3 pyramid_bilinear(const o_pyramid* p, uint32_t level, real u, real v) {
+    uint32_t w = level_dim(p->width, level), h = level_dim(p->height, level);
+    const uint16_t* base = p->texels + (size_t)p->level_offset[level] * 4u;
+    uint32_t x0, x1, y0, y1;
+    real fx, fy;
+    bilinear_index(u, w, &x0, &x1, &fx);
+    bilinear_index(v, h, &y0, &y1, &fy);
+    real c[3];
+    for (int k = 0; k < 3; ++k) {
+        real t00 = o_f16_to_f32(base[((size_t)y0 * w + x0) * 4u + k]);
+        real t10 = o_f16_to_f32(base[((size_t)y0 * w + x1) * 4u + k]);
+        real t01 = o_f16_to_f32(base[((size_t)y1 * w + x0) * 4u + k]);
+        real t11 = o_f16_to_f32(base[((size_t)y1 * w + x1) * 4u + k]);
+        real top = t00 + (t10 - t00) * fx;
+        real bot = t01 + (t11 - t01) * fx;
+        c[k] = top + (bot - top) * fy;
+    }
+    return v3(c[0], c[1], c[2]);
+}
+
+/* framebuffer.sample_by_lod(clamp_sampler, uv, lod) (shader/src/lib.rs:135-138); sampler
+ * state src/main.rs:694-705: LINEAR/LINEAR, mip LINEAR, CLAMP_TO_EDGE, lod in [0, levels-1]. */
+o_vec3 o_sample_pyramid(const o_pyramid* p, real u, real v, real lod) {
+    real max_lod = (real)(p->levels - 1u);
+    real l = R_MIN(R_MAX(lod, R(0.0)), max_lod);
+    real lf = R_FLOOR(l);
+    real t = l - lf;
+    uint32_t l0 = (uint32_t)lf;
+    uint32_t l1 = l0 + 1u < p->levels ? l0 + 1u : p->levels - 1u;
+    o_vec3 a = pyramid_bilinear(p, l0, u, v);
+    o_vec3 b = pyramid_bilinear(p, l1, u, v);
+    return v3_add(a, v3_scale(v3_sub(b, a), t));
+}
+
+/* textures[ggx_lut].sample(clamp_sampler, (n.v, roughness)).xy (shader/src/lib.rs:126-133):
+ * single level R8G8B8A8_UNORM (src/main.rs:316), bilinear, clamp-to-edge, texel = byte/255. */
+o_vec2 o_sample_lut(const uint8_t* rgba8, uint32_t w, uint32_t h, real u, real v) {
+    uint32_t x0, x1, y0, y1;
+    real fx, fy;
+    bilinear_index(u, w, &x0, &x1, &fx);
+    bilinear_index(v, h, &y0, &y1, &fy);
+    real c[2];
+    for (int k = 0; k < 2; ++k) {
+        real t00 = (real)rgba8[((size_t)y0 * w + x0) * 4u + k] / R(255.0);
+        real t10 = (real)rgba8[((size_t)y0 * w + x1) * 4u + k] / R(255.0);
+        real t01 = (real)rgba8[((size_t)y1 * w + x0) * 4u + k] / R(255.0);
+        real t11 = (real)rgba8[((size_t)y1 * w + x1) * 4u + k] / R(255.0);
+        real top = t00 + (t10 - t00) * fx;
+        real bot = t01 + (t11 - t01) * fx;
+        c[k] = top + (bot - top) * fy;
+    }
+    o_vec2 r = {c[0], c[1]};
+    return r;
+}
+
+/* generate_mips (call site src/main.rs:2054-2063; body in the un-vendored
+ * ash-opinionated-abstractions@8591c309 => unpinned).  Restated as the vkCmdBlitImage
+ * VK_FILTER_LINEAR chain it presumably is: level l from level l-1, whole-image regions,
+ * dst texel (i,j) samples the source at unnormalised u = (i+0.5)*(ws/wd), linear filter,
+ * clamp to edge; 2x2 box when the source size is even.  fp32 weights/accumulation in the
+ * order (t00*w00 + t10*w10) + (t01*w01 + t11*w11), RTNE store, all four channels. */
+void o_generate_mips(const o_pyramid* p, uint16_t* texels) {
+    for (uint32_t l = 1; l < p->levels; ++l) {
+        uint32_t ws = level_dim(p->width, l - 1), hs = level_dim(p->height, l - 1);
+        uint32_t wd = level_dim(p->width, l), hd = level_dim(p->height, l);
+        const uint16_t* src = texels + (size_t)p->level_offset[l - 1] * 4u;
+        uint16_t* dst = texels + (size_t)p->level_offset[l] * 4u;
+        real sx = (real)ws / (real)wd, sy = (real)hs / (real)hd;
+        for (uint32_t j = 0; j < hd; ++j) {
+            real y = ((real)j + R(0.5)) * sy - R(0.5);
+            real fy0 = R_FLOOR(y);
+            real by = y - fy0;
+            int32_t y0 = (int32_t)fy0, y1 = y0 + 1;
+            if (y0 < 0) y0 = 0;
+            if (y0 > (int32_t)hs - 1) y0 = (int32_t)hs - 1;
+            if (y1 > (int32_t)hs - 1) y1 = (int32_t)hs - 1;
+            for (uint32_t i = 0; i < wd; ++i) {
+                real x = ((real)i + R(0.5)) * sx - R(0.5);
+                real fx0 = R_FLOOR(x);
+                real ax = x - fx0;
+                int32_t x0 = (int32_t)fx0, x1 = x0 + 1;
+                if (x0 < 0) x0 = 0;
+                if (x0 > (int32_t)ws - 1) x0 = (int32_t)ws - 1;
+                if (x1 > (int32_t)ws - 1) x1 = (int32_t)ws - 1;
+                real w00 = (R(1.0) - ax) * (R(1.0) - by), w10 = ax * (R(1.0) - by);
+                real w01 = (R(1.0) - ax) * by, w11 = ax * by;
+                for (int k = 0; k < 4; ++k) {
+                    real t00 = o_f16_to_f32(src[((size_t)y0 * ws + (uint32_t)x0) * 4u + k]);
+                    real t10 = o_f16_to_f32(src[((size_t)y0 * ws + (uint32_t)x1) * 4u + k]);
+                    real t01 = o_f16_to_f32(src[((size_t)y1 * ws + (uint32_t)x0) * 4u + k]);
+                    real t11 = o_f16_to_f32(src[((size_t)y1 * ws + (uint32_t)x1) * 4u + k]);
+                    real r = (t00 * w00 + t10 * w10) + (t01 * w01 + t11 * w11);
+                    dst[((size_t)j * wd + i) * 4u + k] = o_f32_to_f16(r);
+                }
+            }
+        }
+    }
+}
+
+/* --------------------------------------------------- fragment entry points */
+
+static o_vec3 f3(const float* p) { return v3(p[0], p[1], p[2]); }
+
+/* shader/src/lighting.rs:261-301 (untextured: every `textures.* == -1`) */
+static o_material_params get_material_params(const float diffuse[4], const tr_material_info* m) {
+    o_material_params mp;
+    mp.diffuse_colour = v3(diffuse[0], diffuse[1], diffuse[2]);
+    mp.metallic = m->metallic_factor;
+    mp.perceptual_roughness = m->roughness_factor;
+    mp.index_of_refraction = m->index_of_refraction;
+    mp.specular_colour = f3(m->specular_colour_factor);
+    mp.specular_factor = m->specular_factor;
+    return mp;
+}
+
+/* cluster index: shader/src/lib.rs:88-98 / 205-215 */
+static uint32_t cluster_index(const tr_uniforms* u, const real frag_coord[4]) {
+    uint32_t cx = f32_as_u32(frag_coord[0] / u->cluster_size_in_pixels[0]);
+    uint32_t cy = f32_as_u32(frag_coord[1] / u->cluster_size_in_pixels[1]);
+    uint32_t cz = o_get_depth_slice(&u->light_clustering_coefficients, frag_coord[2]);
+    return cz * u->num_clusters[0] * u->num_clusters[1] + cy * u->num_clusters[0] + cx;
+}
+
+/* storage-buffer reads out of range behave like robustBufferAccess (read 0): the reference
+ * indexes unchecked (shader/src/lib.rs:393-395) and get_depth_slice is not clamped above. */
+static uint32_t cluster_count(const o_scene* s, uint32_t cluster) {
+    return cluster < s->num_clusters_total ? s->cluster_light_counts[cluster] : 0u;
+}
+
+static const o_vec3 DEBUG_COLOURS[15] = { /* shader/src/lib.rs:647-664 */
+    {R(0.0), R(0.0), R(0.0)},      {R(0.0), R(0.0), R(0.1647)},   {R(0.0), R(0.0), R(0.3647)}, {R(0.0), R(0.0), R(0.6647)},
+    {R(0.0), R(0.0), R(0.9647)},   {R(0.0), R(0.9255), R(0.9255)}, {R(0.0), R(0.5647), R(0.0)}, {R(0.0), R(0.7843), R(0.0)},
+    {R(1.0), R(1.0), R(0.0)},      {R(0.90588), R(0.75294), R(0.0)}, {R(1.0), R(0.5647), R(0.0)}, {R(1.0), R(0.0), R(0.0)},
+    {R(0.8392), R(0.0), R(0.0)},   {R(1.0), R(0.0), R(1.0)},      {R(0.6), R(0.3333), R(0.7882)}};
+
+/* shader/src/lib.rs:164-249 */
+void o_fragment(const o_scene* s, o_vec3 position, o_vec3 normal_in, o_vec2 uv, uint32_t material_id,
+                const real frag_coord[4], real out_rgba[4]) {
+    (void)uv;
+    const tr_material_info* material = &s->materials[material_id];
+    const tr_uniforms* u = &s->uniforms;
+    const float* diffuse = material->diffuse_factor;
+
+    o_vec3 view_vector = v3_sub(f3(s->push.view_position), position);
+    o_vec3 view = v3_normalize(view_vector);
+    o_vec3 normal = v3_normalize(normal_in); /* calculate_normal, lighting.rs:222-241, no normal map */
+    o_material_params mp = get_material_params(diffuse, material);
+    o_vec3 emission = f3(material->emissive_factor); /* get_emission, lighting.rs:303-313 */
+
+    uint32_t cluster = cluster_index(u, frag_coord);
+    uint32_t num_lights = cluster_count(s, cluster);
+
+    /* evaluate_lights, lighting.rs:145-220 */
+    o_vec3 sun_dir = f3(u->sun_dir);
+    o_vec3 sun_intensity = v3_scale(f3(u->sun_intensity), R(1.0));
+    o_brdf_result sum = o_basic_brdf(normal, sun_dir, sun_intensity, view, mp);
+    uint32_t offset = cluster * TR_MAX_LIGHTS_PER_CLUSTER;
+    for (uint32_t cur = offset; cur < offset + num_lights; ++cur) {
+        const tr_light* light = &s->lights[s->light_indices[cur]];
+        o_vec3 direction;
+        real distance, attenuation;
+        o_light_direction_and_attenuation(position, f3(light->position_and_spotlight_epsilon),
+                                          &direction, &distance, &attenuation);
+        real factor = R(1.0);
+        if (light->spotlight_direction_and_outer_angle[3] != R(0.0)) factor *= o_spotlight_factor(light, direction);
+        o_vec3 light_emission = v3_scale(f3(light->colour_emission_and_falloff_distance_sq), factor);
+        o_brdf_result r = o_basic_brdf(normal, direction, v3_scale(light_emission, attenuation), view, mp);
+        sum.diffuse = v3_add(sum.diffuse, r.diffuse);
+        sum.specular = v3_add(sum.specular, r.specular);
+    }
+
+    o_vec3 out = v3_add(v3_add(sum.diffuse, sum.specular), emission);
+    if (u->debug_clusters != 0u) { /* :241-245 */
+        o_vec3 a = DEBUG_COLOURS[num_lights % 15u];
+        o_vec3 b = DEBUG_COLOURS[cluster % 15u];
+        out = v3_add(a, v3_scale(v3_add_s(b, -R(0.5)), R(0.025)));
+    }
+    out_rgba[0] = out.x;
+    out_rgba[1] = out.y;
+    out_rgba[2] = out.z;
+    out_rgba[3] = R(1.0);
+}
+
+typedef struct { const o_pyramid* p; } fb_user_t;
+typedef struct { const o_scene* s; } lut_user_t;
+
+static o_vec3 fb_sampler_cb(void* user, o_vec2 uv, real lod) {
+    return o_sample_pyramid(((fb_user_t*)user)->p, uv.x, uv.y, lod);
+}
+static o_vec2 lut_sampler_cb(void* user, real nov, real roughness) {
+    const o_scene* s = ((lut_user_t*)user)->s;
+    return o_sample_lut(s->ggx_lut_rgba8, s->lut_width, s->lut_height, nov, roughness);
+}
+
+/* shader/src/lib.rs:37-162 */
+void o_fragment_transmission(const o_scene* s, const o_pyramid* framebuffer, o_vec3 position,
+                             o_vec3 normal_in, o_vec2 uv, uint32_t material_id, real model_scale,
+                             const real frag_coord[4], real out_rgba[4]) {
+    (void)uv;
+    const tr_material_info* material = &s->materials[material_id];
+    const tr_uniforms* u = &s->uniforms;
+    const float* diffuse = material->diffuse_factor;
+    real transmission_factor = material->transmission_factor;
+
+    o_vec3 view_vector = v3_sub(f3(s->push.view_position), position);
+    o_vec3 view = v3_normalize(view_vector);
+    o_vec3 normal = v3_normalize(normal_in);
+    o_material_params mp = get_material_params(diffuse, material);
+    o_vec3 emission = f3(material->emissive_factor);
+
+    uint32_t cluster = cluster_index(u, frag_coord);
+    uint32_t num_lights = cluster_count(s, cluster);
+
+    /* evaluate_lights_transmission, lighting.rs:13-95 (no spotlight factor here) */
+    o_vec3 sun_dir = f3(u->sun_dir);
+    o_vec3 sun_intensity = v3_scale(f3(u->sun_intensity), R(1.0));
+    o_brdf_result sum = o_basic_brdf(normal, sun_dir, sun_intensity, view, mp);
+    o_vec3 transmission = v3_mul(sun_intensity, o_transmission_btdf(mp, normal, view, sun_dir));
+    uint32_t offset = cluster * TR_MAX_LIGHTS_PER_CLUSTER;
+    for (uint32_t cur = offset; cur < offset + num_lights; ++cur) {
+        const tr_light* light = &s->lights[s->light_indices[cur]];
+        o_vec3 direction;
+        real distance, attenuation;
+        o_light_direction_and_attenuation(position, f3(light->position_and_spotlight_epsilon),
+                                          &direction, &distance, &attenuation);
+        o_vec3 light_emission = v3_scale(f3(light->colour_emission_and_falloff_distance_sq), R(1.0));
+        o_brdf_result r = o_basic_brdf(normal, direction, v3_scale(light_emission, attenuation), view, mp);
+        sum.diffuse = v3_add(sum.diffuse, r.diffuse);
+        sum.specular = v3_add(sum.specular, r.specular);
+        transmission = v3_add(transmission, v3_mul(v3_scale(light_emission, attenuation),
+                                                   o_transmission_btdf(mp, normal, view, direction)));
+    }
+
+    real thickness = material->thickness_factor;
+
+    o_ibl_volume_refraction_params ip;
+    ip.material_params = mp;
+    ip.framebuffer_size_x = s->push.framebuffer_size[0];
+    ip.normal = normal;
+    ip.view = view;
+    for (int k = 0; k < 16; ++k) ip.proj_view_matrix[k] = (real)s->push.proj_view[k];
+    ip.position = position;
+    ip.thickness = thickness;
+    ip.model_scale = model_scale;
+    ip.attenuation_distance = material->attenuation_distance;
+    ip.attenuation_colour = f3(material->attenuation_colour);
+    fb_user_t fbu = {framebuffer};
+    lut_user_t lu = {s};
+    transmission = v3_add(transmission, o_ibl_volume_refraction(&ip, fb_sampler_cb, &fbu, lut_sampler_cb, &lu));
+
+    /* :157-161 (transmission factor applied twice: reference behaviour) */
+    o_vec3 real_transmission = v3_scale(transmission, transmission_factor);
+    o_vec3 diffuse_out = v3_lerp(sum.diffuse, real_transmission, transmission_factor);
+    o_vec3 out = v3_add(v3_add(diffuse_out, sum.specular), emission);
+    out_rgba[0] = out.x;
+    out_rgba[1] = out.y;
+    out_rgba[2] = out.z;
+    out_rgba[3] = R(1.0);
+}
+
+/* ------------------------------------------------------------ whole passes */
+
+typedef struct {
+    const o_scene* s;
+    const o_gbuffer* g;
+    const o_pyramid* fb;
+    tr_rect rect;
+    uint32_t y_begin, y_end;
+    uint16_t* hdr_f16;
+    real* hdr_f32;
+    uint16_t* mip0_f16;
+    int transmissive;
+} band_job;
+
+static void* band_worker(void* arg) {
+    band_job* j = (band_job*)arg;
+    const o_gbuffer* g = j->g;
+    for (uint32_t y = j->y_begin; y < j->y_end; ++y) {
+        for (uint32_t x = j->rect.x0; x < j->rect.x1; ++x) {
+            /* planes hold the tile at (origin_x, origin_y); colour targets are whole-frame */
+            size_t i = (size_t)(y - g->origin_y) * g->width + (x - g->origin_x);
+            size_t o = (size_t)y * j->s->push.framebuffer_size[0] + x;
+            uint32_t mat = g->material_id[i];
+            real rgba[4];
+            if (mat == TR_NOT_COVERED) {
+                if (j->transmissive) continue; /* attachment LOAD: keep */
+                rgba[0] = rgba[1] = rgba[2] = R(0.0); /* clear colour, src/main.rs:1592-1601 */
+                rgba[3] = R(1.0);
+            } else {
+                o_vec3 pos = f3(&g->pos_depth[i * 4]);
+                o_vec3 nrm = f3(&g->nrm_scale[i * 4]);
+                o_vec2 uv = {g->uv[i * 2], g->uv[i * 2 + 1]};
+                real frag_coord[4] = {(real)x + R(0.5), (real)y + R(0.5), g->pos_depth[i * 4 + 3], R(1.0)};
+                if (j->transmissive)
+                    o_fragment_transmission(j->s, j->fb, pos, nrm, uv, mat, g->nrm_scale[i * 4 + 3], frag_coord, rgba);
+                else
+                    o_fragment(j->s, pos, nrm, uv, mat, frag_coord, rgba);
+            }
+            for (int k = 0; k < 4; ++k) {
+                if (j->hdr_f32) j->hdr_f32[o * 4 + k] = rgba[k];
+                if (j->hdr_f16) j->hdr_f16[o * 4 + k] = o_f32_to_f16(rgba[k]);
+                if (j->mip0_f16) j->mip0_f16[o * 4 + k] = o_f32_to_f16(rgba[k]);
+            }
+        }
+    }
+    return NULL;
+}
+
+static void run_bands(band_job proto, int nthreads) {
+    uint32_t rows = proto.rect.y1 - proto.rect.y0;
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > rows) nthreads = rows ? (int)rows : 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    band_job* jobs = (band_job*)malloc(sizeof(band_job) * (size_t)nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t] = proto;
+        jobs[t].y_begin = proto.rect.y0 + (uint32_t)(((uint64_t)rows * (uint64_t)t) / (uint64_t)nthreads);
+        jobs[t].y_end = proto.rect.y0 + (uint32_t)(((uint64_t)rows * (uint64_t)(t + 1)) / (uint64_t)nthreads);
+        if (nthreads == 1) band_worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, band_worker, &jobs[t]);
+    }
+    if (nthreads > 1)
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+}
+
+void o_shade_opaque(const o_scene* s, const o_gbuffer* g, tr_rect rect,
+                    uint16_t* hdr_f16, real* hdr_f32, uint16_t* opaque_mip0_f16, int nthreads) {
+    band_job j;
+    memset(&j, 0, sizeof(j));
+    j.s = s; j.g = g; j.rect = rect; j.hdr_f16 = hdr_f16; j.hdr_f32 = hdr_f32; j.mip0_f16 = opaque_mip0_f16;
+    j.transmissive = 0;
+    run_bands(j, nthreads);
+}
+
+void o_shade_transmission(const o_scene* s, const o_gbuffer* g, const o_pyramid* framebuffer, tr_rect rect,
+                          uint16_t* hdr_f16, real* hdr_f32, int nthreads) {
+    band_job j;
+    memset(&j, 0, sizeof(j));
+    j.s = s; j.g = g; j.fb = framebuffer; j.rect = rect; j.hdr_f16 = hdr_f16; j.hdr_f32 = hdr_f32;
+    j.transmissive = 1;
+    run_bands(j, nthreads);
+}

@@ -1,0 +1,157 @@
+/*
+ * tr_oracle.h — CPU restatement (plain C, scalar IEEE fp32) of the reference's
+ * opaque -> mip chain -> transmissive shading path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load it, and
+ * only as the checker / the reported CPU baseline.  The product (libtr_shade.so) never
+ * links, loads or calls it.
+ *
+ * Pinning: the reference (expenses/transmission-renderer) ships no tests, golden
+ * vectors or fixtures, and neither Rust nor Vulkan exist in the build image, so the
+ * Rust sources cannot be run.  What CAN be run are the reference's own committed
+ * SPIR-V binaries: oracle/spirv_ref/ interprets the .spv files of compiled-shaders/normal
+ * word by word (fixed-function sampling restated, see there) and the fixtures under
+ * tests/golden/ were produced that way.  tests/test_oracle_vs_spirv.py pins every
+ * entry point of this file against those fixtures.  Steps with no in-tree definition
+ * (mip blit filter, texel filtering weights, real->half rounding) are restated from
+ * the Vulkan specification and are called out as "unpinned" where they occur.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference root).  Build: see oracle/Makefile (-ffp-contract=off, no fast-math).
+ */
+#ifndef TR_ORACLE_H
+#define TR_ORACLE_H
+
+#include <stdint.h>
+#include "../include/tr_shade.h" /* wire-struct layouts only */
+
+/* `real` is float in libtr_oracle.so (the reference's fp32 semantics: THE oracle) and double in
+ * libtr_oracle64.so (same formulas in fp64: used only to measure how much of a pixel's value is
+ * fp32 rounding noise of the reference's own formulas, i.e. how ill-conditioned it is). */
+#if defined(O_REAL_DOUBLE)
+typedef double real;
+#else
+typedef float real;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { real x, y, z; } o_vec3;
+typedef struct { real x, y; } o_vec2;
+
+/* glam-pbr/src/lib.rs:163-171 `MaterialParams` */
+typedef struct {
+    o_vec3 diffuse_colour;
+    real  metallic;
+    real  perceptual_roughness;
+    real  index_of_refraction;
+    o_vec3 specular_colour;
+    real  specular_factor;
+} o_material_params;
+
+/* glam-pbr/src/lib.rs:437-441 `BrdfResult` */
+typedef struct { o_vec3 diffuse, specular; } o_brdf_result;
+
+/* glam-pbr/src/lib.rs:235-246 `IblVolumeRefractionParams` */
+typedef struct {
+    o_material_params material_params;
+    uint32_t framebuffer_size_x;
+    o_vec3 normal;
+    o_vec3 view;
+    real  proj_view_matrix[16]; /* column-major */
+    o_vec3 position;
+    real  thickness;
+    real  model_scale;
+    real  attenuation_distance;
+    o_vec3 attenuation_colour;
+} o_ibl_volume_refraction_params;
+
+typedef o_vec3 (*o_framebuffer_sampler)(void* user, o_vec2 uv, real lod);
+typedef o_vec2 (*o_ggx_lut_sampler)(void* user, real normal_dot_view, real perceptual_roughness);
+
+/* ---- glam-pbr public API (glam-pbr/src/lib.rs) ---- */
+void   o_light_direction_and_attenuation(o_vec3 fragment_position, o_vec3 light_position,
+                                         o_vec3* direction, real* distance, real* attenuation);
+real  o_dot_clamped(o_vec3 a, o_vec3 b);                         /* Dot::new :93-98 */
+real  o_d_ggx(real noh, real actual_roughness);                /* :101-109 */
+real  o_v_smith_ggx_correlated(real nov, real nol, real actual_roughness); /* :114-133 */
+o_vec3 o_fresnel_schlick(real voh, o_vec3 f0, o_vec3 f90);       /* :137-139 */
+real  o_to_dielectric_f0(real ior);                             /* :190-195 */
+o_vec3 o_transmission_btdf(o_material_params m, o_vec3 normal, o_vec3 view, o_vec3 light); /* :200-233 */
+o_vec3 o_refract(o_vec3 incident, o_vec3 normal, real ior);      /* :248-256 */
+o_vec3 o_apply_volume_attenuation(o_vec3 transmitted_light, real transmission_distance,
+                                  real attenuation_distance, o_vec3 attenuation_colour); /* :275-290 */
+o_vec3 o_ibl_volume_refraction(const o_ibl_volume_refraction_params* p,
+                               o_framebuffer_sampler fb, void* fb_user,
+                               o_ggx_lut_sampler lut, void* lut_user);     /* :292-354 */
+o_brdf_result o_basic_brdf(o_vec3 normal, o_vec3 light, o_vec3 light_intensity, o_vec3 view,
+                           o_material_params m);                  /* :377-423 */
+o_vec3 o_compute_f0(real metallic, real ior, o_vec3 diffuse_colour); /* :454-465 */
+
+/* ---- shared-structs helpers ---- */
+void     o_light_cluster_coefficients_new(real z_near, real z_far, uint32_t slices,
+                                          tr_light_cluster_coefficients* out);  /* shared-structs:44-52 */
+uint32_t o_get_depth_slice(const tr_light_cluster_coefficients* c, real frag_depth); /* :54-63 */
+real    o_spotlight_factor(const tr_light* l, o_vec3 direction_to_light);      /* :129-138 */
+
+/* ---- host helpers on the path ---- */
+uint32_t o_mip_levels_for_size(uint32_t w, uint32_t h);           /* src/main.rs:2590-2592 */
+void     o_perspective_matrix_reversed(uint32_t w, uint32_t h, real out_colmajor[16]); /* src/main.rs:39-54 */
+void     o_sun_as_normal(real pitch, real yaw, real out[3]);   /* src/main.rs:2715-2722 */
+
+/* ---- half conversion (RTNE; rounding mode is unpinned in Vulkan) ---- */
+uint16_t o_f32_to_f16(real f);
+real    o_f16_to_f32(uint16_t h);
+
+/* ---- fixed-function sampling restated from the Vulkan spec (unpinned) ---- */
+typedef struct {
+    const uint16_t* texels;   /* RGBA16F, levels packed as tr_pyramid */
+    uint32_t width, height, levels;
+    uint32_t level_offset[TR_MAX_MIP_LEVELS];
+} o_pyramid;
+
+void   o_pyramid_layout(uint32_t w, uint32_t h, o_pyramid* out, uint64_t* total_texels);
+o_vec3 o_sample_pyramid(const o_pyramid* p, real u, real v, real lod);  /* clamp_sampler, trilinear */
+o_vec2 o_sample_lut(const uint8_t* rgba8, uint32_t w, uint32_t h, real u, real v); /* bilinear, clamp */
+void   o_generate_mips(const o_pyramid* p, uint16_t* texels);      /* generate_mips, src/main.rs:2054 */
+
+/* ---- scene tables shared by both fragment entry points ---- */
+typedef struct {
+    const tr_material_info* materials;  uint32_t num_materials;
+    const tr_light* lights;             uint32_t num_lights;
+    const uint32_t* cluster_light_counts;
+    const uint32_t* light_indices;
+    uint32_t num_clusters_total;
+    const uint8_t* ggx_lut_rgba8; uint32_t lut_width, lut_height;
+    tr_uniforms uniforms;
+    tr_push_constants push;
+} o_scene;
+
+/* shader/src/lib.rs:164-249 `fragment` (untextured materials: every Textures id == -1). */
+void o_fragment(const o_scene* s, o_vec3 position, o_vec3 normal, o_vec2 uv, uint32_t material_id,
+                const real frag_coord[4], real out_rgba[4]);
+/* shader/src/lib.rs:37-162 `fragment_transmission` (untextured materials). */
+void o_fragment_transmission(const o_scene* s, const o_pyramid* framebuffer, o_vec3 position,
+                             o_vec3 normal, o_vec2 uv, uint32_t material_id, real model_scale,
+                             const real frag_coord[4], real out_rgba[4]);
+
+/* ---- whole passes over TGB-v1 planes (host memory). out_f32 (optional) receives the
+ *      un-rounded fp32 RGBA; out_f16 (optional) the RTNE RGBA16F target. ---- */
+typedef struct {
+    const float* pos_depth; const float* nrm_scale; const float* uv; const uint32_t* material_id;
+    uint32_t width, height;      /* plane size */
+    uint32_t origin_x, origin_y; /* frame position of plane element (0,0), as tr_gbuffer */
+} o_gbuffer;
+
+void o_shade_opaque(const o_scene* s, const o_gbuffer* g, tr_rect rect,
+                    uint16_t* hdr_f16, real* hdr_f32, uint16_t* opaque_mip0_f16, int nthreads);
+void o_shade_transmission(const o_scene* s, const o_gbuffer* g, const o_pyramid* framebuffer, tr_rect rect,
+                          uint16_t* hdr_f16, real* hdr_f32, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

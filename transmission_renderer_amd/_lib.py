@@ -1,0 +1,81 @@
+"""ctypes binding of libtr_shade.so (include/tr_shade.h).
+
+There is no fallback: if the HIP library has not been built (`python __graft_entry__.py` or
+`make -C transmission_renderer_amd/csrc`) or cannot be loaded, importing the shading path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import wire
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtr_shade.so")
+
+# Every symbol include/tr_shade.h declares (tests check the .so exports exactly these).
+SYMBOLS = (
+    "tr_abi_version", "tr_status_string", "tr_last_hip_error", "tr_context_create", "tr_context_destroy",
+    "tr_pyramid_layout", "tr_upload_materials", "tr_upload_lights", "tr_set_cluster_tables",
+    "tr_upload_ggx_lut", "tr_shade_opaque", "tr_generate_mips", "tr_shade_transmission",
+)
+
+_lib = None
+
+
+class TrError(RuntimeError):
+    def __init__(self, status: int, where: str, hip_error: int = 0):
+        self.status = status
+        self.hip_error = hip_error
+        msg = load().tr_status_string(status).decode()
+        super().__init__(f"{where}: {msg} (status {status}, hipError {hip_error})")
+
+
+def load() -> C.CDLL:
+    """Loads libtr_shade.so once.  torch is imported first so both share one HIP runtime
+    (torch bundles libamdhip64.so.7; the soname is resolved to the copy already in the process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "This package has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads the HIP runtime this process will use)
+    except Exception:  # pragma: no cover - torch is plumbing, the library itself does not need it
+        pass
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+    lib.tr_abi_version.restype = u32
+    lib.tr_status_string.restype = C.c_char_p
+    lib.tr_status_string.argtypes = [i32]
+    lib.tr_last_hip_error.restype = i32
+    lib.tr_last_hip_error.argtypes = [vp]
+    lib.tr_context_create.restype = i32
+    lib.tr_context_create.argtypes = [i32, C.POINTER(vp)]
+    lib.tr_context_destroy.restype = i32
+    lib.tr_context_destroy.argtypes = [vp]
+    lib.tr_pyramid_layout.restype = i32
+    lib.tr_pyramid_layout.argtypes = [u32, u32, C.POINTER(wire.Pyramid), C.POINTER(C.c_size_t)]
+    lib.tr_upload_materials.restype = i32
+    lib.tr_upload_materials.argtypes = [vp, C.POINTER(wire.MaterialInfo), u32, vp]
+    lib.tr_upload_lights.restype = i32
+    lib.tr_upload_lights.argtypes = [vp, C.POINTER(wire.Light), u32, vp]
+    lib.tr_set_cluster_tables.restype = i32
+    lib.tr_set_cluster_tables.argtypes = [vp, vp, vp, u32]
+    lib.tr_upload_ggx_lut.restype = i32
+    lib.tr_upload_ggx_lut.argtypes = [vp, C.c_void_p, u32, u32, vp]
+    lib.tr_shade_opaque.restype = i32
+    lib.tr_shade_opaque.argtypes = [vp, C.POINTER(wire.GBuffer), C.POINTER(wire.Uniforms),
+                                    C.POINTER(wire.PushConstants), vp, i32, vp, wire.Rect, vp]
+    lib.tr_generate_mips.restype = i32
+    lib.tr_generate_mips.argtypes = [vp, C.POINTER(wire.Pyramid), vp]
+    lib.tr_shade_transmission.restype = i32
+    lib.tr_shade_transmission.argtypes = [vp, C.POINTER(wire.GBuffer), C.POINTER(wire.Uniforms),
+                                          C.POINTER(wire.PushConstants), C.POINTER(wire.Pyramid), vp, i32,
+                                          wire.Rect, vp]
+    if lib.tr_abi_version() != 1:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.tr_abi_version()} != 1")
+    _lib = lib
+    return lib

@@ -1,0 +1,398 @@
+// tr_shade.hip — C ABI (include/tr_shade.h) over the gfx950 kernels in tr_kernels.h.
+//
+// Host side of the boundary: owns the digested tables (materials, lights, GGX LUT pair table,
+// pyramid level table) in HBM, validates arguments, and enqueues kernels on the caller's
+// stream.  Nothing here computes pixels on the CPU; without a HIP device tr_context_create
+// fails with TR_ERR_NO_DEVICE and every other entry point needs a context.
+#include "tr_kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace tr;
+
+struct tr_context {
+    int device = 0;
+    int32_t last_hip_error = 0;
+
+    // materials
+    tr_material_info* d_materials_raw = nullptr;
+    tr_dmat* d_dmats = nullptr;
+    uint32_t num_materials = 0, cap_materials = 0;
+    bool dmats_dirty = false;
+    std::vector<tr_material_info> stage_materials;
+
+    // lights
+    tr_dlight* d_lights = nullptr;
+    uint32_t num_lights = 0, cap_lights = 0;
+    std::vector<tr_dlight> stage_lights;
+
+    // cluster tables (borrowed)
+    const uint32_t* d_cluster_counts = nullptr;
+    const uint32_t* d_light_indices = nullptr;
+    uint32_t num_clusters_total = 0;
+
+    // GGX LUT
+    uint32_t* d_lut_rgba8 = nullptr;
+    uint32_t* d_lut_pairs = nullptr;
+    uint32_t lut_w = 0, lut_h = 0, lut_stride = 0;
+    std::vector<uint8_t> stage_lut;
+
+    // pyramid level table
+    tr_level_table* d_levels = nullptr;
+    tr_level_table h_levels{};
+    uint32_t h_levels_count = 0;
+};
+
+namespace {
+
+#define TR_HIP(ctx, expr)                                   \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) {                             \
+            if (ctx) (ctx)->last_hip_error = (int32_t)e_;   \
+            return TR_ERR_HIP;                              \
+        }                                                   \
+    } while (0)
+
+inline uint32_t level_dim(uint32_t d, uint32_t l) { return (d >> l) ? (d >> l) : 1u; }
+
+// mip_levels_for_size, src/main.rs:2590-2592: (min(w,h) as f32).log2() as u32 + 1
+uint32_t mip_levels_for_size(uint32_t w, uint32_t h) {
+    uint32_t m = w < h ? w : h;
+    float l = std::log2((float)m);
+    uint32_t li = (l > 0.0f) ? (uint32_t)l : 0u;
+    return li + 1u;
+}
+
+tr_status ensure_digested(tr_context* ctx, hipStream_t stream) {
+    if (!ctx->dmats_dirty) return TR_OK;
+    if (ctx->num_materials == 0 || ctx->lut_h == 0) return TR_ERR_TABLES_MISSING;
+    uint32_t n = ctx->num_materials;
+    hipLaunchKernelGGL(digest_materials_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, ctx->d_materials_raw,
+                       ctx->d_dmats, n, ctx->lut_h, ctx->lut_stride);
+    TR_HIP(ctx, hipGetLastError());
+    ctx->dmats_dirty = false;
+    return TR_OK;
+}
+
+tr_status ensure_levels(tr_context* ctx, const tr_pyramid* p, hipStream_t stream) {
+    bool same = ctx->h_levels_count == p->levels;
+    for (uint32_t l = 0; same && l < p->levels; ++l)
+        same = ctx->h_levels.offset[l] == p->level_offset[l] && ctx->h_levels.width[l] == level_dim(p->width, l) &&
+               ctx->h_levels.height[l] == level_dim(p->height, l);
+    if (same) return TR_OK;
+    std::memset(&ctx->h_levels, 0, sizeof(ctx->h_levels));
+    for (uint32_t l = 0; l < p->levels; ++l) {
+        ctx->h_levels.offset[l] = p->level_offset[l];
+        ctx->h_levels.width[l] = level_dim(p->width, l);
+        ctx->h_levels.height[l] = level_dim(p->height, l);
+    }
+    ctx->h_levels_count = p->levels;
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_levels, &ctx->h_levels, sizeof(tr_level_table), hipMemcpyHostToDevice, stream));
+    return TR_OK;
+}
+
+tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u,
+                            const tr_push_constants* pc, tr_rect rect, tr_frame_params* fp) {
+    const uint32_t fw = pc->framebuffer_size[0], fh = pc->framebuffer_size[1];
+    if (rect.x0 >= rect.x1 || rect.y0 >= rect.y1 || rect.x1 > fw || rect.y1 > fh) return TR_ERR_INVALID_ARGUMENT;
+    if (rect.x0 < g->origin_x || rect.y0 < g->origin_y || rect.x1 > g->origin_x + g->width ||
+        rect.y1 > g->origin_y + g->height)
+        return TR_ERR_INVALID_ARGUMENT;  // the tile must be covered by the planes this rank holds
+    std::memset(fp, 0, sizeof(*fp));
+    std::memcpy(fp->proj_view, pc->proj_view, sizeof(fp->proj_view));
+    std::memcpy(fp->view_position, pc->view_position, sizeof(fp->view_position));
+    fp->log2_fb_width = std::log2((float)pc->framebuffer_size[0]);  // glam-pbr/src/lib.rs:334
+    std::memcpy(fp->sun_dir, u->sun_dir, sizeof(fp->sun_dir));
+    std::memcpy(fp->sun_intensity, u->sun_intensity, sizeof(fp->sun_intensity));
+    fp->z_near = u->light_clustering_coefficients.z_near;
+    fp->z_far = u->light_clustering_coefficients.z_far;
+    fp->lcc_scale = u->light_clustering_coefficients.scale;
+    fp->lcc_bias = u->light_clustering_coefficients.bias;
+    fp->cluster_size_px[0] = u->cluster_size_in_pixels[0];
+    fp->cluster_size_px[1] = u->cluster_size_in_pixels[1];
+    fp->num_clusters_x = u->num_clusters[0];
+    fp->num_clusters_y = u->num_clusters[1];
+    fp->num_clusters_total = ctx->num_clusters_total;
+    fp->debug_clusters = u->debug_clusters;
+    fp->width = fw;
+    fp->height = fh;
+    fp->g_width = g->width;
+    fp->g_origin_x = g->origin_x;
+    fp->g_origin_y = g->origin_y;
+    fp->rect_x0 = rect.x0;
+    fp->rect_y0 = rect.y0;
+    fp->rect_x1 = rect.x1;
+    fp->rect_y1 = rect.y1;
+    fp->tiles_x = (rect.x1 - rect.x0 + 63u) / 64u;
+    fp->tiles_y = (rect.y1 - rect.y0 + 3u) / 4u;
+    fp->lut_width = ctx->lut_w;
+    fp->lut_height = ctx->lut_h;
+    fp->lut_stride = ctx->lut_stride;
+    return TR_OK;
+}
+
+tr_tables make_tables(const tr_context* ctx) {
+    tr_tables tb;
+    tb.dmats = ctx->d_dmats;
+    tb.lights = ctx->d_lights;
+    tb.cluster_counts = ctx->d_cluster_counts;
+    tb.light_indices = ctx->d_light_indices;
+    tb.lut_pairs = ctx->d_lut_pairs;
+    tb.levels = ctx->d_levels;
+    return tb;
+}
+
+bool tables_ready(const tr_context* ctx, bool need_lut) {
+    return ctx->num_materials > 0 && ctx->d_cluster_counts && ctx->d_light_indices && ctx->num_clusters_total > 0 &&
+           (!need_lut || ctx->d_lut_pairs) && ctx->lut_h > 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t tr_abi_version(void) { return TR_ABI_VERSION; }
+
+const char* tr_status_string(tr_status status) {
+    switch (status) {
+        case TR_OK: return "ok";
+        case TR_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case TR_ERR_NO_DEVICE: return "no HIP device (this library has no CPU path)";
+        case TR_ERR_HIP: return "HIP runtime error (see tr_last_hip_error)";
+        case TR_ERR_TABLES_MISSING: return "pass launched before its tables were uploaded";
+        case TR_ERR_OUT_OF_MEMORY: return "out of memory";
+        case TR_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+int32_t tr_last_hip_error(const tr_context* ctx) { return ctx ? ctx->last_hip_error : 0; }
+
+tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
+    if (!out_ctx) return TR_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return TR_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= count) return TR_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return TR_ERR_NO_DEVICE;
+    tr_context* ctx = new (std::nothrow) tr_context();
+    if (!ctx) return TR_ERR_OUT_OF_MEMORY;
+    ctx->device = device_ordinal;
+    if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess) {
+        delete ctx;
+        return TR_ERR_OUT_OF_MEMORY;
+    }
+    *out_ctx = ctx;
+    return TR_OK;
+}
+
+tr_status tr_context_destroy(tr_context* ctx) {
+    if (!ctx) return TR_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ctx->d_materials_raw);
+    (void)hipFree(ctx->d_dmats);
+    (void)hipFree(ctx->d_lights);
+    (void)hipFree(ctx->d_lut_rgba8);
+    (void)hipFree(ctx->d_lut_pairs);
+    (void)hipFree(ctx->d_levels);
+    delete ctx;
+    return TR_OK;
+}
+
+tr_status tr_pyramid_layout(uint32_t width, uint32_t height, tr_pyramid* out, size_t* out_bytes) {
+    if (!out || width == 0 || height == 0) return TR_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof(*out));
+    out->width = width;
+    out->height = height;
+    uint32_t levels = mip_levels_for_size(width, height);
+    if (levels > TR_MAX_MIP_LEVELS) levels = TR_MAX_MIP_LEVELS;
+    out->levels = levels;
+    uint64_t off = 0;
+    for (uint32_t l = 0; l < levels; ++l) {
+        out->level_offset[l] = (uint32_t)off;
+        off += (uint64_t)level_dim(width, l) * level_dim(height, l);
+    }
+    if (off > 0xFFFFFFFFull) return TR_ERR_UNSUPPORTED;
+    if (out_bytes) *out_bytes = (size_t)off * 8u;
+    return TR_OK;
+}
+
+tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials_host, uint32_t count, void* stream_) {
+    if (!ctx || !materials_host || count == 0) return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < count; ++i) {
+        const tr_textures& t = materials_host[i].textures;
+        // Material textures (shader/src/lighting.rs:222-313 with ids != -1) are not on this build's path yet.
+        if (t.diffuse != -1 || t.metallic_roughness != -1 || t.normal_map != -1 || t.emissive != -1 ||
+            t.transmission != -1 || t.thickness != -1 || t.specular != -1 || t.specular_colour != -1)
+            return TR_ERR_UNSUPPORTED;
+    }
+    if (count > ctx->cap_materials) {
+        (void)hipFree(ctx->d_materials_raw);
+        (void)hipFree(ctx->d_dmats);
+        ctx->d_materials_raw = nullptr;
+        ctx->d_dmats = nullptr;
+        ctx->cap_materials = 0;
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_materials_raw, sizeof(tr_material_info) * count));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_dmats, sizeof(tr_dmat) * count));
+        ctx->cap_materials = count;
+    }
+    ctx->stage_materials.assign(materials_host, materials_host + count);
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_materials_raw, ctx->stage_materials.data(), sizeof(tr_material_info) * count,
+                               hipMemcpyHostToDevice, stream));
+    ctx->num_materials = count;
+    ctx->dmats_dirty = true;
+    return TR_OK;
+}
+
+tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_t count, void* stream_) {
+    if (!ctx || (!lights_host && count)) return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t alloc = count ? count : 1u;
+    if (alloc > ctx->cap_lights) {
+        (void)hipFree(ctx->d_lights);
+        ctx->d_lights = nullptr;
+        ctx->cap_lights = 0;
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_lights, sizeof(tr_dlight) * alloc));
+        ctx->cap_lights = alloc;
+    }
+    ctx->stage_lights.resize(alloc);
+    std::memset(ctx->stage_lights.data(), 0, sizeof(tr_dlight) * alloc);
+    for (uint32_t i = 0; i < count; ++i) {
+        const tr_light& s = lights_host[i];
+        tr_dlight& d = ctx->stage_lights[i];
+        for (int k = 0; k < 3; ++k) {
+            d.pos[k] = s.position_and_spotlight_epsilon[k];
+            d.colour[k] = s.colour_emission_and_falloff_distance_sq[k];
+            d.spot_dir[k] = s.spotlight_direction_and_outer_angle[k];
+        }
+        const float outer = s.spotlight_direction_and_outer_angle[3];
+        d.is_spot = outer != 0.0f ? 1u : 0u;  // Light::is_a_spotlight, shared-structs/src/lib.rs:125-127
+        d.cos_outer = std::cos(outer);
+        d.inv_spot_epsilon = 1.0f / s.position_and_spotlight_epsilon[3];
+    }
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_lights, ctx->stage_lights.data(), sizeof(tr_dlight) * alloc,
+                               hipMemcpyHostToDevice, stream));
+    ctx->num_lights = count;
+    return TR_OK;
+}
+
+tr_status tr_set_cluster_tables(tr_context* ctx, const void* counts_dev, const void* indices_dev,
+                                uint32_t num_clusters_total) {
+    if (!ctx || !counts_dev || !indices_dev || num_clusters_total == 0) return TR_ERR_INVALID_ARGUMENT;
+    ctx->d_cluster_counts = (const uint32_t*)counts_dev;
+    ctx->d_light_indices = (const uint32_t*)indices_dev;
+    ctx->num_clusters_total = num_clusters_total;
+    return TR_OK;
+}
+
+tr_status tr_upload_ggx_lut(tr_context* ctx, const uint8_t* rgba8_host, uint32_t width, uint32_t height,
+                            void* stream_) {
+    if (!ctx || !rgba8_host || width == 0 || height == 0) return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t stride = width + 2u;
+    if (width != ctx->lut_w || height != ctx->lut_h) {
+        (void)hipFree(ctx->d_lut_rgba8);
+        (void)hipFree(ctx->d_lut_pairs);
+        ctx->d_lut_rgba8 = ctx->d_lut_pairs = nullptr;
+        ctx->lut_w = ctx->lut_h = ctx->lut_stride = 0;
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_lut_rgba8, (size_t)width * height * 4u));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_lut_pairs, (size_t)stride * height * 4u));
+    }
+    ctx->stage_lut.assign(rgba8_host, rgba8_host + (size_t)width * height * 4u);
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_lut_rgba8, ctx->stage_lut.data(), ctx->stage_lut.size(), hipMemcpyHostToDevice,
+                               stream));
+    hipLaunchKernelGGL(build_lut_pairs_kernel, dim3((stride + 255) / 256, height), dim3(256), 0, stream,
+                       ctx->d_lut_rgba8, ctx->d_lut_pairs, width, height, stride);
+    TR_HIP(ctx, hipGetLastError());
+    ctx->lut_w = width;
+    ctx->lut_h = height;
+    ctx->lut_stride = stride;
+    ctx->dmats_dirty = ctx->num_materials > 0;  // LUT rows are part of the digested material
+    return TR_OK;
+}
+
+tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u, const tr_push_constants* pc,
+                          void* hdr_out, tr_format format, void* opaque_mip0_out, tr_rect rect, void* stream_) {
+    if (!ctx || !g || !u || !pc || !hdr_out || !g->pos_depth || !g->nrm_scale || !g->material_id)
+        return TR_ERR_INVALID_ARGUMENT;
+    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F) return TR_ERR_INVALID_ARGUMENT;
+    if (!tables_ready(ctx, false)) return TR_ERR_TABLES_MISSING;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    tr_frame_params fp;
+    tr_status st = fill_frame_params(ctx, g, u, pc, rect, &fp);
+    if (st != TR_OK) return st;
+    st = ensure_digested(ctx, stream);
+    if (st != TR_OK) return st;
+    fp.pyr_levels = 1;
+    const tr_tables tb = make_tables(ctx);
+    const dim3 grid(fp.tiles_x * fp.tiles_y), block(256);
+    if (format == TR_FORMAT_RGBA16F)
+        hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, fp, tb, (const float4*)g->pos_depth,
+                           (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)nullptr,
+                           (uint2*)hdr_out, (uint2*)opaque_mip0_out);
+    else
+        hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, fp, tb, (const float4*)g->pos_depth,
+                           (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)nullptr,
+                           (float4*)hdr_out, (uint2*)opaque_mip0_out);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* p, void* stream_) {
+    if (!ctx || !p || !p->texels || p->levels == 0 || p->levels > TR_MAX_MIP_LEVELS) return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    uint2* base = (uint2*)p->texels;
+    for (uint32_t l = 1; l < p->levels; ++l) {
+        const uint32_t ws = level_dim(p->width, l - 1), hs = level_dim(p->height, l - 1);
+        const uint32_t wd = level_dim(p->width, l), hd = level_dim(p->height, l);
+        hipLaunchKernelGGL(downsample_kernel, dim3((wd + 63) / 64, (hd + 3) / 4), dim3(256), 0, stream,
+                           (const uint2*)(base + p->level_offset[l - 1]), base + p->level_offset[l], ws, hs, wd, hd);
+    }
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u,
+                                const tr_push_constants* pc, const tr_pyramid* p, void* hdr_inout, tr_format format,
+                                tr_rect rect, void* stream_) {
+    if (!ctx || !g || !u || !pc || !p || !hdr_inout || !p->texels || !g->pos_depth || !g->nrm_scale ||
+        !g->material_id || p->levels == 0 || p->levels > TR_MAX_MIP_LEVELS)
+        return TR_ERR_INVALID_ARGUMENT;
+    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F) return TR_ERR_INVALID_ARGUMENT;
+    if (!tables_ready(ctx, true)) return TR_ERR_TABLES_MISSING;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    tr_frame_params fp;
+    tr_status st = fill_frame_params(ctx, g, u, pc, rect, &fp);
+    if (st != TR_OK) return st;
+    st = ensure_digested(ctx, stream);
+    if (st != TR_OK) return st;
+    st = ensure_levels(ctx, p, stream);
+    if (st != TR_OK) return st;
+    fp.pyr_levels = p->levels;
+    const tr_tables tb = make_tables(ctx);
+    const dim3 grid(fp.tiles_x * fp.tiles_y), block(256);
+    if (format == TR_FORMAT_RGBA16F)
+        hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, fp, tb, (const float4*)g->pos_depth,
+                           (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)p->texels,
+                           (uint2*)hdr_inout, (uint2*)nullptr);
+    else
+        hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, fp, tb, (const float4*)g->pos_depth,
+                           (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)p->texels,
+                           (float4*)hdr_inout, (uint2*)nullptr);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""Host-side frame recorder over the C ABI: the compute-pipeline replacement of `record()`.
+
+Mirrors the part of src/main.rs:1551-2263 that schedules the hot path —
+  "main opaque" (fragment)  ->  "opaque framebuffer mipchain" (generate_mips)
+  ->  "opaque transmissive objects" (fragment_transmission) —
+with the attachment contract of src/render_passes.rs (RGBA16F colour targets, LOAD on the
+transmission pass) and the zone names of src/profiling.rs as timing labels.
+
+torch is plumbing only: it owns device memory (tensors) and the stream; every pixel is computed
+by libtr_shade.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, wire
+from .png import read_png_rgba8
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def load_ggx_lut() -> np.ndarray:
+    """ggx_lut.png exactly as src/main.rs:295-330 uploads it: (1024, 1024, 4) uint8, row 0 first."""
+    cache = os.path.join(ASSET_DIR, "ggx_lut.png")
+    return read_png_rgba8(cache)
+
+
+@dataclass
+class GBufferPlanes:
+    """TGB-v1 planes on the device (include/tr_shade.h tr_gbuffer)."""
+    pos_depth: torch.Tensor    # (H, W, 4) float32
+    nrm_scale: torch.Tensor    # (H, W, 4) float32
+    uv: torch.Tensor           # (H, W, 2) float32
+    material_id: torch.Tensor  # (H, W) int32 (bit pattern of u32; -1 = not covered)
+    origin_x: int = 0          # frame position of plane element (0, 0): a rank may hold one tile only
+    origin_y: int = 0
+
+    @property
+    def height(self) -> int:
+        return int(self.pos_depth.shape[0])
+
+    @property
+    def width(self) -> int:
+        return int(self.pos_depth.shape[1])
+
+    def as_struct(self) -> wire.GBuffer:
+        for t in (self.pos_depth, self.nrm_scale, self.uv, self.material_id):
+            assert t.is_cuda and t.is_contiguous()
+        assert self.pos_depth.dtype == torch.float32 and self.material_id.dtype == torch.int32
+        return wire.GBuffer(self.pos_depth.data_ptr(), self.nrm_scale.data_ptr(), self.uv.data_ptr(),
+                            self.material_id.data_ptr(), self.width, self.height, self.origin_x, self.origin_y)
+
+    @classmethod
+    def from_numpy(cls, g: dict, device) -> "GBufferPlanes":
+        return cls(torch.from_numpy(g["pos_depth"]).to(device), torch.from_numpy(g["nrm_scale"]).to(device),
+                   torch.from_numpy(g["uv"]).to(device),
+                   torch.from_numpy(g["material_id"].view(np.int32)).to(device),
+                   int(g.get("origin_x", 0)), int(g.get("origin_y", 0)))
+
+
+class OpaquePyramid:
+    """`opaque_sampled_hdr_framebuffer` (src/main.rs:383-402): RGBA16F, full mip chain, one allocation."""
+
+    def __init__(self, width: int, height: int, device):
+        lib = _lib.load()
+        self.desc = wire.Pyramid()
+        nbytes = C.c_size_t()
+        st = lib.tr_pyramid_layout(width, height, C.byref(self.desc), C.byref(nbytes))
+        if st != 0:
+            raise _lib.TrError(st, "tr_pyramid_layout")
+        self.width, self.height, self.levels = width, height, int(self.desc.levels)
+        self.texels = torch.zeros((nbytes.value // 8, 4), dtype=torch.float16, device=device)
+        self.desc.texels = self.texels.data_ptr()
+
+    def level(self, l: int) -> torch.Tensor:
+        w, h = max(self.width >> l, 1), max(self.height >> l, 1)
+        off = int(self.desc.level_offset[l])
+        return self.texels[off:off + w * h].view(h, w, 4)
+
+
+class TransmissionRenderer:
+    """One context = one GPU = one host thread (the reference's single queue, src/main.rs:243)."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("transmission_renderer_amd needs a HIP device: there is no CPU path")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self._ctx = C.c_void_p()
+        st = self.lib.tr_context_create(device, C.byref(self._ctx))
+        if st != 0:
+            raise _lib.TrError(st, "tr_context_create")
+        self._keep = {}
+
+    # ---- plumbing
+    def _check(self, st: int, where: str):
+        if st != 0:
+            raise _lib.TrError(st, where, self.lib.tr_last_hip_error(self._ctx))
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self.lib.tr_context_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables (descriptor sets 0 and 2 of the reference; src/descriptor_sets.rs:30-80, 149-176)
+    def upload_materials(self, materials: Sequence[wire.MaterialInfo]):
+        arr = wire.as_ctypes_array(list(materials), wire.MaterialInfo)
+        self._check(self.lib.tr_upload_materials(self._ctx, arr, len(materials), self._stream()), "tr_upload_materials")
+
+    def upload_lights(self, lights: Sequence[wire.Light]):
+        arr = wire.as_ctypes_array(list(lights), wire.Light) if lights else None
+        self._check(self.lib.tr_upload_lights(self._ctx, arr, len(lights), self._stream()), "tr_upload_lights")
+
+    def set_cluster_tables(self, counts: torch.Tensor, indices: torch.Tensor):
+        assert counts.is_cuda and indices.is_cuda and counts.dtype == torch.int32 and indices.dtype == torch.int32
+        assert indices.numel() == counts.numel() * wire.MAX_LIGHTS_PER_CLUSTER
+        self._keep["clusters"] = (counts, indices)
+        self._check(self.lib.tr_set_cluster_tables(self._ctx, counts.data_ptr(), indices.data_ptr(), counts.numel()),
+                    "tr_set_cluster_tables")
+
+    def upload_ggx_lut(self, rgba8: Optional[np.ndarray] = None):
+        if rgba8 is None:
+            rgba8 = load_ggx_lut()
+        rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        h, w, c = rgba8.shape
+        assert c == 4
+        self._check(self.lib.tr_upload_ggx_lut(self._ctx, rgba8.ctypes.data_as(C.c_void_p), w, h, self._stream()),
+                    "tr_upload_ggx_lut")
+
+    # ---- passes
+    @staticmethod
+    def _fmt(t: torch.Tensor) -> int:
+        if t.dtype == torch.float16:
+            return wire.FORMAT_RGBA16F
+        if t.dtype == torch.float32:
+            return wire.FORMAT_RGBA32F
+        raise TypeError("colour targets are RGBA16F or RGBA32F")
+
+    @staticmethod
+    def _rect(g: GBufferPlanes, rect) -> wire.Rect:
+        if rect is None:  # everything the planes cover
+            return wire.Rect(g.origin_x, g.origin_y, g.origin_x + g.width, g.origin_y + g.height)
+        return wire.Rect(*[int(v) for v in rect])
+
+    @staticmethod
+    def _check_target(hdr: torch.Tensor, push: wire.PushConstants):
+        fw, fh = int(push.framebuffer_size[0]), int(push.framebuffer_size[1])
+        assert hdr.is_cuda and hdr.is_contiguous() and hdr.numel() == fw * fh * 4, "colour targets are whole-frame"
+
+    def shade_opaque(self, g: GBufferPlanes, uniforms: wire.Uniforms, push: wire.PushConstants, hdr: torch.Tensor,
+                     pyramid: Optional[OpaquePyramid] = None, rect=None):
+        """"main opaque": `fragment` (shader/src/lib.rs:164-249) -> hdr and pyramid level 0."""
+        gs = g.as_struct()
+        self._check_target(hdr, push)
+        mip0 = pyramid.texels.data_ptr() + int(pyramid.desc.level_offset[0]) * 8 if pyramid is not None else None
+        self._check(self.lib.tr_shade_opaque(self._ctx, C.byref(gs), C.byref(uniforms), C.byref(push), hdr.data_ptr(),
+                                             self._fmt(hdr), mip0, self._rect(g, rect), self._stream()),
+                    "tr_shade_opaque")
+
+    def generate_mips(self, pyramid: OpaquePyramid):
+        """"opaque framebuffer mipchain" (src/main.rs:2046-2064)."""
+        self._check(self.lib.tr_generate_mips(self._ctx, C.byref(pyramid.desc), self._stream()), "tr_generate_mips")
+
+    def shade_transmission(self, g: GBufferPlanes, uniforms: wire.Uniforms, push: wire.PushConstants,
+                           pyramid: OpaquePyramid, hdr: torch.Tensor, rect=None):
+        """"opaque transmissive objects": `fragment_transmission` (shader/src/lib.rs:37-162) over hdr (LOAD)."""
+        gs = g.as_struct()
+        self._check_target(hdr, push)
+        self._check(self.lib.tr_shade_transmission(self._ctx, C.byref(gs), C.byref(uniforms), C.byref(push),
+                                                   C.byref(pyramid.desc), hdr.data_ptr(), self._fmt(hdr),
+                                                   self._rect(g, rect), self._stream()),
+                    "tr_shade_transmission")
+
+    def record(self, opaque: GBufferPlanes, transmissive: GBufferPlanes, uniforms: wire.Uniforms,
+               push: wire.PushConstants, hdr: torch.Tensor, pyramid: OpaquePyramid, rect=None):
+        """The hot-path slice of `record()` in the reference's order (src/main.rs:1969-2124)."""
+        self.shade_opaque(opaque, uniforms, push, hdr, pyramid, rect)
+        self.generate_mips(pyramid)
+        self.shade_transmission(transmissive, uniforms, push, pyramid, hdr, rect)
