@@ -1,20 +1,33 @@
 // tr_kernels.h — gfx950 (CDNA4, wave64) device code of the transmission/volume PBR shading path.
 //
-// One thread shades one pixel; a wave is a 64x1 pixel row segment so every G-buffer plane is
-// read as one contiguous 1 KiB / 512 B / 256 B burst per wave; a 256-thread workgroup is a
-// 64x4 screen tile.  Workgroups are renumbered so that each XCD (own L2) owns a contiguous
-// band of the screen: the data-dependent taps into the opaque pyramid then re-use texel rows
-// inside one L2 instead of being fetched by all eight.
+// Shape of the work
+//   One thread shades one pixel; a wave is a 64x1 pixel row segment, so every G-buffer plane is
+//   read as one contiguous 1 KiB / 256 B burst per wave and the RGBA16F target is written as one
+//   512 B burst; a 256-thread workgroup is a 64x4 screen tile.  Workgroups are renumbered so that
+//   each XCD (own L2) owns a contiguous band of the screen: the data-dependent taps into the
+//   opaque pyramid then re-use texel rows inside one L2 instead of being fetched by all eight.
 //
-// The math is NOT a transliteration of the reference.  Everything that depends only on the
-// material is digested once per upload into a 128-byte record (f0, f90-f0, alpha^2, Beer
-// coefficients, LUT row, ...; `tr_dmat`), read through the scalar unit when a wave sees one
-// material.  Per light, the halfway-vector algebra is collapsed onto two dot products
-// (n.l and v.l):  |v+l|^2 = 2+2 v.l,  v.h = (1+v.l)/|v+l|,  n.h = (n.v+n.l)/|v+l|, and the
-// mirrored light of transmission_btdf needs no vector at all (n.l' = -n.l, v.l' = v.l-2 n.l n.v).
-// D*V is one reciprocal.  x^5 is three multiplies.  These differ from the reference's op order
-// by a few ulp of fp32; the parity bar is 1e-4 per-channel RMSE on the RGBA16F target
-// (tests/test_gpu_parity.py), see DESIGN.md.
+// What bounds it (rocprofv3 PMC, profiles/r01): the path is VALU-issue bound, not HBM bound — a
+// gfx950 SIMD retires one wave64 fp32 instruction per 4 cycles unless it is a packed
+// (v_pk_{fma,mul,add}_f32) one.  So the math is arranged to be short and packable, NOT as a
+// transliteration of the reference:
+//   * everything that depends only on the material is digested once per upload into `tr_dmat`
+//     and read through the scalar unit: a wave handles one material at a time (waves that
+//     straddle several run a waterfall loop over them), so there is a single code path and the
+//     material costs no vector registers;
+//   * per light, the halfway-vector algebra collapses onto n.l, v.l and |n x (v+l)|^2:
+//       |v+l|^2 = 2+2 v.l,  v.h = (1+v.l)/|v+l|,  1-(n.h)^2 = |n x (v+l)|^2/|v+l|^2
+//     (the last form keeps d_ggx well conditioned at low roughness); the mirrored light of
+//     transmission_btdf needs no vector at all (n.l' = -n.l, v.l' = v.l - 2 n.l n.v, and
+//     n x (v+l') = n x (v+l)), so the basic_brdf lobe and the btdf lobe are the two halves of the
+//     same packed instructions;  D*V is one reciprocal per lobe, x^5 three multiplies;
+//   * the two mip levels of the trilinear tap, and the two channels of the GGX LUT, are likewise
+//     the two halves of packed instructions; horizontally adjacent texels come in one 16-byte load;
+//   * the cluster x / y lookups are exact tables (built with the reference's own IEEE division on
+//     the host), the depth slice is one v_log_f32;
+//   * the pyramid / LUT taps are issued before the light loop and consumed after it.
+// These differ from the reference's op order by a few ulp of fp32 (and are closer to exact
+// arithmetic where the reference is ill-conditioned); parity criteria: tests/test_gpu_parity.py.
 //
 // Reference semantics implemented here (file:line relative to the reference root):
 //   fragment_transmission        shader/src/lib.rs:37-162
@@ -37,28 +50,32 @@ constexpr float kPi = 3.14159265358979323846f;
 constexpr float kFrac1Pi = 0.318309886183790671538f;
 constexpr float kLog2e = 1.44269504088896340736f;
 
-// ---------------------------------------------------------------- digested material (128 B)
+typedef float v2f __attribute__((ext_vector_type(2)));  // one v_pk_*_f32 operand
+
+// ---------------------------------------------------------------- digested material (160 B)
+// Index 0 of every pair belongs to the basic_brdf lobe, index 1 to the transmission_btdf lobe.
 struct alignas(16) tr_dmat {
     float diffuse[3];      // diffuse_factor.rgb (base colour)
-    float a2;              // (roughness^2)^2                       (d_ggx / v_smith alpha^2)
-    float c_diff[3];       // lerp(diffuse, 0, metallic) * (1/pi)
-    float at2;             // (roughness^2 * clamp(2 ior - 2, 0, 1))^2   (transmission alpha^2)
-    float f0[3];           // calculate_combined_f0
     float f90;             // calculate_combined_f90 (a splat)
-    float df[3];           // f90 - f0
+    float c_diff[3];       // lerp(diffuse, 0, metallic) * (1/pi)
     float eta;             // 1 / ior
-    float emission[3];
+    float f0[3];           // calculate_combined_f0
     float transmission_factor;
-    float neg_atten_log2[3];  // -(-ln(colour)/distance) * log2(e); 0 when distance == +INF
+    float df[3];           // f90 - f0
     float thickness;
+    float emission[3];
     float rough_ior;       // roughness * clamp(2 ior - 2, 0, 1)   (pyramid lod = log2(W) * this)
+    float neg_atten_log2[3];  // -(-ln(colour)/distance) * log2(e); 0 when distance == +INF
     float lut_fy;          // GGX LUT row interpolation weight   (v = perceptual roughness)
+    float a2[2];           // alpha^2: (roughness^2)^2 ; (roughness^2 * clamp(2 ior - 2, 0, 1))^2
+    float oma2[2];         // 1 - a2
+    float k[2];            // a2 * 0.5 / pi   (numerator of D*V)
     uint32_t lut_row0;     // GGX LUT row offsets into the pair table (entries)
     uint32_t lut_row1;
     uint32_t flags;        // bit0: has finite attenuation distance
-    uint32_t _pad[3];
+    uint32_t _pad[7];
 };
-static_assert(sizeof(tr_dmat) == 128, "digested material is 128 B");
+static_assert(sizeof(tr_dmat) == 160, "digested material is 160 B");
 
 // Light as the kernels read it: the reference's 48-byte record (shared-structs/src/lib.rs:70-78)
 // with the per-light constants of spotlight_factor (:129-138) digested at upload.
@@ -73,6 +90,8 @@ struct tr_level_table {           // pyramid geometry, one entry per mip level
     uint32_t offset[TR_MAX_MIP_LEVELS];  // texels from pyramid base
     uint32_t width[TR_MAX_MIP_LEVELS];
     uint32_t height[TR_MAX_MIP_LEVELS];
+    float wf[TR_MAX_MIP_LEVELS];         // (float)width, (float)height
+    float hf[TR_MAX_MIP_LEVELS];
 };
 
 // Everything a shading launch needs besides the planes; passed by value (kernarg -> SGPRs).
@@ -81,12 +100,11 @@ struct tr_frame_params {
     float view_position[3];
     float log2_fb_width;         // log2(framebuffer_size.x as f32)
     float sun_dir[3];
-    float z_near;
+    float slice_k;               // depth slice = slice_k - lcc_scale * log2(slice_a * depth + slice_b)
     float sun_intensity[3];
-    float z_far;
-    float cluster_size_px[2];
-    float lcc_scale, lcc_bias;
-    uint32_t num_clusters_x, num_clusters_y;
+    float lcc_scale;
+    float slice_a, slice_b;
+    uint32_t clusters_xy;        // num_clusters.x * num_clusters.y
     uint32_t num_clusters_total;
     uint32_t debug_clusters;
     uint32_t width, height;      // frame size (colour-target pitch)
@@ -94,17 +112,35 @@ struct tr_frame_params {
     uint32_t g_origin_x, g_origin_y;  // frame position of plane element (0,0)
     uint32_t rect_x0, rect_y0, rect_x1, rect_y1;
     uint32_t tiles_x, tiles_y;   // 64x4 tiles covering the rect
-    uint32_t lut_width, lut_height, lut_stride;  // pair-table stride in entries (= lut_width + 2)
+    uint32_t lut_width, lut_stride;  // pair-table stride in entries (= lut_width + 2)
     uint32_t pyr_levels;
+    uint32_t ablate;             // profiling only (TR_ABLATE env): bit0 no pyramid taps, bit1 no LUT, bit2 no sun,
+                                 // bit3 no punctual lights, bit4 no refraction math
 };
 
+// Tables that a whole wave reads at one address (material, lights, cluster lists, level geometry)
+// are addressed through the constant address space: a uniform load from it is always issued on the
+// scalar unit (s_load into SGPRs), also inside the material / cluster loops where the compiler
+// cannot otherwise prove that no store clobbers them.  (Constant and global are the same memory.)
+#define TR_CONSTANT __attribute__((address_space(4)))
+typedef const TR_CONSTANT tr_dmat cdmat;
+typedef const TR_CONSTANT tr_dlight cdlight;
+typedef const TR_CONSTANT tr_level_table clevels;
+typedef const TR_CONSTANT uint32_t cu32;
+template <class T>
+__device__ __forceinline__ const TR_CONSTANT T* as_constant(const T* p) {
+    return (const TR_CONSTANT T*)(p);
+}
+
 struct tr_tables {
-    const tr_dmat* __restrict__ dmats;
-    const tr_dlight* __restrict__ lights;
-    const uint32_t* __restrict__ cluster_counts;
-    const uint32_t* __restrict__ light_indices;
+    cdmat* dmats;
+    cdlight* lights;
+    cu32* cluster_counts;
+    cu32* light_indices;
     const uint32_t* __restrict__ lut_pairs;      // (R,G)[x-1], (R,G)[x] per entry
-    const tr_level_table* __restrict__ levels;   // device copy (divergent-material path)
+    clevels* levels;
+    const uint16_t* __restrict__ cluster_x;      // [frame width]  u32(frag_coord.x / cluster_size.x)
+    cu32* cluster_y_term;                        // [frame height] u32(frag_coord.y / cluster_size.y) * num_clusters.x
 };
 
 // ------------------------------------------------------------------------ small helpers
@@ -116,214 +152,251 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
     return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
-__device__ __forceinline__ float pow5(float x) {
-    float x2 = x * x;
-    return x2 * x2 * x;
-}
+__device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_max(v2f a, float b) { return v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
 
 struct f3 {
     float x, y, z;
 };
 
-// D * V with a single reciprocal, from f = 1 - noh^2 (1 - a2) supplied by the caller.
-//   d_ggx                  glam-pbr/src/lib.rs:101-109   D = a2 / (pi f^2)
-//   v_smith_ggx_correlated glam-pbr/src/lib.rs:114-133   V = 0.5 / g  (0 unless g > 0)
-__device__ __forceinline__ float ggx_d_times_v(float f, float nov, float nol, float a2) {
-    float one_minus_a2 = 1.0f - a2;
-    float gv = nol * fast_sqrt(fmaf(nov * nov, one_minus_a2, a2));
-    float gl = nov * fast_sqrt(fmaf(nol * nol, one_minus_a2, a2));
-    float g = gv + gl;
-    float dv = (a2 * (0.5f * kFrac1Pi)) * rcp(f * f * g);
-    return g > 0.0f ? dv : 0.0f;
-}
-
-// f of d_ggx, well conditioned.  The reference evaluates f = noh^2 (a2 - 1) + 1 with noh = n.h; at
-// low roughness (a2 ~ 1e-6) that needs 1 - noh^2 to ~1e-9 absolute, which the straightforward fp32
-// form only delivers by luck of rounding.  Here 1 - noh^2 = sin2 = |n x (v+l)|^2 / |v+l|^2 comes in
-// with fp32 *relative* accuracy, and f = sin2 + a2 (1 - sin2) has no cancellation.
-// noh is clamped to EPSILON by Dot::new when n.h <= 0 (:93-98): then f = 1 + eps^2 (a2 - 1) = 1.
-__device__ __forceinline__ float ggx_f(float sin2, float n_dot_hv, float a2) {
-    return n_dot_hv > 0.0f ? fmaf(a2, 1.0f - sin2, sin2) : 1.0f;
-}
-
 // Accumulators of one pixel over its lights.
 struct light_acc {
-    f3 d;  // sum I * nol * (1 - max(F))            (x c_diff/pi at the end)
-    f3 s;  // sum I * nol * D*V * F
-    f3 t;  // sum I * (1 - F') * D_t*V_t            (x diffuse at the end)
+    f3 d;        // sum I * nol * (1 - max(F))                     (x c_diff/pi at the end)
+    v2f st[3];   // per channel: { sum I * nol * D*V * F ,  sum I * (1 - F') * D_t*V_t }
 };
 
-// One light against one pixel: basic_brdf (+ transmission_btdf when TRANSMISSIVE).
+// One light against one pixel: basic_brdf (+ transmission_btdf when TRANSMISSIVE), the two lobes
+// evaluated side by side in the halves of packed fp32 instructions.
 //   n, v unit; l unit direction to the light; I = rgb intensity reaching the pixel.
+//
+//   f of d_ggx (glam-pbr/src/lib.rs:101-109): the reference evaluates f = noh^2 (a2 - 1) + 1 with
+//   noh = n.h; at low roughness (a2 ~ 1e-6) that needs 1 - noh^2 to ~1e-9 absolute, which the
+//   fp32 form only delivers by luck of rounding.  Here 1 - noh^2 = sin2 = |n x (v+l)|^2 / |v+l|^2
+//   has fp32 *relative* accuracy and f = sin2 + a2 (1 - sin2) has no cancellation.  noh is
+//   clamped to EPSILON by Dot::new when n.h <= 0 (:93-98): then f = 1 + eps^2 (a2 - 1) = 1.
+//   |n x (v+l)|^2 is shared by both lobes: the mirrored light l' = l - 2 (n.l) n differs from l by
+//   a multiple of n, and n x n = 0.
 template <bool TRANSMISSIVE>
-__device__ __forceinline__ void eval_light(light_acc& acc, const tr_dmat& m, f3 n, f3 v, float nov_raw, float nov,
+__device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, f3 n, f3 v, float nov_raw, float nov,
                                            f3 l, f3 I) {
     const float nl_raw = dot3(n.x, n.y, n.z, l.x, l.y, l.z);
     const float vl = dot3(v.x, v.y, v.z, l.x, l.y, l.z);
-    // |n x (v+l)|^2: shared by both lobes, because the mirrored light l' = l - 2 (n.l) n differs
-    // from l by a multiple of n and n x n = 0.
     const float hx = v.x + l.x, hy = v.y + l.y, hz = v.z + l.z;
     const float cx = fmaf(n.y, hz, -(n.z * hy)), cy = fmaf(n.z, hx, -(n.x * hz)), cz = fmaf(n.x, hy, -(n.y * hx));
     const float c2 = dot3(cx, cy, cz, cx, cy, cz);
 
-    // ---- basic_brdf (glam-pbr/src/lib.rs:377-423)
-    {
-        float inv_h = rsq(fmaf(2.0f, vl, 2.0f));            // 1/|v+l|   (|v| = |l| = 1)
-        float voh = fmaxf((1.0f + vl) * inv_h, kEpsilon);    // Dot::new clamps to EPSILON (:93-98)
-        float nol = fmaxf(nl_raw, kEpsilon);
-        float p = pow5(1.0f - voh);                          // fresnel_schlick :137-139
-        float Fx = fmaf(m.df[0], p, m.f0[0]);
-        float Fy = fmaf(m.df[1], p, m.f0[1]);
-        float Fz = fmaf(m.df[2], p, m.f0[2]);
-        float f = ggx_f(c2 * (inv_h * inv_h), nov_raw + nl_raw, m.a2);
-        float dv = ggx_d_times_v(f, nov, nol, m.a2);
-        float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));  // diffuse_brdf :356-360
-        float ws = nol * dv;                                 // specular_brdf :362-375
+    if constexpr (TRANSMISSIVE) {
+        // lobe 0: basic_brdf (glam-pbr/src/lib.rs:377-423); lobe 1: transmission_btdf (:200-233)
+        const v2f vlp = {vl, fmaf(-2.0f * nl_raw, nov_raw, vl)};            // v.l , v.l'
+        const v2f s = pk_fma(splat(2.0f), vlp, splat(2.0f));               // |v+l|^2 (|v| = |l| = 1)
+        const v2f inv_h = {rsq(s.x), rsq(s.y)};
+        const v2f voh = pk_max((vlp + 1.0f) * inv_h, kEpsilon);            // Dot::new clamps to EPSILON (:93-98)
+        const v2f nol = {fmaxf(nl_raw, kEpsilon), fmaxf(-nl_raw, kEpsilon)};  // n.l , n.l' = -(n.l)
+        const v2f omv = 1.0f - voh;
+        const v2f omv2 = omv * omv;
+        const v2f p = omv2 * omv2 * omv;                                   // fresnel_schlick :137-139
+        const v2f a2 = {m.a2[0], m.a2[1]}, oma2 = {m.oma2[0], m.oma2[1]}, kk = {m.k[0], m.k[1]};
+        const v2f sin2 = (inv_h * inv_h) * c2;
+        v2f f = pk_fma(a2, 1.0f - sin2, sin2);
+        f.x = (nov_raw + nl_raw) > 0.0f ? f.x : 1.0f;
+        f.y = (nov_raw - nl_raw) > 0.0f ? f.y : 1.0f;
+        // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal per lobe
+        const v2f ra = pk_fma(splat(nov * nov), oma2, a2), rb = pk_fma(nol * nol, oma2, a2);
+        const v2f g = nol * v2f{fast_sqrt(ra.x), fast_sqrt(ra.y)} + nov * v2f{fast_sqrt(rb.x), fast_sqrt(rb.y)};
+        const v2f den = f * f * g;
+        v2f dv = kk * v2f{rcp(den.x), rcp(den.y)};
+        dv.x = g.x > 0.0f ? dv.x : 0.0f;
+        dv.y = g.y > 0.0f ? dv.y : 0.0f;
+        const v2f w = {nol.x * dv.x, dv.y};  // specular_brdf is weighted by n.l (:414-421), the btdf is not (:232)
+        const v2f F0 = pk_fma(splat(m.df[0]), p, splat(m.f0[0]));          // { F , F' } per channel
+        const v2f F1 = pk_fma(splat(m.df[1]), p, splat(m.f0[1]));
+        const v2f F2 = pk_fma(splat(m.df[2]), p, splat(m.f0[2]));
+        const float wd = nol.x * (1.0f - fmaxf(F0.x, fmaxf(F1.x, F2.x)));  // diffuse_brdf :356-360
         acc.d.x = fmaf(I.x, wd, acc.d.x);
         acc.d.y = fmaf(I.y, wd, acc.d.y);
         acc.d.z = fmaf(I.z, wd, acc.d.z);
-        acc.s.x = fmaf(I.x * Fx, ws, acc.s.x);
-        acc.s.y = fmaf(I.y * Fy, ws, acc.s.y);
-        acc.s.z = fmaf(I.z * Fz, ws, acc.s.z);
+        const v2f sgn = {1.0f, -1.0f}, off = {0.0f, 1.0f};                  // { F , 1 - F' }
+        acc.st[0] = pk_fma(pk_fma(F0, sgn, off) * I.x, w, acc.st[0]);
+        acc.st[1] = pk_fma(pk_fma(F1, sgn, off) * I.y, w, acc.st[1]);
+        acc.st[2] = pk_fma(pk_fma(F2, sgn, off) * I.z, w, acc.st[2]);
+    } else {
+        const float inv_h = rsq(fmaf(2.0f, vl, 2.0f));
+        const float voh = fmaxf((1.0f + vl) * inv_h, kEpsilon);
+        const float nol = fmaxf(nl_raw, kEpsilon);
+        const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
+        const float sin2 = c2 * (inv_h * inv_h);
+        const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
+        const float g = nol * fast_sqrt(fmaf(nov * nov, m.oma2[0], m.a2[0])) +
+                        nov * fast_sqrt(fmaf(nol * nol, m.oma2[0], m.a2[0]));
+        float dv = m.k[0] * rcp(f * f * g);
+        dv = g > 0.0f ? dv : 0.0f;
+        const float Fx = fmaf(m.df[0], p, m.f0[0]), Fy = fmaf(m.df[1], p, m.f0[1]), Fz = fmaf(m.df[2], p, m.f0[2]);
+        const float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));
+        const float ws = nol * dv;
+        acc.d.x = fmaf(I.x, wd, acc.d.x);
+        acc.d.y = fmaf(I.y, wd, acc.d.y);
+        acc.d.z = fmaf(I.z, wd, acc.d.z);
+        acc.st[0].x = fmaf(I.x * Fx, ws, acc.st[0].x);
+        acc.st[1].x = fmaf(I.y * Fy, ws, acc.st[1].x);
+        acc.st[2].x = fmaf(I.z * Fz, ws, acc.st[2].x);
     }
-    // ---- transmission_btdf (glam-pbr/src/lib.rs:200-233): light mirrored about the surface,
-    //      n.l' = -(n.l), v.l' = v.l - 2 (n.l)(n.v); no vector is ever formed.
-    if constexpr (TRANSMISSIVE) {
-        float vlm = fmaf(-2.0f * nl_raw, nov_raw, vl);
-        float inv_h = rsq(fmaf(2.0f, vlm, 2.0f));
-        float voh = fmaxf((1.0f + vlm) * inv_h, kEpsilon);
-        float nolm = fmaxf(-nl_raw, kEpsilon);
-        float p = pow5(1.0f - voh);
-        float f = ggx_f(c2 * (inv_h * inv_h), nov_raw - nl_raw, m.at2);
-        float dv = ggx_d_times_v(f, nov, nolm, m.at2);
-        acc.t.x = fmaf(I.x * (1.0f - fmaf(m.df[0], p, m.f0[0])), dv, acc.t.x);
-        acc.t.y = fmaf(I.y * (1.0f - fmaf(m.df[1], p, m.f0[1])), dv, acc.t.y);
-        acc.t.z = fmaf(I.z * (1.0f - fmaf(m.df[2], p, m.f0[2])), dv, acc.t.z);
-    }
-}
-
-// Light::spotlight_factor (shared-structs/src/lib.rs:129-138); only `fragment` applies it.
-__device__ __forceinline__ float spotlight_factor(const tr_dlight& L, f3 dir_to_light) {
-    float theta = -dot3(dir_to_light.x, dir_to_light.y, dir_to_light.z, L.spot_dir[0], L.spot_dir[1], L.spot_dir[2]);
-    return fmaxf((theta - L.cos_outer) * L.inv_spot_epsilon, 0.0f);
 }
 
 template <bool TRANSMISSIVE>
-__device__ __forceinline__ void eval_punctual(light_acc& acc, const tr_dmat& m, const tr_dlight& L, f3 pos, f3 n, f3 v,
+__device__ __forceinline__ void eval_punctual(light_acc& acc, cdmat& m, cdlight& L, f3 pos, f3 n, f3 v,
                                               float nov_raw, float nov) {
     // light_direction_and_attenuation (glam-pbr/src/lib.rs:12-23): bare 1/d^2
     float dx = L.pos[0] - pos.x, dy = L.pos[1] - pos.y, dz = L.pos[2] - pos.z;
-    float d2 = dot3(dx, dy, dz, dx, dy, dz);
-    float inv_d = rsq(d2);
+    float inv_d = rsq(dot3(dx, dy, dz, dx, dy, dz));
     f3 l = {dx * inv_d, dy * inv_d, dz * inv_d};
     float att = inv_d * inv_d;
-    if constexpr (!TRANSMISSIVE) {  // shader/src/lighting.rs:201-203 (absent from the transmissive loop)
-        if (L.is_spot) att *= spotlight_factor(L, l);
+    if constexpr (!TRANSMISSIVE) {
+        // Light::spotlight_factor (shared-structs/src/lib.rs:129-138); shader/src/lighting.rs:201-203
+        // applies it in `fragment` only — the transmissive loop (:58-92) has no spotlight factor.
+        if (L.is_spot) {
+            float theta = -dot3(l.x, l.y, l.z, L.spot_dir[0], L.spot_dir[1], L.spot_dir[2]);
+            att *= fmaxf((theta - L.cos_outer) * L.inv_spot_epsilon, 0.0f);
+        }
     }
     f3 I = {L.colour[0] * att, L.colour[1] * att, L.colour[2] * att};
     eval_light<TRANSMISSIVE>(acc, m, n, v, nov_raw, nov, l, I);
 }
 
 // ------------------------------------------------------------------ opaque pyramid taps
-// clamp_sampler (src/main.rs:694-705): LINEAR min/mag, LINEAR mip, CLAMP_TO_EDGE.
-struct lin_tap {
-    uint32_t i0, i1;
-    float w;
+// clamp_sampler (src/main.rs:694-705): LINEAR min/mag, LINEAR mip, CLAMP_TO_EDGE.  Per axis:
+//   x = u*w - 0.5;  xc = clamp(x, 0, w-1);  i0 = floor(xc), i1 = min(i0+1, w-1), weight xc - i0
+// (identical to clamping floor(x) and floor(x)+1 to the edge, and defined for NaN/inf u).  The
+// taps (i0, i1) of a row are fetched as one 16-byte load of texels (b, b+1), b = min(i0, w-2): at
+// the right edge b = w-2 and the weight xc - b becomes exactly 1.  Levels narrower than 2 texels
+// take single-texel loads.
+struct tap_pair {   // two mip levels side by side
+    v2f wx, wy;     // weights
+    uint32_t a00[2], a01[2];  // texel index of (row0, b) and (row1, b) per level
 };
-__device__ __forceinline__ lin_tap linear_tap(float coord, uint32_t dim) {
-    float fdim = (float)dim;
-    float x = fmaf(coord, fdim, -0.5f);
-    x = fminf(fmaxf(x, -1.0f), fdim);  // finite for NaN/inf coordinates; no-op otherwise (edge clamp follows)
-    float fl = floorf(x);
-    lin_tap t;
-    t.w = x - fl;
-    int a = (int)fl;
-    int mx = (int)dim - 1;
-    t.i0 = (uint32_t)min(max(a, 0), mx);
-    t.i1 = (uint32_t)min(max(a + 1, 0), mx);
-    return t;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));  // two adjacent RGBA16F texels, texel (8-byte) aligned
+
+__device__ __forceinline__ float h2f_lo(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu))); }
+__device__ __forceinline__ float h2f_hi(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }
+
+// rgb of the bilinear taps of both levels -> trilinear result.
+struct pyramid_fetch {
+    uint4 r0[2], r1[2];   // per level: row0 pair, row1 pair
+    v2f wx, wy;
+    float t;
+};
+
+__device__ __forceinline__ void axis_pair(float u, v2f dimf, v2f& w, uint32_t (&b)[2]) {
+    v2f x = pk_fma(splat(u), dimf, splat(-0.5f));
+    v2f hi = dimf - 1.0f;
+    v2f xc = {fminf(fmaxf(x.x, 0.0f), hi.x), fminf(fmaxf(x.y, 0.0f), hi.y)};
+    v2f lim = dimf - 2.0f;  // >= 0 on this path (both levels at least 2 texels wide)
+    v2f bf = {fminf(floorf(xc.x), lim.x), fminf(floorf(xc.y), lim.y)};
+    w = xc - bf;
+    b[0] = (uint32_t)bf.x;
+    b[1] = (uint32_t)bf.y;
 }
 
-__device__ __forceinline__ f3 unpack_rgb16f(uint2 t) {
-    f3 r;
-    r.x = __half2float(__ushort_as_half((unsigned short)(t.x & 0xFFFFu)));
-    r.y = __half2float(__ushort_as_half((unsigned short)(t.x >> 16)));
-    r.z = __half2float(__ushort_as_half((unsigned short)(t.y & 0xFFFFu)));
-    return r;
+__device__ __forceinline__ void axis_single(float u, float dimf, float& w, uint32_t& i0, uint32_t& i1) {
+    float x = fmaf(u, dimf, -0.5f);
+    float xc = fminf(fmaxf(x, 0.0f), dimf - 1.0f);
+    float fl = floorf(xc);
+    w = xc - fl;
+    i0 = (uint32_t)fl;
+    i1 = (uint32_t)fminf(fl + 1.0f, dimf - 1.0f);
 }
 
-__device__ __forceinline__ f3 lerp3(f3 a, f3 b, float t) {
-    return {fmaf(b.x - a.x, t, a.x), fmaf(b.y - a.y, t, a.y), fmaf(b.z - a.z, t, a.z)};
-}
-
-__device__ __forceinline__ f3 bilinear_level(const uint2* __restrict__ texels, uint32_t offset, uint32_t w, uint32_t h,
-                                             float u, float v) {
-    lin_tap tx = linear_tap(u, w);
-    lin_tap ty = linear_tap(v, h);
-    const uint2* r0 = texels + offset + ty.i0 * w;
-    const uint2* r1 = texels + offset + ty.i1 * w;
-    uint2 q00 = r0[tx.i0], q10 = r0[tx.i1], q01 = r1[tx.i0], q11 = r1[tx.i1];
-    f3 top = lerp3(unpack_rgb16f(q00), unpack_rgb16f(q10), tx.w);
-    f3 bot = lerp3(unpack_rgb16f(q01), unpack_rgb16f(q11), tx.w);
-    return lerp3(top, bot, ty.w);
-}
-
-// framebuffer.sample_by_lod(clamp_sampler, uv, lod).rgb (shader/src/lib.rs:135-138)
-template <bool UNIFORM>
-__device__ __forceinline__ f3 sample_pyramid(const uint2* __restrict__ texels, const tr_frame_params& fp,
-                                             const tr_level_table* __restrict__ lv, float u, float v, float lod) {
-    float l = fminf(fmaxf(lod, 0.0f), (float)(fp.pyr_levels - 1u));
+// Issues the loads of framebuffer.sample_by_lod(clamp_sampler, uv, lod) (shader/src/lib.rs:135-138).
+// `lod` is wave-uniform (it depends on the material only), so level geometry is scalar.
+__device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __restrict__ texels,
+                                              clevels* lv, uint32_t levels, float u, float v,
+                                              float lod) {
+    float l = fminf(fmaxf(lod, 0.0f), (float)(levels - 1u));
     float lf = floorf(l);
-    float t = l - lf;
-    uint32_t l0 = (uint32_t)lf;
-    uint32_t l1 = min(l0 + 1u, fp.pyr_levels - 1u);
-    if constexpr (UNIFORM) {  // lod depends on the material only: wave-uniform -> scalar loads
-        l0 = __builtin_amdgcn_readfirstlane(l0);
-        l1 = __builtin_amdgcn_readfirstlane(l1);
+    pf.t = l - lf;
+    const uint32_t l0 = __builtin_amdgcn_readfirstlane((uint32_t)lf);
+    const uint32_t l1 = min(l0 + 1u, levels - 1u);
+    const uint32_t w0 = lv->width[l0], w1 = lv->width[l1], h0 = lv->height[l0], h1 = lv->height[l1];
+    const uint2* b0 = texels + lv->offset[l0];
+    const uint2* b1 = texels + lv->offset[l1];
+    if (w1 >= 2u) {  // (w0 >= w1): the common case, every row fetched as one 16-byte texel pair
+        uint32_t bx[2];
+        axis_pair(u, v2f{lv->wf[l0], lv->wf[l1]}, pf.wx, bx);
+        float wy0, wy1;
+        uint32_t y00, y01, y10, y11;
+        axis_single(v, lv->hf[l0], wy0, y00, y01);
+        axis_single(v, lv->hf[l1], wy1, y10, y11);
+        pf.wy = v2f{wy0, wy1};
+        auto ld = [](const uint2* p) {
+            u32x4 t = *reinterpret_cast<const u32x4_a8*>(p);  // one global_load_dwordx4
+            return uint4{t.x, t.y, t.z, t.w};
+        };
+        pf.r0[0] = ld(b0 + y00 * w0 + bx[0]);
+        pf.r1[0] = ld(b0 + y01 * w0 + bx[0]);
+        pf.r0[1] = ld(b1 + y10 * w1 + bx[1]);
+        pf.r1[1] = ld(b1 + y11 * w1 + bx[1]);
+    } else {         // a level narrower than 2 texels: single-texel loads, same arithmetic
+        float wx0, wx1, wy0, wy1;
+        uint32_t x00, x01, x10, x11, y00, y01, y10, y11;
+        axis_single(u, lv->wf[l0], wx0, x00, x01);
+        axis_single(u, lv->wf[l1], wx1, x10, x11);
+        axis_single(v, lv->hf[l0], wy0, y00, y01);
+        axis_single(v, lv->hf[l1], wy1, y10, y11);
+        pf.wx = v2f{wx0, wx1};
+        pf.wy = v2f{wy0, wy1};
+        uint2 a, b;
+        a = b0[y00 * w0 + x00]; b = b0[y00 * w0 + x01]; pf.r0[0] = uint4{a.x, a.y, b.x, b.y};
+        a = b0[y01 * w0 + x00]; b = b0[y01 * w0 + x01]; pf.r1[0] = uint4{a.x, a.y, b.x, b.y};
+        a = b1[y10 * w1 + x10]; b = b1[y10 * w1 + x11]; pf.r0[1] = uint4{a.x, a.y, b.x, b.y};
+        a = b1[y11 * w1 + x10]; b = b1[y11 * w1 + x11]; pf.r1[1] = uint4{a.x, a.y, b.x, b.y};
     }
-    f3 a = bilinear_level(texels, lv->offset[l0], lv->width[l0], lv->height[l0], u, v);
-    f3 b = bilinear_level(texels, lv->offset[l1], lv->width[l1], lv->height[l1], u, v);
-    return lerp3(a, b, t);
+}
+
+// Filters the fetched texels: bilinear per level (lerp form, fp32), then across levels.
+__device__ __forceinline__ f3 pyramid_resolve(const pyramid_fetch& pf) {
+    float out[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        auto ch = [c](const uint4& q, int texel) {
+            uint32_t w = (c < 2) ? (texel ? q.z : q.x) : (texel ? q.w : q.y);
+            return (c == 1) ? h2f_hi(w) : h2f_lo(w);
+        };
+        v2f t00 = {ch(pf.r0[0], 0), ch(pf.r0[1], 0)}, t10 = {ch(pf.r0[0], 1), ch(pf.r0[1], 1)};
+        v2f t01 = {ch(pf.r1[0], 0), ch(pf.r1[1], 0)}, t11 = {ch(pf.r1[0], 1), ch(pf.r1[1], 1)};
+        v2f top = pk_fma(t10 - t00, pf.wx, t00);
+        v2f bot = pk_fma(t11 - t01, pf.wx, t01);
+        v2f bl = pk_fma(bot - top, pf.wy, top);
+        out[c] = fmaf(bl.y - bl.x, pf.t, bl.x);
+    }
+    return {out[0], out[1], out[2]};
 }
 
 // textures[ggx_lut].sample(clamp_sampler, (n.v, roughness)).xy (shader/src/lib.rs:126-133).
 // The row pair and its weight depend on the material only (tr_dmat); the pair table gives both
-// horizontal neighbours of a row in one dword.
-__device__ __forceinline__ void sample_lut(const uint32_t* __restrict__ pairs, const tr_frame_params& fp,
-                                           const tr_dmat& m, float nov_raw, float& A, float& B) {
-    float fw = (float)fp.lut_width;
-    float x = fmaf(nov_raw, fw, -0.5f);
-    x = fminf(fmaxf(x, -1.0f), fw);
+// horizontal neighbours of a row in one dword.  R and G ride in the halves of packed ops.
+struct lut_fetch {
+    uint32_t p0, p1;
+    float fx;
+};
+__device__ __forceinline__ void lut_issue(lut_fetch& lf, const uint32_t* __restrict__ pairs, float lut_wf,
+                                          cdmat& m, float nov_raw) {
+    float x = fmaf(nov_raw, lut_wf, -0.5f);
+    x = fminf(fmaxf(x, -1.0f), lut_wf);
     float fl = floorf(x);
-    float fx = x - fl;
+    lf.fx = x - fl;
     uint32_t k = (uint32_t)((int)fl + 1);
-    uint32_t p0 = pairs[m.lut_row0 + k];
-    uint32_t p1 = pairs[m.lut_row1 + k];
-    float r00 = (float)(p0 & 0xFFu), g00 = (float)((p0 >> 8) & 0xFFu);
-    float r10 = (float)((p0 >> 16) & 0xFFu), g10 = (float)(p0 >> 24);
-    float r01 = (float)(p1 & 0xFFu), g01 = (float)((p1 >> 8) & 0xFFu);
-    float r11 = (float)((p1 >> 16) & 0xFFu), g11 = (float)(p1 >> 24);
-    float rt = fmaf(r10 - r00, fx, r00), rb = fmaf(r11 - r01, fx, r01);
-    float gt = fmaf(g10 - g00, fx, g00), gb = fmaf(g11 - g01, fx, g01);
-    A = fmaf(rb - rt, m.lut_fy, rt) * (1.0f / 255.0f);
-    B = fmaf(gb - gt, m.lut_fy, gt) * (1.0f / 255.0f);
+    lf.p0 = pairs[m.lut_row0 + k];
+    lf.p1 = pairs[m.lut_row1 + k];
 }
-
-// ------------------------------------------------------------------------ cluster lookup
-// shader/src/lib.rs:88-98; LightClusterCoefficients::get_depth_slice shared-structs/src/lib.rs:54-63.
-// The two screen divisions and the linear-depth division are IEEE-exact so that cluster
-// boundaries fall on the same pixels as in the reference.
-__device__ __forceinline__ uint32_t f32_as_u32_sat(float f) {  // Rust `as u32`: saturating, NaN -> 0
-    return (f > 0.0f) ? ((f >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)f) : 0u;
-}
-__device__ __forceinline__ uint32_t cluster_index(const tr_frame_params& fp, uint32_t px, uint32_t py, float depth) {
-#pragma clang fp contract(off)
-    uint32_t cx = f32_as_u32_sat(((float)px + 0.5f) / fp.cluster_size_px[0]);
-    uint32_t cy = f32_as_u32_sat(((float)py + 0.5f) / fp.cluster_size_px[1]);
-    float depth_range = 2.0f * (1.0f - depth) - 1.0f;
-    float lin = (2.0f * fp.z_near * fp.z_far) / ((fp.z_far + fp.z_near) - depth_range * (fp.z_far - fp.z_near));
-    uint32_t cz = f32_as_u32_sat(fmaxf(__log2f(lin) * fp.lcc_scale + fp.lcc_bias, 0.0f));
-    return cz * fp.num_clusters_x * fp.num_clusters_y + cy * fp.num_clusters_x + cx;
+__device__ __forceinline__ v2f lut_resolve(const lut_fetch& lf, float fy) {
+    auto b = [](uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); };
+    v2f t00 = {b(lf.p0, 0), b(lf.p0, 1)}, t10 = {b(lf.p0, 2), b(lf.p0, 3)};
+    v2f t01 = {b(lf.p1, 0), b(lf.p1, 1)}, t11 = {b(lf.p1, 2), b(lf.p1, 3)};
+    v2f top = pk_fma(t10 - t00, splat(lf.fx), t00);
+    v2f bot = pk_fma(t11 - t01, splat(lf.fx), t01);
+    return pk_fma(bot - top, splat(fy), top) * (1.0f / 255.0f);
 }
 
 __device__ __forceinline__ uint2 pack_rgba16f(float r, float g, float b, float a) {
@@ -347,11 +420,12 @@ __device__ __forceinline__ f3 debug_colour_for_id(uint32_t id) {
 }
 
 // ------------------------------------------------------------------------ one pixel
-// UNIFORM: the whole wave shares `m` (scalar registers).  Returns rgb; alpha is 1.
-template <bool TRANSMISSIVE, bool UNIFORM>
-__device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_tables& tb, const tr_dmat& m,
-                                          const uint2* __restrict__ pyramid, float4 pd, float4 ns, uint32_t px,
-                                          uint32_t py, bool active, uint64_t active_mask) {
+// Runs with exec = the lanes of the wave that share material `m` (scalar registers).
+// `lane` = lane id in the wave; `cluster_xy` = cluster x + cluster y * num_clusters.x of this pixel.
+template <bool TRANSMISSIVE>
+__device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_tables& tb, cdmat& m,
+                                          const uint2* __restrict__ pyramid, float4 pd, float4 ns, uint32_t lane,
+                                          uint32_t cluster_xy) {
     const f3 pos = {pd.x, pd.y, pd.z};
     // view = normalize(view_position - position) (lib.rs:79-80); normal = normalize(n) (lighting.rs:229)
     float vx = fp.view_position[0] - pos.x, vy = fp.view_position[1] - pos.y, vz = fp.view_position[2] - pos.z;
@@ -362,48 +436,30 @@ __device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_ta
     const float nov_raw = dot3(n.x, n.y, n.z, v.x, v.y, v.z);
     const float nov = fmaxf(nov_raw, kEpsilon);
 
-    light_acc acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    // ---- cluster lookup (shader/src/lib.rs:88-98): x / y from exact tables (cluster_xy), the depth slice of
+    // shared-structs/src/lib.rs:54-63 folded to  slice = u32(max(K - scale * log2(2n + 2 depth (f - n)), 0)).
+    // The light count and the first list entry are requested here so that they are back long before the loop.
+    const float zs = fmaf(-fp.lcc_scale, fast_log2(fmaf(pd.w, fp.slice_a, fp.slice_b)), fp.slice_k);
+    const uint32_t cz = (uint32_t)fmaxf(zs, 0.0f);  // v_cvt_u32_f32 saturates, NaN -> 0 (Rust `as u32`)
+    const uint32_t cluster = cz * fp.clusters_xy + cluster_xy;
+    const bool in_range = cluster < fp.num_clusters_total;  // out-of-range reads as 0 lights (robust access)
+    const uint32_t csafe = in_range ? cluster : 0u;
+    const uint32_t* indices = (const uint32_t*)tb.light_indices + (size_t)csafe * TR_MAX_LIGHTS_PER_CLUSTER;
+    uint32_t num_lights = ((const uint32_t*)tb.cluster_counts)[csafe];   // per-lane (vector) reads
+    uint32_t head = indices[0];
+    num_lights = in_range ? num_lights : 0u;
 
-    // sun (lighting.rs:37-53 / 171-177)
-    eval_light<TRANSMISSIVE>(acc, m, n, v, nov_raw, nov, {fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]},
-                             {fp.sun_intensity[0], fp.sun_intensity[1], fp.sun_intensity[2]});
-
-    // clustered punctual lights (lighting.rs:55-92 / 179-217)
-    uint32_t cluster = cluster_index(fp, px, py, pd.w);
-    bool in_range = cluster < fp.num_clusters_total;  // out-of-range reads as 0 lights (robust access)
-    uint32_t c_safe = in_range ? cluster : 0u;
-    int first = __ffsll((unsigned long long)active_mask) - 1;
-    uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c_safe, first);
-    bool c_uniform = __ballot(active && (c_safe != c0 || !in_range)) == 0ull;
-    uint32_t num_lights = 0;
-    if (c_uniform) {
-        // every live lane reads the same list: scalar loads, lights live in SGPRs
-        c0 = __builtin_amdgcn_readfirstlane(c0);
-        num_lights = tb.cluster_counts[c0];
-        const uint32_t* idx = tb.light_indices + (size_t)c0 * TR_MAX_LIGHTS_PER_CLUSTER;
-        for (uint32_t i = 0; i < num_lights; ++i) {
-            const tr_dlight& L = tb.lights[idx[i]];
-            eval_punctual<TRANSMISSIVE>(acc, m, L, pos, n, v, nov_raw, nov);
-        }
-    } else {
-        num_lights = in_range ? tb.cluster_counts[c_safe] : 0u;
-        if (!active) num_lights = 0;
-        const uint32_t* idx = tb.light_indices + (size_t)c_safe * TR_MAX_LIGHTS_PER_CLUSTER;
-        for (uint32_t i = 0; i < num_lights; ++i) {
-            const tr_dlight L = tb.lights[idx[i]];
-            eval_punctual<TRANSMISSIVE>(acc, m, L, pos, n, v, nov_raw, nov);
-        }
-    }
-
-    f3 diffuse = {acc.d.x * m.c_diff[0], acc.d.y * m.c_diff[1], acc.d.z * m.c_diff[2]};
-
+    // ---- ibl_volume_refraction, part 1 (glam-pbr/src/lib.rs:292-337): where the refracted ray leaves
+    //      the volume, projected to the screen; the taps are in flight while the lights are evaluated.
+    pyramid_fetch pf;
+    lut_fetch lf;
+    float len = 0.0f;
     if constexpr (TRANSMISSIVE) {
-        // ibl_volume_refraction (glam-pbr/src/lib.rs:292-354)
         // refract(-v, n, ior) :248-256 ; unit length by construction (Snell), so no re-normalise
         float eta = m.eta;
         float k = fmaf(-eta * eta, fmaf(-nov_raw, nov_raw, 1.0f), 1.0f);
         float cn = fmaf(-eta, nov_raw, fast_sqrt(k));   // eta * n.i + sqrt(k), n.i = -n.v
-        float len = m.thickness * ns.w;                 // thickness * model_scale :264
+        len = m.thickness * ns.w;                       // thickness * model_scale :264
         float ex = fmaf(fmaf(-eta, v.x, -cn * n.x), len, pos.x);
         float ey = fmaf(fmaf(-eta, v.y, -cn * n.y), len, pos.y);
         float ez = fmaf(fmaf(-eta, v.z, -cn * n.z), len, pos.z);
@@ -411,22 +467,60 @@ __device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_ta
         float cx = fmaf(P[8], ez, fmaf(P[4], ey, fmaf(P[0], ex, P[12])));
         float cy = fmaf(P[9], ez, fmaf(P[5], ey, fmaf(P[1], ex, P[13])));
         float cw = fmaf(P[11], ez, fmaf(P[7], ey, fmaf(P[3], ex, P[15])));
-        float tu = fmaf(cx / cw, 0.5f, 0.5f);
-        float tv = fmaf(cy / cw, 0.5f, 0.5f);
+        float hw = 0.5f * rcp(cw);                      // (clip.xy / clip.w + 1) / 2  :330-332
+        float tu = fmaf(cx, hw, 0.5f);
+        float tv = fmaf(cy, hw, 0.5f);
         float lod = fp.log2_fb_width * m.rough_ior;     // :334-335
-        f3 T = sample_pyramid<UNIFORM>(pyramid, fp, tb.levels, tu, tv, lod);
-        // apply_volume_attenuation (Beer's law) :275-290
-        if (m.flags & 1u) {
+        if (!(fp.ablate & 1u)) pyramid_issue(pf, pyramid, tb.levels, fp.pyr_levels, tu, tv, lod);
+        else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; }
+        if (!(fp.ablate & 2u)) lut_issue(lf, tb.lut_pairs, (float)fp.lut_width, m, nov_raw);
+        else { lf.p0 = lf.p1 = 0x40404040u; lf.fx = nov_raw; }
+    }
+
+    light_acc acc = {{0.f, 0.f, 0.f}, {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}};
+
+    // sun (lighting.rs:37-53 / 171-177)
+    if (!(fp.ablate & 4u))
+    eval_light<TRANSMISSIVE>(acc, m, n, v, nov_raw, nov, {fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]},
+                             {fp.sun_intensity[0], fp.sun_intensity[1], fp.sun_intensity[2]});
+
+    // ---- clustered punctual lights (lighting.rs:55-92 / 179-217).  Every lane walks its own cluster's list
+    // (fetched at the top of this function); at each step the lanes whose next light index equals that of
+    // the first pending lane evaluate it together, with the light read through the scalar unit.  When the
+    // lists agree (the normal case, also across cluster boundaries) that is one pass per light.
+    if (!(fp.ablate & 8u)) {
+        uint32_t i = 0;
+        uint64_t pending = __ballot(i < num_lights);
+        while (pending) {
+            const int l0 = __ffsll((unsigned long long)pending) - 1;
+            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)head, l0);
+            const uint64_t group = __ballot(i < num_lights && head == h0);
+            if ((group >> lane) & 1ull) {  // membership from the mask keeps h0 scalar (see shade_kernel)
+                const uint32_t next = indices[min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u)];  // in flight during the eval
+                eval_punctual<TRANSMISSIVE>(acc, m, tb.lights[h0], pos, n, v, nov_raw, nov);
+                ++i;
+                head = next;
+            }
+            pending = __ballot(i < num_lights);
+        }
+    }
+
+    f3 diffuse = {acc.d.x * m.c_diff[0], acc.d.y * m.c_diff[1], acc.d.z * m.c_diff[2]};
+
+    if constexpr (TRANSMISSIVE) {
+        // ---- ibl_volume_refraction, part 2 (:337-353)
+        f3 T = pyramid_resolve(pf);
+        if (m.flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
             T.x *= fast_exp2(m.neg_atten_log2[0] * len);
             T.y *= fast_exp2(m.neg_atten_log2[1] * len);
             T.z *= fast_exp2(m.neg_atten_log2[2] * len);
         }
-        float A, B;
-        sample_lut(tb.lut_pairs, fp, m, nov_raw, A, B);
+        const v2f AB = lut_resolve(lf, m.lut_fy);
         // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
-        float tx = fmaf(1.0f - fmaf(m.f0[0], A, m.f90 * B), T.x, acc.t.x) * m.diffuse[0];
-        float ty = fmaf(1.0f - fmaf(m.f0[1], A, m.f90 * B), T.y, acc.t.y) * m.diffuse[1];
-        float tz = fmaf(1.0f - fmaf(m.f0[2], A, m.f90 * B), T.z, acc.t.z) * m.diffuse[2];
+        const float fb = m.f90 * AB.y;
+        float tx = fmaf(1.0f - fmaf(m.f0[0], AB.x, fb), T.x, acc.st[0].y) * m.diffuse[0];
+        float ty = fmaf(1.0f - fmaf(m.f0[1], AB.x, fb), T.y, acc.st[1].y) * m.diffuse[1];
+        float tz = fmaf(1.0f - fmaf(m.f0[2], AB.x, fb), T.z, acc.st[2].y) * m.diffuse[2];
         // lib.rs:157-159: real = tf * transmission; diffuse = lerp(diffuse, real, tf)
         float tf = m.transmission_factor;
         diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
@@ -434,8 +528,8 @@ __device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_ta
         diffuse.z = fmaf(fmaf(tf, tz, -diffuse.z), tf, diffuse.z);
     }
 
-    f3 out = {diffuse.x + acc.s.x + m.emission[0], diffuse.y + acc.s.y + m.emission[1],
-              diffuse.z + acc.s.z + m.emission[2]};
+    f3 out = {diffuse.x + acc.st[0].x + m.emission[0], diffuse.y + acc.st[1].x + m.emission[1],
+              diffuse.z + acc.st[2].x + m.emission[2]};
     if constexpr (!TRANSMISSIVE) {
         if (fp.debug_clusters != 0u) {  // lib.rs:241-245
             f3 a = debug_colour_for_id(num_lights), b = debug_colour_for_id(cluster);
@@ -446,66 +540,96 @@ __device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_ta
 }
 
 // ------------------------------------------------------------------------ the shading kernel
-// grid: 1-D over 64x4 tiles of the rect, renumbered per XCD (see top of file); block: 256.
+// Persistent workgroups: grid = 8 * k blocks of 256 threads (k per XCD; hardware block b runs on XCD
+// b % 8).  The 64x4-pixel tiles of the rect are cut into 8 contiguous bands, one per XCD, and the k
+// blocks of an XCD sweep their band front to back, so at any moment an XCD's L2 serves a compact
+// window of the screen (and of the opaque pyramid behind it).  A wave is a 16x4 pixel tile — few
+// waves straddle a material or cluster border, every plane row segment is still >= one 128 B line —
+// and the G-buffer of the block's next tile is already in flight while the current one is shaded.
+// Every table is its own `const __restrict__` kernel argument (noalias).
+struct tile_regs {
+    float4 pd, ns;
+    uint32_t mat, cluster_xy, px, py;
+};
+
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */>
-__global__ __launch_bounds__(256) void shade_kernel(const tr_frame_params fp, const tr_tables tb,
-                                                    const float4* __restrict__ pos_depth,
-                                                    const float4* __restrict__ nrm_scale,
-                                                    const uint32_t* __restrict__ material_id,
-                                                    const uint2* __restrict__ pyramid, OutT* __restrict__ hdr,
-                                                    uint2* __restrict__ mip0) {
-    // XCD-aware renumbering: hardware block b runs on XCD b % 8; give XCD x the x-th eighth of the tiles.
+__global__ __launch_bounds__(256) void shade_kernel(
+    const tr_frame_params fp, const tr_dmat* __restrict__ dmats, const tr_dlight* __restrict__ lights,
+    const uint32_t* __restrict__ cluster_counts, const uint32_t* __restrict__ light_indices,
+    const uint32_t* __restrict__ lut_pairs, const tr_level_table* __restrict__ levels,
+    const uint16_t* __restrict__ cluster_x, const uint32_t* __restrict__ cluster_y_term,
+    const float4* __restrict__ pos_depth, const float4* __restrict__ nrm_scale,
+    const uint32_t* __restrict__ material_id, const uint2* __restrict__ pyramid, OutT* __restrict__ hdr,
+    uint2* __restrict__ mip0) {
+    const tr_tables tb = {as_constant(dmats), as_constant(lights), as_constant(cluster_counts),
+                          as_constant(light_indices), lut_pairs, as_constant(levels), cluster_x,
+                          as_constant(cluster_y_term)};
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lx = wave * 16u + (lane & 15u), ly = lane >> 4;  // position inside the 64x4 block tile
+
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
-    uint32_t b = blockIdx.x;
-    const uint32_t per = ntiles >> 3;
-    uint32_t tile = (b < per * 8u) ? ((b & 7u) * per + (b >> 3)) : b;
-    const uint32_t tyi = tile / fp.tiles_x;
-    const uint32_t txi = tile - tyi * fp.tiles_x;
+    const uint32_t xcd = blockIdx.x & 7u, stride = gridDim.x >> 3;
+    const uint32_t per = ntiles >> 3, rem = ntiles & 7u;
+    const uint32_t band_start = xcd * per + min(xcd, rem);
+    const uint32_t band_len = per + (xcd < rem ? 1u : 0u);
 
-    const uint32_t lane_x = threadIdx.x & 63u, wave_y = threadIdx.x >> 6;
-    const uint32_t px = fp.rect_x0 + txi * 64u + lane_x;
-    const uint32_t py = fp.rect_y0 + tyi * 4u + wave_y;
-    const bool inside = px < fp.rect_x1 && py < fp.rect_y1;
-    const size_t pix = (size_t)py * fp.width + px;                                        // colour targets
-    const size_t gpix = (size_t)(py - fp.g_origin_y) * fp.g_width + (px - fp.g_origin_x);  // G-buffer planes
+    // Branch-free: out-of-rect lanes read a clamped (valid) pixel and are masked later, and the prefetch
+    // past the end of the band re-reads the last tile.  With no branch around the loads the compiler
+    // can wait for exactly the older tile's loads (s_waitcnt vmcnt(N)) and leave the prefetch in flight.
+    auto fetch = [&](uint32_t j, tile_regs& t) {
+        const uint32_t tile = band_start + min(j, band_len - 1u);
+        const uint32_t tyi = tile / fp.tiles_x;
+        const uint32_t txi = tile - tyi * fp.tiles_x;
+        t.px = fp.rect_x0 + txi * 64u + lx;
+        t.py = fp.rect_y0 + tyi * 4u + ly;
+        const uint32_t cx = min(t.px, fp.rect_x1 - 1u), cy = min(t.py, fp.rect_y1 - 1u);
+        const size_t gpix = (size_t)(cy - fp.g_origin_y) * fp.g_width + (cx - fp.g_origin_x);
+        t.mat = material_id[gpix];
+        t.pd = pos_depth[gpix];
+        t.ns = nrm_scale[gpix];
+        t.cluster_xy = (uint32_t)cluster_x[cx] + cluster_y_term[cy];
+    };
 
-    uint32_t mat = TR_NOT_COVERED;
-    float4 pd = {0.f, 0.f, 0.f, 0.5f}, ns = {0.f, 0.f, 1.f, 1.f};
-    if (inside) {
-        mat = material_id[gpix];
-        pd = pos_depth[gpix];
-        ns = nrm_scale[gpix];
-    }
-    const bool active = inside && mat != TR_NOT_COVERED;
-    const uint64_t amask = __ballot(active);
+    uint32_t j = blockIdx.x >> 3;
+    if (j >= band_len) return;
+    tile_regs cur, nxt;
+    fetch(j, cur);
+    while (j < band_len) {
+        const uint32_t jn = j + stride;
+        fetch(jn, nxt);  // in flight while `cur` is shaded
 
-    if constexpr (!TRANSMISSIVE) {
-        // uncovered pixels of the opaque pass get the clear colour (src/main.rs:1592-1601)
-        if (inside && !active) {
-            if constexpr (sizeof(OutT) == 8) hdr[pix] = pack_rgba16f(0.f, 0.f, 0.f, 1.f);
-            else hdr[pix] = OutT{0.f, 0.f, 0.f, 1.f};
-            if (mip0) mip0[pix] = pack_rgba16f(0.f, 0.f, 0.f, 1.f);
+        const bool inside = cur.px < fp.rect_x1 && cur.py < fp.rect_y1;
+        const bool active = inside && cur.mat != TR_NOT_COVERED;
+        // One material at a time through the scalar unit; a wave that straddles k materials loops k times.
+        f3 out = {0.f, 0.f, 0.f};  // clear colour of the opaque pass (src/main.rs:1592-1601)
+        uint64_t todo = __ballot(active);
+        if (fp.ablate & 32u) {  // profiling only: pure streaming skeleton
+            todo = 0;
+            out = f3{cur.pd.x + cur.ns.x + (float)cur.mat, cur.pd.y + cur.ns.y + (float)cur.cluster_xy, cur.pd.z + cur.ns.z + cur.pd.w + cur.ns.w};
         }
-    }
-    if (amask == 0ull) return;
-
-    const int first = __ffsll((unsigned long long)amask) - 1;
-    uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)mat, first);
-    const bool uniform = __ballot(active && mat != m0) == 0ull;
-    f3 out;
-    if (uniform) {
-        m0 = __builtin_amdgcn_readfirstlane(m0);
-        out = shade_pixel<TRANSMISSIVE, true>(fp, tb, tb.dmats[m0], pyramid, pd, ns, px, py, active, amask);
-    } else {
-        const tr_dmat m = tb.dmats[active ? mat : m0];
-        out = shade_pixel<TRANSMISSIVE, false>(fp, tb, m, pyramid, pd, ns, px, py, active, amask);
-    }
-    if (active) {
-        if constexpr (sizeof(OutT) == 8) hdr[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
-        else hdr[pix] = OutT{out.x, out.y, out.z, 1.0f};
-        if constexpr (!TRANSMISSIVE) {
-            if (mip0) mip0[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
+        while (todo) {
+            const int l0 = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)cur.mat, l0);
+            const uint64_t group = __ballot(active && cur.mat == m0);
+            todo &= ~group;
+            // Membership is read back from the ballot mask, not from `mat == m0`: inside `if (mat == m0)` the
+            // optimiser substitutes the per-lane `mat` for the scalar `m0` and the table reads turn into
+            // per-lane vector loads.
+            if ((group >> lane) & 1ull)
+                out = shade_pixel<TRANSMISSIVE>(fp, tb, tb.dmats[m0], pyramid, cur.pd, cur.ns, lane, cur.cluster_xy);
         }
+        // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
+        if (TRANSMISSIVE ? active : inside) {
+            const size_t pix = (size_t)cur.py * fp.width + cur.px;
+            if constexpr (sizeof(OutT) == 8) hdr[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
+            else hdr[pix] = OutT{out.x, out.y, out.z, 1.0f};
+            if constexpr (!TRANSMISSIVE) {
+                if (mip0) mip0[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
+            }
+        }
+        cur = nxt;
+        j = jn;
     }
 }
 
@@ -526,8 +650,12 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
     const float ior_clamp = fminf(fmaxf(ior * 2.0f - 2.0f, 0.0f), 1.0f);
     const float alpha = rough * rough;
     const float alpha_t = alpha * ior_clamp;                         // ActualRoughness::apply_ior :144-146
-    d.a2 = alpha * alpha;
-    d.at2 = alpha_t * alpha_t;
+    d.a2[0] = alpha * alpha;
+    d.a2[1] = alpha_t * alpha_t;
+    for (int k = 0; k < 2; ++k) {
+        d.oma2[k] = 1.0f - d.a2[k];
+        d.k[k] = d.a2[k] * (0.5f * kFrac1Pi);
+    }
     d.f90 = mi.specular_factor + (1.0f - mi.specular_factor) * metallic;  // calculate_combined_f90
     for (int k = 0; k < 3; ++k) {
         float diff = mi.diffuse_factor[k];
@@ -558,13 +686,13 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
     int a = (int)fl, mx = (int)lut_height - 1;
     d.lut_row0 = (uint32_t)min(max(a, 0), mx) * lut_stride;
     d.lut_row1 = (uint32_t)min(max(a + 1, 0), mx) * lut_stride;
-    d._pad[0] = d._pad[1] = d._pad[2] = 0u;
+    for (int k = 0; k < 7; ++k) d._pad[k] = 0u;
     out[i] = d;
 }
 
-// GGX LUT -> pair table: entry k of a row holds (R,G) of texels clamp(k-2) and clamp(k-1)... see below.
-// For the unclamped left tap i0 = floor(u*w - 0.5) in [-1, w], entry k = i0 + 1 holds texel
-// clamp(i0) in its low half and clamp(i0 + 1) in its high half: one dword load per row.
+// GGX LUT -> pair table.  For the unclamped left tap i0 = floor(u*w - 0.5) in [-1, w], entry
+// k = i0 + 1 of a row holds (R,G) of texel clamp(i0) in its low half and of texel clamp(i0 + 1)
+// in its high half: both horizontal neighbours in one dword load.
 __global__ void build_lut_pairs_kernel(const uint32_t* __restrict__ rgba8, uint32_t* __restrict__ pairs, uint32_t w,
                                        uint32_t h, uint32_t stride) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

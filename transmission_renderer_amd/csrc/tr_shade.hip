@@ -7,6 +7,7 @@
 #include "tr_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -16,6 +17,7 @@ using namespace tr;
 struct tr_context {
     int device = 0;
     int32_t last_hip_error = 0;
+    uint32_t blocks_per_xcd = 128;  // (CUs / 8) * 4 resident blocks per CU
 
     // materials
     tr_material_info* d_materials_raw = nullptr;
@@ -44,6 +46,14 @@ struct tr_context {
     tr_level_table* d_levels = nullptr;
     tr_level_table h_levels{};
     uint32_t h_levels_count = 0;
+
+    // cluster x / y lookup tables (exact u32(frag_coord / cluster_size), shader/src/lib.rs:89)
+    uint16_t* d_cluster_x = nullptr;
+    uint32_t* d_cluster_y_term = nullptr;
+    uint32_t cl_w = 0, cl_h = 0, cl_cap_w = 0, cl_cap_h = 0, cl_ncx = 0;
+    float cl_sx = 0.0f, cl_sy = 0.0f;
+    std::vector<uint16_t> stage_cluster_x;
+    std::vector<uint32_t> stage_cluster_y;
 };
 
 namespace {
@@ -89,9 +99,59 @@ tr_status ensure_levels(tr_context* ctx, const tr_pyramid* p, hipStream_t stream
         ctx->h_levels.offset[l] = p->level_offset[l];
         ctx->h_levels.width[l] = level_dim(p->width, l);
         ctx->h_levels.height[l] = level_dim(p->height, l);
+        ctx->h_levels.wf[l] = (float)ctx->h_levels.width[l];
+        ctx->h_levels.hf[l] = (float)ctx->h_levels.height[l];
     }
     ctx->h_levels_count = p->levels;
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_levels, &ctx->h_levels, sizeof(tr_level_table), hipMemcpyHostToDevice, stream));
+    return TR_OK;
+}
+
+// Rust `f32 as u32`: saturating, NaN -> 0
+inline uint32_t f32_as_u32(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+// cluster_xy = (frag_coord.xy / cluster_size_in_pixels).as_uvec2() (shader/src/lib.rs:89) for every
+// column / row of the frame, with the reference's own IEEE fp32 division, done once per geometry.
+tr_status ensure_cluster_tables(tr_context* ctx, const tr_uniforms* u, uint32_t fw, uint32_t fh, hipStream_t stream) {
+    const float sx = u->cluster_size_in_pixels[0], sy = u->cluster_size_in_pixels[1];
+    const uint32_t ncx = u->num_clusters[0];
+    if (ctx->d_cluster_x && ctx->cl_w == fw && ctx->cl_h == fh && ctx->cl_sx == sx && ctx->cl_sy == sy &&
+        ctx->cl_ncx == ncx)
+        return TR_OK;
+    if (fw > ctx->cl_cap_w) {
+        (void)hipFree(ctx->d_cluster_x);
+        ctx->d_cluster_x = nullptr;
+        ctx->cl_cap_w = 0;
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_cluster_x, sizeof(uint16_t) * fw));
+        ctx->cl_cap_w = fw;
+    }
+    if (fh > ctx->cl_cap_h) {
+        (void)hipFree(ctx->d_cluster_y_term);
+        ctx->d_cluster_y_term = nullptr;
+        ctx->cl_cap_h = 0;
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_cluster_y_term, sizeof(uint32_t) * fh));
+        ctx->cl_cap_h = fh;
+    }
+    ctx->stage_cluster_x.resize(fw);
+    ctx->stage_cluster_y.resize(fh);
+    for (uint32_t x = 0; x < fw; ++x) {
+        uint32_t c = f32_as_u32(((float)x + 0.5f) / sx);
+        ctx->stage_cluster_x[x] = (uint16_t)(c > 0xFFFFu ? 0xFFFFu : c);
+    }
+    for (uint32_t y = 0; y < fh; ++y) ctx->stage_cluster_y[y] = f32_as_u32(((float)y + 0.5f) / sy) * ncx;
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_cluster_x, ctx->stage_cluster_x.data(), sizeof(uint16_t) * fw,
+                               hipMemcpyHostToDevice, stream));
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_cluster_y_term, ctx->stage_cluster_y.data(), sizeof(uint32_t) * fh,
+                               hipMemcpyHostToDevice, stream));
+    ctx->cl_w = fw;
+    ctx->cl_h = fh;
+    ctx->cl_sx = sx;
+    ctx->cl_sy = sy;
+    ctx->cl_ncx = ncx;
     return TR_OK;
 }
 
@@ -108,14 +168,17 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     fp->log2_fb_width = std::log2((float)pc->framebuffer_size[0]);  // glam-pbr/src/lib.rs:334
     std::memcpy(fp->sun_dir, u->sun_dir, sizeof(fp->sun_dir));
     std::memcpy(fp->sun_intensity, u->sun_intensity, sizeof(fp->sun_intensity));
-    fp->z_near = u->light_clustering_coefficients.z_near;
-    fp->z_far = u->light_clustering_coefficients.z_far;
-    fp->lcc_scale = u->light_clustering_coefficients.scale;
-    fp->lcc_bias = u->light_clustering_coefficients.bias;
-    fp->cluster_size_px[0] = u->cluster_size_in_pixels[0];
-    fp->cluster_size_px[1] = u->cluster_size_in_pixels[1];
-    fp->num_clusters_x = u->num_clusters[0];
-    fp->num_clusters_y = u->num_clusters[1];
+    {
+        // get_depth_slice (shared-structs/src/lib.rs:54-63) folded: linear = 2nf / (2n + 2 d (f - n)), so
+        // log2(linear) * scale + bias = K - scale * log2(slice_a * d + slice_b)
+        const tr_light_cluster_coefficients& c = u->light_clustering_coefficients;
+        const double n = c.z_near, f = c.z_far;
+        fp->lcc_scale = c.scale;
+        fp->slice_a = (float)(2.0 * (f - n));
+        fp->slice_b = (float)(2.0 * n);
+        fp->slice_k = (float)(std::log2(2.0 * n * f) * (double)c.scale + (double)c.bias);
+    }
+    fp->clusters_xy = u->num_clusters[0] * u->num_clusters[1];
     fp->num_clusters_total = ctx->num_clusters_total;
     fp->debug_clusters = u->debug_clusters;
     fp->width = fw;
@@ -129,20 +192,41 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     fp->rect_y1 = rect.y1;
     fp->tiles_x = (rect.x1 - rect.x0 + 63u) / 64u;
     fp->tiles_y = (rect.y1 - rect.y0 + 3u) / 4u;
+    if (const char* e = std::getenv("TR_ABLATE")) fp->ablate = (uint32_t)std::atoi(e);  // profiling only
     fp->lut_width = ctx->lut_w;
-    fp->lut_height = ctx->lut_h;
     fp->lut_stride = ctx->lut_stride;
     return TR_OK;
 }
 
-tr_tables make_tables(const tr_context* ctx) {
-    tr_tables tb;
+// Persistent grid: 8 XCDs x k blocks, k chosen so that every CU holds its 4 resident 256-thread blocks.
+uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles) {
+    const uint32_t per_xcd = (ntiles + 7u) / 8u;
+    uint32_t k = ctx->blocks_per_xcd < per_xcd ? ctx->blocks_per_xcd : per_xcd;
+    if (k == 0) k = 1;
+    return 8u * k;
+}
+
+struct host_tables {  // the table pointers of one launch (plain global pointers on the host side)
+    const tr_dmat* dmats;
+    const tr_dlight* lights;
+    const uint32_t* cluster_counts;
+    const uint32_t* light_indices;
+    const uint32_t* lut_pairs;
+    const tr_level_table* levels;
+    const uint16_t* cluster_x;
+    const uint32_t* cluster_y_term;
+};
+
+host_tables make_tables(const tr_context* ctx) {
+    host_tables tb;
     tb.dmats = ctx->d_dmats;
     tb.lights = ctx->d_lights;
     tb.cluster_counts = ctx->d_cluster_counts;
     tb.light_indices = ctx->d_light_indices;
     tb.lut_pairs = ctx->d_lut_pairs;
     tb.levels = ctx->d_levels;
+    tb.cluster_x = ctx->d_cluster_x;
+    tb.cluster_y_term = ctx->d_cluster_y_term;
     return tb;
 }
 
@@ -182,6 +266,12 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
     tr_context* ctx = new (std::nothrow) tr_context();
     if (!ctx) return TR_ERR_OUT_OF_MEMORY;
     ctx->device = device_ordinal;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount >= 8)
+            ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * 4u;
+        if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
+    }
     if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess) {
         delete ctx;
         return TR_ERR_OUT_OF_MEMORY;
@@ -200,6 +290,8 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_lut_rgba8);
     (void)hipFree(ctx->d_lut_pairs);
     (void)hipFree(ctx->d_levels);
+    (void)hipFree(ctx->d_cluster_x);
+    (void)hipFree(ctx->d_cluster_y_term);
     delete ctx;
     return TR_OK;
 }
@@ -333,15 +425,21 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     if (st != TR_OK) return st;
     st = ensure_digested(ctx, stream);
     if (st != TR_OK) return st;
+    st = ensure_cluster_tables(ctx, u, fp.width, fp.height, stream);
+    if (st != TR_OK) return st;
     fp.pyr_levels = 1;
-    const tr_tables tb = make_tables(ctx);
-    const dim3 grid(fp.tiles_x * fp.tiles_y), block(256);
+    const host_tables tb = make_tables(ctx);
+    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y)), block(256);
     if (format == TR_FORMAT_RGBA16F)
-        hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, fp, tb, (const float4*)g->pos_depth,
+        hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, fp, tb.dmats, tb.lights, tb.cluster_counts,
+                           tb.light_indices, tb.lut_pairs, tb.levels, tb.cluster_x, tb.cluster_y_term,
+                           (const float4*)g->pos_depth,
                            (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)nullptr,
                            (uint2*)hdr_out, (uint2*)opaque_mip0_out);
     else
-        hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, fp, tb, (const float4*)g->pos_depth,
+        hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, fp, tb.dmats, tb.lights, tb.cluster_counts,
+                           tb.light_indices, tb.lut_pairs, tb.levels, tb.cluster_x, tb.cluster_y_term,
+                           (const float4*)g->pos_depth,
                            (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)nullptr,
                            (float4*)hdr_out, (uint2*)opaque_mip0_out);
     TR_HIP(ctx, hipGetLastError());
@@ -380,15 +478,21 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     if (st != TR_OK) return st;
     st = ensure_levels(ctx, p, stream);
     if (st != TR_OK) return st;
+    st = ensure_cluster_tables(ctx, u, fp.width, fp.height, stream);
+    if (st != TR_OK) return st;
     fp.pyr_levels = p->levels;
-    const tr_tables tb = make_tables(ctx);
-    const dim3 grid(fp.tiles_x * fp.tiles_y), block(256);
+    const host_tables tb = make_tables(ctx);
+    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y)), block(256);
     if (format == TR_FORMAT_RGBA16F)
-        hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, fp, tb, (const float4*)g->pos_depth,
+        hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, fp, tb.dmats, tb.lights, tb.cluster_counts,
+                           tb.light_indices, tb.lut_pairs, tb.levels, tb.cluster_x, tb.cluster_y_term,
+                           (const float4*)g->pos_depth,
                            (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)p->texels,
                            (uint2*)hdr_inout, (uint2*)nullptr);
     else
-        hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, fp, tb, (const float4*)g->pos_depth,
+        hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, fp, tb.dmats, tb.lights, tb.cluster_counts,
+                           tb.light_indices, tb.lut_pairs, tb.levels, tb.cluster_x, tb.cluster_y_term,
+                           (const float4*)g->pos_depth,
                            (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)p->texels,
                            (float4*)hdr_inout, (uint2*)nullptr);
     TR_HIP(ctx, hipGetLastError());
