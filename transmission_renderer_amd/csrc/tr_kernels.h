@@ -189,8 +189,12 @@ __device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, f3 n, f3 v,
     if constexpr (TRANSMISSIVE) {
         // lobe 0: basic_brdf (glam-pbr/src/lib.rs:377-423); lobe 1: transmission_btdf (:200-233)
         const v2f vlp = {vl, fmaf(-2.0f * nl_raw, nov_raw, vl)};            // v.l , v.l'
-        const v2f s = pk_fma(splat(2.0f), vlp, splat(2.0f));               // |v+l|^2 (|v| = |l| = 1)
-        const v2f inv_h = {rsq(s.x), rsq(s.y)};
+        // |v+l|^2 (|v| = |l| = 1).  It vanishes where v = -l; for the mirrored light that is exactly the
+        // specular peak of the reflection lobe (v + l' = (v+l) - 2 (n.l) n = 0 when h = n), so it is hit on
+        // real pixels and rounding can push it below zero: floor it (the reference normalises a ~1e-8 vector
+        // there and gets an arbitrary but finite h; F' = f90 makes the lobe's weight vanish either way).
+        const v2f s = pk_fma(splat(2.0f), vlp, splat(2.0f));
+        const v2f inv_h = {rsq(fmaxf(s.x, 1e-12f)), rsq(fmaxf(s.y, 1e-12f))};
         const v2f voh = pk_max((vlp + 1.0f) * inv_h, kEpsilon);            // Dot::new clamps to EPSILON (:93-98)
         const v2f nol = {fmaxf(nl_raw, kEpsilon), fmaxf(-nl_raw, kEpsilon)};  // n.l , n.l' = -(n.l)
         const v2f omv = 1.0f - voh;
@@ -221,7 +225,7 @@ __device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, f3 n, f3 v,
         acc.st[1] = pk_fma(pk_fma(F1, sgn, off) * I.y, w, acc.st[1]);
         acc.st[2] = pk_fma(pk_fma(F2, sgn, off) * I.z, w, acc.st[2]);
     } else {
-        const float inv_h = rsq(fmaf(2.0f, vl, 2.0f));
+        const float inv_h = rsq(fmaxf(fmaf(2.0f, vl, 2.0f), 1e-12f));
         const float voh = fmaxf((1.0f + vl) * inv_h, kEpsilon);
         const float nol = fmaxf(nl_raw, kEpsilon);
         const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
