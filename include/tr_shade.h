@@ -195,7 +195,9 @@ int32_t     tr_last_hip_error(const tr_context* ctx);
 uint32_t    tr_abi_version(void);
 
 /* mip_levels_for_size (src/main.rs:2590-2592) and the packed layout above.
- * `texels` is left NULL; total size in bytes is returned through out_bytes. */
+ * `texels` is left NULL; the size to allocate is returned through out_bytes.  It includes 8 bytes of
+ * tail padding after the last texel: the sampler fetches texels in 16-byte pairs and may read (never
+ * use) them.  The allocation must be at least out_bytes. */
 tr_status tr_pyramid_layout(uint32_t width, uint32_t height, tr_pyramid* out_pyramid, size_t* out_bytes);
 
 /* -------------------------------------------------------------------- tables */

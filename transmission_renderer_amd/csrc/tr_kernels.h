@@ -92,6 +92,7 @@ struct tr_level_table {           // pyramid geometry, one entry per mip level
     uint32_t height[TR_MAX_MIP_LEVELS];
     float wf[TR_MAX_MIP_LEVELS];         // (float)width, (float)height
     float hf[TR_MAX_MIP_LEVELS];
+    float xlim[TR_MAX_MIP_LEVELS];       // max(width - 2, 0): left texel of the right-most 16-byte pair
 };
 
 // Everything a shading launch needs besides the planes; passed by value (kernarg -> SGPRs).
@@ -132,16 +133,36 @@ __device__ __forceinline__ const TR_CONSTANT T* as_constant(const T* p) {
     return (const TR_CONSTANT T*)(p);
 }
 
-struct tr_tables {
-    cdmat* dmats;
-    cdlight* lights;
-    cu32* cluster_counts;
-    cu32* light_indices;
-    const uint32_t* __restrict__ lut_pairs;      // (R,G)[x-1], (R,G)[x] per entry
-    clevels* levels;
-    const uint16_t* __restrict__ cluster_x;      // [frame width]  u32(frag_coord.x / cluster_size.x)
-    cu32* cluster_y_term;                        // [frame height] u32(frag_coord.y / cluster_size.y) * num_clusters.x
+// The single kernel argument of shade_kernel: frame parameters and every pointer.  The kernel reads it
+// through the kernarg segment pointer, re-"laundered" at the start of each phase (`launder`): a value
+// is then fetched by s_load in the phase that uses it instead of being loaded in the prologue and kept
+// (or spilled to VGPR lanes — ~100 v_readlane/v_writelane per tile before this) across the whole kernel.
+struct tr_launch {
+    tr_frame_params fp;
+    const tr_dmat* dmats;
+    const tr_dlight* lights;
+    const uint32_t* cluster_counts;
+    const uint32_t* light_indices;
+    const uint32_t* lut_pairs;          // (R,G)[x-1], (R,G)[x] per entry
+    const tr_level_table* levels;
+    const uint16_t* cluster_x;          // [frame width]  u32(frag_coord.x / cluster_size.x)
+    const uint32_t* cluster_y_term;     // [frame height] u32(frag_coord.y / cluster_size.y) * num_clusters.x
+    const float4* pos_depth;
+    const float4* nrm_scale;
+    const uint32_t* material_id;
+    const uint2* pyramid;
+    void* hdr;
+    uint2* mip0;
 };
+typedef const TR_CONSTANT tr_launch claunch;
+
+// Makes a (uniform) pointer opaque to the optimiser: loads through the result cannot be hoisted above
+// this point, so their live ranges start here.
+template <class T>
+__device__ __forceinline__ T* launder(T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
 
 // ------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -177,11 +198,20 @@ struct light_acc {
 //   clamped to EPSILON by Dot::new when n.h <= 0 (:93-98): then f = 1 + eps^2 (a2 - 1) = 1.
 //   |n x (v+l)|^2 is shared by both lobes: the mirrored light l' = l - 2 (n.l) n differs from l by
 //   a multiple of n, and n x n = 0.
+// Per-pixel, light-independent inputs of eval_light.
+struct pixel_frame {
+    f3 n, v;           // unit normal and view vector
+    v2f nvx, nvy, nvz; // { n , v } component pairs: n.l and v.l come out of three packed ops
+    float nov_raw, nov;  // n.v and max(n.v, EPSILON)
+    v2f g_nov;         // sqrt(n.v^2 (1 - a2) + a2) per lobe: the light-independent half of v_smith
+};
+
 template <bool TRANSMISSIVE>
-__device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, f3 n, f3 v, float nov_raw, float nov,
-                                           f3 l, f3 I) {
-    const float nl_raw = dot3(n.x, n.y, n.z, l.x, l.y, l.z);
-    const float vl = dot3(v.x, v.y, v.z, l.x, l.y, l.z);
+__device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, const pixel_frame& px, f3 l, f3 I) {
+    const f3 n = px.n, v = px.v;
+    const float nov_raw = px.nov_raw, nov = px.nov;
+    const v2f nlvl = pk_fma(px.nvz, splat(l.z), pk_fma(px.nvy, splat(l.y), px.nvx * l.x));
+    const float nl_raw = nlvl.x, vl = nlvl.y;
     const float hx = v.x + l.x, hy = v.y + l.y, hz = v.z + l.z;
     const float cx = fmaf(n.y, hz, -(n.z * hy)), cy = fmaf(n.z, hx, -(n.x * hz)), cz = fmaf(n.x, hy, -(n.y * hx));
     const float c2 = dot3(cx, cy, cz, cx, cy, cz);
@@ -206,8 +236,8 @@ __device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, f3 n, f3 v,
         f.x = (nov_raw + nl_raw) > 0.0f ? f.x : 1.0f;
         f.y = (nov_raw - nl_raw) > 0.0f ? f.y : 1.0f;
         // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal per lobe
-        const v2f ra = pk_fma(splat(nov * nov), oma2, a2), rb = pk_fma(nol * nol, oma2, a2);
-        const v2f g = nol * v2f{fast_sqrt(ra.x), fast_sqrt(ra.y)} + nov * v2f{fast_sqrt(rb.x), fast_sqrt(rb.y)};
+        const v2f rb = pk_fma(nol * nol, oma2, a2);
+        const v2f g = nol * px.g_nov + nov * v2f{fast_sqrt(rb.x), fast_sqrt(rb.y)};
         const v2f den = f * f * g;
         v2f dv = kk * v2f{rcp(den.x), rcp(den.y)};
         dv.x = g.x > 0.0f ? dv.x : 0.0f;
@@ -231,8 +261,7 @@ __device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, f3 n, f3 v,
         const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
         const float sin2 = c2 * (inv_h * inv_h);
         const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
-        const float g = nol * fast_sqrt(fmaf(nov * nov, m.oma2[0], m.a2[0])) +
-                        nov * fast_sqrt(fmaf(nol * nol, m.oma2[0], m.a2[0]));
+        const float g = nol * px.g_nov.x + nov * fast_sqrt(fmaf(nol * nol, m.oma2[0], m.a2[0]));
         float dv = m.k[0] * rcp(f * f * g);
         dv = g > 0.0f ? dv : 0.0f;
         const float Fx = fmaf(m.df[0], p, m.f0[0]), Fy = fmaf(m.df[1], p, m.f0[1]), Fz = fmaf(m.df[2], p, m.f0[2]);
@@ -248,8 +277,7 @@ __device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, f3 n, f3 v,
 }
 
 template <bool TRANSMISSIVE>
-__device__ __forceinline__ void eval_punctual(light_acc& acc, cdmat& m, cdlight& L, f3 pos, f3 n, f3 v,
-                                              float nov_raw, float nov) {
+__device__ __forceinline__ void eval_punctual(light_acc& acc, cdmat& m, cdlight& L, f3 pos, const pixel_frame& px) {
     // light_direction_and_attenuation (glam-pbr/src/lib.rs:12-23): bare 1/d^2
     float dx = L.pos[0] - pos.x, dy = L.pos[1] - pos.y, dz = L.pos[2] - pos.z;
     float inv_d = rsq(dot3(dx, dy, dz, dx, dy, dz));
@@ -264,7 +292,7 @@ __device__ __forceinline__ void eval_punctual(light_acc& acc, cdmat& m, cdlight&
         }
     }
     f3 I = {L.colour[0] * att, L.colour[1] * att, L.colour[2] * att};
-    eval_light<TRANSMISSIVE>(acc, m, n, v, nov_raw, nov, l, I);
+    eval_light<TRANSMISSIVE>(acc, m, px, l, I);
 }
 
 // ------------------------------------------------------------------ opaque pyramid taps
@@ -290,14 +318,14 @@ struct pyramid_fetch {
     uint4 r0[2], r1[2];   // per level: row0 pair, row1 pair
     v2f wx, wy;
     float t;
+    bool narrow0, narrow1;  // (scalar) the level is one texel wide: the pair's second texel is not its neighbour
 };
 
-__device__ __forceinline__ void axis_pair(float u, v2f dimf, v2f& w, uint32_t (&b)[2]) {
+__device__ __forceinline__ void axis_pair(float u, v2f dimf, v2f limf, v2f& w, uint32_t (&b)[2]) {
     v2f x = pk_fma(splat(u), dimf, splat(-0.5f));
     v2f hi = dimf - 1.0f;
     v2f xc = {fminf(fmaxf(x.x, 0.0f), hi.x), fminf(fmaxf(x.y, 0.0f), hi.y)};
-    v2f lim = dimf - 2.0f;  // >= 0 on this path (both levels at least 2 texels wide)
-    v2f bf = {fminf(floorf(xc.x), lim.x), fminf(floorf(xc.y), lim.y)};
+    v2f bf = {fminf(floorf(xc.x), limf.x), fminf(floorf(xc.y), limf.y)};  // limf = max(w - 2, 0)
     w = xc - bf;
     b[0] = (uint32_t)bf.x;
     b[1] = (uint32_t)bf.y;
@@ -313,7 +341,10 @@ __device__ __forceinline__ void axis_single(float u, float dimf, float& w, uint3
 }
 
 // Issues the loads of framebuffer.sample_by_lod(clamp_sampler, uv, lod) (shader/src/lib.rs:135-138).
-// `lod` is wave-uniform (it depends on the material only), so level geometry is scalar.
+// `lod` is wave-uniform (it depends on the material only), so level geometry is scalar.  Every row of
+// every level is one 16-byte load of two adjacent texels; in a level that is a single texel wide the
+// second one belongs to the next row / level (or to the 8 bytes of tail padding tr_pyramid_layout
+// reserves) and is replaced by the first before use.
 __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __restrict__ texels,
                                               clevels* lv, uint32_t levels, float u, float v,
                                               float lod) {
@@ -322,44 +353,32 @@ __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __
     pf.t = l - lf;
     const uint32_t l0 = __builtin_amdgcn_readfirstlane((uint32_t)lf);
     const uint32_t l1 = min(l0 + 1u, levels - 1u);
-    const uint32_t w0 = lv->width[l0], w1 = lv->width[l1], h0 = lv->height[l0], h1 = lv->height[l1];
+    const uint32_t w0 = lv->width[l0], w1 = lv->width[l1];
     const uint2* b0 = texels + lv->offset[l0];
     const uint2* b1 = texels + lv->offset[l1];
-    if (w1 >= 2u) {  // (w0 >= w1): the common case, every row fetched as one 16-byte texel pair
-        uint32_t bx[2];
-        axis_pair(u, v2f{lv->wf[l0], lv->wf[l1]}, pf.wx, bx);
-        float wy0, wy1;
-        uint32_t y00, y01, y10, y11;
-        axis_single(v, lv->hf[l0], wy0, y00, y01);
-        axis_single(v, lv->hf[l1], wy1, y10, y11);
-        pf.wy = v2f{wy0, wy1};
-        auto ld = [](const uint2* p) {
-            u32x4 t = *reinterpret_cast<const u32x4_a8*>(p);  // one global_load_dwordx4
-            return uint4{t.x, t.y, t.z, t.w};
-        };
-        pf.r0[0] = ld(b0 + y00 * w0 + bx[0]);
-        pf.r1[0] = ld(b0 + y01 * w0 + bx[0]);
-        pf.r0[1] = ld(b1 + y10 * w1 + bx[1]);
-        pf.r1[1] = ld(b1 + y11 * w1 + bx[1]);
-    } else {         // a level narrower than 2 texels: single-texel loads, same arithmetic
-        float wx0, wx1, wy0, wy1;
-        uint32_t x00, x01, x10, x11, y00, y01, y10, y11;
-        axis_single(u, lv->wf[l0], wx0, x00, x01);
-        axis_single(u, lv->wf[l1], wx1, x10, x11);
-        axis_single(v, lv->hf[l0], wy0, y00, y01);
-        axis_single(v, lv->hf[l1], wy1, y10, y11);
-        pf.wx = v2f{wx0, wx1};
-        pf.wy = v2f{wy0, wy1};
-        uint2 a, b;
-        a = b0[y00 * w0 + x00]; b = b0[y00 * w0 + x01]; pf.r0[0] = uint4{a.x, a.y, b.x, b.y};
-        a = b0[y01 * w0 + x00]; b = b0[y01 * w0 + x01]; pf.r1[0] = uint4{a.x, a.y, b.x, b.y};
-        a = b1[y10 * w1 + x10]; b = b1[y10 * w1 + x11]; pf.r0[1] = uint4{a.x, a.y, b.x, b.y};
-        a = b1[y11 * w1 + x10]; b = b1[y11 * w1 + x11]; pf.r1[1] = uint4{a.x, a.y, b.x, b.y};
-    }
+    uint32_t bx[2];
+    axis_pair(u, v2f{lv->wf[l0], lv->wf[l1]}, v2f{lv->xlim[l0], lv->xlim[l1]}, pf.wx, bx);
+    float wy0, wy1;
+    uint32_t y00, y01, y10, y11;
+    axis_single(v, lv->hf[l0], wy0, y00, y01);
+    axis_single(v, lv->hf[l1], wy1, y10, y11);
+    pf.wy = v2f{wy0, wy1};
+    auto ld = [](const uint2* p) {
+        u32x4 t = *reinterpret_cast<const u32x4_a8*>(p);  // one global_load_dwordx4
+        return uint4{t.x, t.y, t.z, t.w};
+    };
+    pf.r0[0] = ld(b0 + y00 * w0 + bx[0]);
+    pf.r1[0] = ld(b0 + y01 * w0 + bx[0]);
+    pf.r0[1] = ld(b1 + y10 * w1 + bx[1]);
+    pf.r1[1] = ld(b1 + y11 * w1 + bx[1]);
+    pf.narrow0 = w0 < 2u;
+    pf.narrow1 = w1 < 2u;
 }
 
 // Filters the fetched texels: bilinear per level (lerp form, fp32), then across levels.
-__device__ __forceinline__ f3 pyramid_resolve(const pyramid_fetch& pf) {
+__device__ __forceinline__ f3 pyramid_resolve(pyramid_fetch& pf) {
+    if (pf.narrow0) { pf.r0[0].z = pf.r0[0].x; pf.r0[0].w = pf.r0[0].y; pf.r1[0].z = pf.r1[0].x; pf.r1[0].w = pf.r1[0].y; }
+    if (pf.narrow1) { pf.r0[1].z = pf.r0[1].x; pf.r0[1].w = pf.r0[1].y; pf.r1[1].z = pf.r1[1].x; pf.r1[1].w = pf.r1[1].y; }
     float out[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -427,31 +446,42 @@ __device__ __forceinline__ f3 debug_colour_for_id(uint32_t id) {
 // Runs with exec = the lanes of the wave that share material `m` (scalar registers).
 // `lane` = lane id in the wave; `cluster_xy` = cluster x + cluster y * num_clusters.x of this pixel.
 template <bool TRANSMISSIVE>
-__device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_tables& tb, cdmat& m,
-                                          const uint2* __restrict__ pyramid, float4 pd, float4 ns, uint32_t lane,
+__device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float4 ns, uint32_t lane,
                                           uint32_t cluster_xy) {
+    // ================= phase 1: frame of the pixel, cluster list request, refraction taps =================
+    L = launder(L);
+    m = launder(m);
     const f3 pos = {pd.x, pd.y, pd.z};
     // view = normalize(view_position - position) (lib.rs:79-80); normal = normalize(n) (lighting.rs:229)
-    float vx = fp.view_position[0] - pos.x, vy = fp.view_position[1] - pos.y, vz = fp.view_position[2] - pos.z;
+    float vx = L->fp.view_position[0] - pos.x, vy = L->fp.view_position[1] - pos.y, vz = L->fp.view_position[2] - pos.z;
     float inv_v = rsq(dot3(vx, vy, vz, vx, vy, vz));
     const f3 v = {vx * inv_v, vy * inv_v, vz * inv_v};
     float inv_n = rsq(dot3(ns.x, ns.y, ns.z, ns.x, ns.y, ns.z));
     const f3 n = {ns.x * inv_n, ns.y * inv_n, ns.z * inv_n};
     const float nov_raw = dot3(n.x, n.y, n.z, v.x, v.y, v.z);
     const float nov = fmaxf(nov_raw, kEpsilon);
+    pixel_frame px;
+    px.n = n;
+    px.v = v;
+    px.nvx = v2f{n.x, v.x};
+    px.nvy = v2f{n.y, v.y};
+    px.nvz = v2f{n.z, v.z};
+    px.nov_raw = nov_raw;
+    px.nov = nov;
 
     // ---- cluster lookup (shader/src/lib.rs:88-98): x / y from exact tables (cluster_xy), the depth slice of
     // shared-structs/src/lib.rs:54-63 folded to  slice = u32(max(K - scale * log2(2n + 2 depth (f - n)), 0)).
     // The light count and the first list entry are requested here so that they are back long before the loop.
-    const float zs = fmaf(-fp.lcc_scale, fast_log2(fmaf(pd.w, fp.slice_a, fp.slice_b)), fp.slice_k);
+    const float zs = fmaf(-L->fp.lcc_scale, fast_log2(fmaf(pd.w, L->fp.slice_a, L->fp.slice_b)), L->fp.slice_k);
     const uint32_t cz = (uint32_t)fmaxf(zs, 0.0f);  // v_cvt_u32_f32 saturates, NaN -> 0 (Rust `as u32`)
-    const uint32_t cluster = cz * fp.clusters_xy + cluster_xy;
-    const bool in_range = cluster < fp.num_clusters_total;  // out-of-range reads as 0 lights (robust access)
+    const uint32_t cluster = cz * L->fp.clusters_xy + cluster_xy;
+    const bool in_range = cluster < L->fp.num_clusters_total;  // out-of-range reads as 0 lights (robust access)
     const uint32_t csafe = in_range ? cluster : 0u;
-    const uint32_t* indices = (const uint32_t*)tb.light_indices + (size_t)csafe * TR_MAX_LIGHTS_PER_CLUSTER;
-    uint32_t num_lights = ((const uint32_t*)tb.cluster_counts)[csafe];   // per-lane (vector) reads
+    const uint32_t* indices = L->light_indices + (size_t)csafe * TR_MAX_LIGHTS_PER_CLUSTER;  // per-lane reads
+    uint32_t num_lights = L->cluster_counts[csafe];
     uint32_t head = indices[0];
     num_lights = in_range ? num_lights : 0u;
+    if (L->fp.ablate & 8u) num_lights = 0;
 
     // ---- ibl_volume_refraction, part 1 (glam-pbr/src/lib.rs:292-337): where the refracted ray leaves
     //      the volume, projected to the screen; the taps are in flight while the lights are evaluated.
@@ -460,39 +490,47 @@ __device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_ta
     float len = 0.0f;
     if constexpr (TRANSMISSIVE) {
         // refract(-v, n, ior) :248-256 ; unit length by construction (Snell), so no re-normalise
-        float eta = m.eta;
+        float eta = m->eta;
         float k = fmaf(-eta * eta, fmaf(-nov_raw, nov_raw, 1.0f), 1.0f);
         float cn = fmaf(-eta, nov_raw, fast_sqrt(k));   // eta * n.i + sqrt(k), n.i = -n.v
-        len = m.thickness * ns.w;                       // thickness * model_scale :264
+        len = m->thickness * ns.w;                      // thickness * model_scale :264
         float ex = fmaf(fmaf(-eta, v.x, -cn * n.x), len, pos.x);
         float ey = fmaf(fmaf(-eta, v.y, -cn * n.y), len, pos.y);
         float ez = fmaf(fmaf(-eta, v.z, -cn * n.z), len, pos.z);
-        const float* P = fp.proj_view;                  // column-major
+        const TR_CONSTANT float* P = L->fp.proj_view;   // column-major
         float cx = fmaf(P[8], ez, fmaf(P[4], ey, fmaf(P[0], ex, P[12])));
         float cy = fmaf(P[9], ez, fmaf(P[5], ey, fmaf(P[1], ex, P[13])));
         float cw = fmaf(P[11], ez, fmaf(P[7], ey, fmaf(P[3], ex, P[15])));
         float hw = 0.5f * rcp(cw);                      // (clip.xy / clip.w + 1) / 2  :330-332
         float tu = fmaf(cx, hw, 0.5f);
         float tv = fmaf(cy, hw, 0.5f);
-        float lod = fp.log2_fb_width * m.rough_ior;     // :334-335
-        if (!(fp.ablate & 1u)) pyramid_issue(pf, pyramid, tb.levels, fp.pyr_levels, tu, tv, lod);
-        else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; }
-        if (!(fp.ablate & 2u)) lut_issue(lf, tb.lut_pairs, (float)fp.lut_width, m, nov_raw);
+        float lod = L->fp.log2_fb_width * m->rough_ior; // :334-335
+        if (!(L->fp.ablate & 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod);
+        else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
+        if (!(L->fp.ablate & 2u)) lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, *m, nov_raw);
         else { lf.p0 = lf.p1 = 0x40404040u; lf.fx = nov_raw; }
     }
 
+    // ================= phase 2: the sun (lighting.rs:37-53 / 171-177) =================
+    L = launder(L);
+    m = launder(m);
+    {
+        const v2f ra = pk_fma(splat(nov * nov), v2f{m->oma2[0], m->oma2[1]}, v2f{m->a2[0], m->a2[1]});
+        px.g_nov = v2f{fast_sqrt(ra.x), TRANSMISSIVE ? fast_sqrt(ra.y) : 0.0f};
+    }
     light_acc acc = {{0.f, 0.f, 0.f}, {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}};
+    if (!(L->fp.ablate & 4u))
+        eval_light<TRANSMISSIVE>(acc, *m, px, {L->fp.sun_dir[0], L->fp.sun_dir[1], L->fp.sun_dir[2]},
+                                 {L->fp.sun_intensity[0], L->fp.sun_intensity[1], L->fp.sun_intensity[2]});
 
-    // sun (lighting.rs:37-53 / 171-177)
-    if (!(fp.ablate & 4u))
-    eval_light<TRANSMISSIVE>(acc, m, n, v, nov_raw, nov, {fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]},
-                             {fp.sun_intensity[0], fp.sun_intensity[1], fp.sun_intensity[2]});
-
-    // ---- clustered punctual lights (lighting.rs:55-92 / 179-217).  Every lane walks its own cluster's list
-    // (fetched at the top of this function); at each step the lanes whose next light index equals that of
-    // the first pending lane evaluate it together, with the light read through the scalar unit.  When the
-    // lists agree (the normal case, also across cluster boundaries) that is one pass per light.
-    if (!(fp.ablate & 8u)) {
+    // ================= phase 3: clustered punctual lights (lighting.rs:55-92 / 179-217) =================
+    // Every lane walks its own cluster's list (requested in phase 1); at each step the lanes whose next light
+    // index equals that of the first pending lane evaluate it together, with the light read through the scalar
+    // unit.  When the lists agree (the normal case, also across cluster boundaries) that is one pass per light.
+    {
+        L = launder(L);
+        m = launder(m);
+        cdlight* lights = as_constant(L->lights);
         uint32_t i = 0;
         uint64_t pending = __ballot(i < num_lights);
         while (pending) {
@@ -501,7 +539,7 @@ __device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_ta
             const uint64_t group = __ballot(i < num_lights && head == h0);
             if ((group >> lane) & 1ull) {  // membership from the mask keeps h0 scalar (see shade_kernel)
                 const uint32_t next = indices[min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u)];  // in flight during the eval
-                eval_punctual<TRANSMISSIVE>(acc, m, tb.lights[h0], pos, n, v, nov_raw, nov);
+                eval_punctual<TRANSMISSIVE>(acc, *m, lights[h0], pos, px);
                 ++i;
                 head = next;
             }
@@ -509,33 +547,36 @@ __device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_ta
         }
     }
 
-    f3 diffuse = {acc.d.x * m.c_diff[0], acc.d.y * m.c_diff[1], acc.d.z * m.c_diff[2]};
+    // ================= phase 4: resolve the taps, composite =================
+    L = launder(L);
+    m = launder(m);
+    f3 diffuse = {acc.d.x * m->c_diff[0], acc.d.y * m->c_diff[1], acc.d.z * m->c_diff[2]};
 
     if constexpr (TRANSMISSIVE) {
         // ---- ibl_volume_refraction, part 2 (:337-353)
         f3 T = pyramid_resolve(pf);
-        if (m.flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
-            T.x *= fast_exp2(m.neg_atten_log2[0] * len);
-            T.y *= fast_exp2(m.neg_atten_log2[1] * len);
-            T.z *= fast_exp2(m.neg_atten_log2[2] * len);
+        if (m->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
+            T.x *= fast_exp2(m->neg_atten_log2[0] * len);
+            T.y *= fast_exp2(m->neg_atten_log2[1] * len);
+            T.z *= fast_exp2(m->neg_atten_log2[2] * len);
         }
-        const v2f AB = lut_resolve(lf, m.lut_fy);
+        const v2f AB = lut_resolve(lf, m->lut_fy);
         // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
-        const float fb = m.f90 * AB.y;
-        float tx = fmaf(1.0f - fmaf(m.f0[0], AB.x, fb), T.x, acc.st[0].y) * m.diffuse[0];
-        float ty = fmaf(1.0f - fmaf(m.f0[1], AB.x, fb), T.y, acc.st[1].y) * m.diffuse[1];
-        float tz = fmaf(1.0f - fmaf(m.f0[2], AB.x, fb), T.z, acc.st[2].y) * m.diffuse[2];
+        const float fb = m->f90 * AB.y;
+        float tx = fmaf(1.0f - fmaf(m->f0[0], AB.x, fb), T.x, acc.st[0].y) * m->diffuse[0];
+        float ty = fmaf(1.0f - fmaf(m->f0[1], AB.x, fb), T.y, acc.st[1].y) * m->diffuse[1];
+        float tz = fmaf(1.0f - fmaf(m->f0[2], AB.x, fb), T.z, acc.st[2].y) * m->diffuse[2];
         // lib.rs:157-159: real = tf * transmission; diffuse = lerp(diffuse, real, tf)
-        float tf = m.transmission_factor;
+        float tf = m->transmission_factor;
         diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
         diffuse.y = fmaf(fmaf(tf, ty, -diffuse.y), tf, diffuse.y);
         diffuse.z = fmaf(fmaf(tf, tz, -diffuse.z), tf, diffuse.z);
     }
 
-    f3 out = {diffuse.x + acc.st[0].x + m.emission[0], diffuse.y + acc.st[1].x + m.emission[1],
-              diffuse.z + acc.st[2].x + m.emission[2]};
+    f3 out = {diffuse.x + acc.st[0].x + m->emission[0], diffuse.y + acc.st[1].x + m->emission[1],
+              diffuse.z + acc.st[2].x + m->emission[2]};
     if constexpr (!TRANSMISSIVE) {
-        if (fp.debug_clusters != 0u) {  // lib.rs:241-245
+        if (L->fp.debug_clusters != 0u) {  // lib.rs:241-245
             f3 a = debug_colour_for_id(num_lights), b = debug_colour_for_id(cluster);
             out = {fmaf(b.x - 0.5f, 0.025f, a.x), fmaf(b.y - 0.5f, 0.025f, a.y), fmaf(b.z - 0.5f, 0.025f, a.z)};
         }
@@ -550,29 +591,20 @@ __device__ __forceinline__ f3 shade_pixel(const tr_frame_params& fp, const tr_ta
 // window of the screen (and of the opaque pyramid behind it).  A wave is a 16x4 pixel tile — few
 // waves straddle a material or cluster border, every plane row segment is still >= one 128 B line —
 // and the G-buffer of the block's next tile is already in flight while the current one is shaded.
-// Every table is its own `const __restrict__` kernel argument (noalias).
 struct tile_regs {
     float4 pd, ns;
     uint32_t mat, cluster_xy, px, py;
 };
 
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */>
-__global__ __launch_bounds__(256) void shade_kernel(
-    const tr_frame_params fp, const tr_dmat* __restrict__ dmats, const tr_dlight* __restrict__ lights,
-    const uint32_t* __restrict__ cluster_counts, const uint32_t* __restrict__ light_indices,
-    const uint32_t* __restrict__ lut_pairs, const tr_level_table* __restrict__ levels,
-    const uint16_t* __restrict__ cluster_x, const uint32_t* __restrict__ cluster_y_term,
-    const float4* __restrict__ pos_depth, const float4* __restrict__ nrm_scale,
-    const uint32_t* __restrict__ material_id, const uint2* __restrict__ pyramid, OutT* __restrict__ hdr,
-    uint2* __restrict__ mip0) {
-    const tr_tables tb = {as_constant(dmats), as_constant(lights), as_constant(cluster_counts),
-                          as_constant(light_indices), lut_pairs, as_constant(levels), cluster_x,
-                          as_constant(cluster_y_term)};
+__global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_value) {
+    (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
+    claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lx = wave * 16u + (lane & 15u), ly = lane >> 4;  // position inside the 64x4 block tile
 
-    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    const uint32_t ntiles = L->fp.tiles_x * L->fp.tiles_y;
     const uint32_t xcd = blockIdx.x & 7u, stride = gridDim.x >> 3;
     const uint32_t per = ntiles >> 3, rem = ntiles & 7u;
     const uint32_t band_start = xcd * per + min(xcd, rem);
@@ -582,36 +614,32 @@ __global__ __launch_bounds__(256) void shade_kernel(
     // past the end of the band re-reads the last tile.  With no branch around the loads the compiler
     // can wait for exactly the older tile's loads (s_waitcnt vmcnt(N)) and leave the prefetch in flight.
     auto fetch = [&](uint32_t j, tile_regs& t) {
+        claunch* F = launder(L);
         const uint32_t tile = band_start + min(j, band_len - 1u);
-        const uint32_t tyi = tile / fp.tiles_x;
-        const uint32_t txi = tile - tyi * fp.tiles_x;
-        t.px = fp.rect_x0 + txi * 64u + lx;
-        t.py = fp.rect_y0 + tyi * 4u + ly;
-        const uint32_t cx = min(t.px, fp.rect_x1 - 1u), cy = min(t.py, fp.rect_y1 - 1u);
-        const size_t gpix = (size_t)(cy - fp.g_origin_y) * fp.g_width + (cx - fp.g_origin_x);
-        t.mat = material_id[gpix];
-        t.pd = pos_depth[gpix];
-        t.ns = nrm_scale[gpix];
-        t.cluster_xy = (uint32_t)cluster_x[cx] + cluster_y_term[cy];
+        const uint32_t tyi = tile / F->fp.tiles_x;
+        const uint32_t txi = tile - tyi * F->fp.tiles_x;
+        t.px = F->fp.rect_x0 + txi * 64u + lx;
+        t.py = F->fp.rect_y0 + tyi * 4u + ly;
+        const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
+        const size_t gpix = (size_t)(cy - F->fp.g_origin_y) * F->fp.g_width + (cx - F->fp.g_origin_x);
+        t.mat = F->material_id[gpix];
+        t.pd = F->pos_depth[gpix];
+        t.ns = F->nrm_scale[gpix];
+        t.cluster_xy = (uint32_t)F->cluster_x[cx] + F->cluster_y_term[cy];
     };
 
-    uint32_t j = blockIdx.x >> 3;
-    if (j >= band_len) return;
-    tile_regs cur, nxt;
-    fetch(j, cur);
-    while (j < band_len) {
-        const uint32_t jn = j + stride;
-        fetch(jn, nxt);  // in flight while `cur` is shaded
-
-        const bool inside = cur.px < fp.rect_x1 && cur.py < fp.rect_y1;
+    auto shade_tile = [&](const tile_regs& cur) {
+        claunch* S = launder(L);
+        const bool inside = cur.px < S->fp.rect_x1 && cur.py < S->fp.rect_y1;
         const bool active = inside && cur.mat != TR_NOT_COVERED;
         // One material at a time through the scalar unit; a wave that straddles k materials loops k times.
         f3 out = {0.f, 0.f, 0.f};  // clear colour of the opaque pass (src/main.rs:1592-1601)
         uint64_t todo = __ballot(active);
-        if (fp.ablate & 32u) {  // profiling only: pure streaming skeleton
+        if (S->fp.ablate & 32u) {  // profiling only: pure streaming skeleton
             todo = 0;
             out = f3{cur.pd.x + cur.ns.x + (float)cur.mat, cur.pd.y + cur.ns.y + (float)cur.cluster_xy, cur.pd.z + cur.ns.z + cur.pd.w + cur.ns.w};
         }
+        cdmat* dmats = as_constant(S->dmats);
         while (todo) {
             const int l0 = __ffsll((unsigned long long)todo) - 1;
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)cur.mat, l0);
@@ -621,19 +649,36 @@ __global__ __launch_bounds__(256) void shade_kernel(
             // optimiser substitutes the per-lane `mat` for the scalar `m0` and the table reads turn into
             // per-lane vector loads.
             if ((group >> lane) & 1ull)
-                out = shade_pixel<TRANSMISSIVE>(fp, tb, tb.dmats[m0], pyramid, cur.pd, cur.ns, lane, cur.cluster_xy);
+                out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cur.cluster_xy);
         }
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         if (TRANSMISSIVE ? active : inside) {
-            const size_t pix = (size_t)cur.py * fp.width + cur.px;
+            claunch* W = launder(L);
+            const size_t pix = (size_t)cur.py * W->fp.width + cur.px;
+            OutT* hdr = (OutT*)W->hdr;
             if constexpr (sizeof(OutT) == 8) hdr[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
             else hdr[pix] = OutT{out.x, out.y, out.z, 1.0f};
             if constexpr (!TRANSMISSIVE) {
+                uint2* mip0 = W->mip0;
                 if (mip0) mip0[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
             }
         }
-        cur = nxt;
-        j = jn;
+    };
+
+    // Two tiles per trip, ping-ponging between two register sets, so the prefetched tile never has to be copied.
+    uint32_t j = blockIdx.x >> 3;
+    if (j >= band_len) return;
+    tile_regs ta, tb2;
+    fetch(j, ta);
+    for (;;) {
+        fetch(j + stride, tb2);  // in flight while `ta` is shaded
+        shade_tile(ta);
+        j += stride;
+        if (j >= band_len) break;
+        fetch(j + stride, ta);
+        shade_tile(tb2);
+        j += stride;
+        if (j >= band_len) break;
     }
 }
 

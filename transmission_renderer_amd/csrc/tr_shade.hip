@@ -101,6 +101,7 @@ tr_status ensure_levels(tr_context* ctx, const tr_pyramid* p, hipStream_t stream
         ctx->h_levels.height[l] = level_dim(p->height, l);
         ctx->h_levels.wf[l] = (float)ctx->h_levels.width[l];
         ctx->h_levels.hf[l] = (float)ctx->h_levels.height[l];
+        ctx->h_levels.xlim[l] = ctx->h_levels.width[l] >= 2u ? (float)(ctx->h_levels.width[l] - 2u) : 0.0f;
     }
     ctx->h_levels_count = p->levels;
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_levels, &ctx->h_levels, sizeof(tr_level_table), hipMemcpyHostToDevice, stream));
@@ -310,7 +311,9 @@ tr_status tr_pyramid_layout(uint32_t width, uint32_t height, tr_pyramid* out, si
         off += (uint64_t)level_dim(width, l) * level_dim(height, l);
     }
     if (off > 0xFFFFFFFFull) return TR_ERR_UNSUPPORTED;
-    if (out_bytes) *out_bytes = (size_t)off * 8u;
+    // + one texel of tail padding: the sampler reads texels in 16-byte pairs and may touch (never use) the 8
+    // bytes after the last texel of the last level
+    if (out_bytes) *out_bytes = (size_t)(off + 1u) * 8u;
     return TR_OK;
 }
 
@@ -430,18 +433,17 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     fp.pyr_levels = 1;
     const host_tables tb = make_tables(ctx);
     const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y)), block(256);
-    if (format == TR_FORMAT_RGBA16F)
-        hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, fp, tb.dmats, tb.lights, tb.cluster_counts,
-                           tb.light_indices, tb.lut_pairs, tb.levels, tb.cluster_x, tb.cluster_y_term,
-                           (const float4*)g->pos_depth,
-                           (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)nullptr,
-                           (uint2*)hdr_out, (uint2*)opaque_mip0_out);
-    else
-        hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, fp, tb.dmats, tb.lights, tb.cluster_counts,
-                           tb.light_indices, tb.lut_pairs, tb.levels, tb.cluster_x, tb.cluster_y_term,
-                           (const float4*)g->pos_depth,
-                           (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)nullptr,
-                           (float4*)hdr_out, (uint2*)opaque_mip0_out);
+    {
+        tr_launch L;
+        L.fp = fp;
+        L.dmats = tb.dmats; L.lights = tb.lights; L.cluster_counts = tb.cluster_counts; L.light_indices = tb.light_indices;
+        L.lut_pairs = tb.lut_pairs; L.levels = tb.levels; L.cluster_x = tb.cluster_x; L.cluster_y_term = tb.cluster_y_term;
+        L.pos_depth = (const float4*)g->pos_depth; L.nrm_scale = (const float4*)g->nrm_scale;
+        L.material_id = (const uint32_t*)g->material_id; L.pyramid = (const uint2*)nullptr;
+        L.hdr = hdr_out; L.mip0 = (uint2*)opaque_mip0_out;
+        if (format == TR_FORMAT_RGBA16F) hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, L);
+        else hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, L);
+    }
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
@@ -483,18 +485,17 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     fp.pyr_levels = p->levels;
     const host_tables tb = make_tables(ctx);
     const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y)), block(256);
-    if (format == TR_FORMAT_RGBA16F)
-        hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, fp, tb.dmats, tb.lights, tb.cluster_counts,
-                           tb.light_indices, tb.lut_pairs, tb.levels, tb.cluster_x, tb.cluster_y_term,
-                           (const float4*)g->pos_depth,
-                           (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)p->texels,
-                           (uint2*)hdr_inout, (uint2*)nullptr);
-    else
-        hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, fp, tb.dmats, tb.lights, tb.cluster_counts,
-                           tb.light_indices, tb.lut_pairs, tb.levels, tb.cluster_x, tb.cluster_y_term,
-                           (const float4*)g->pos_depth,
-                           (const float4*)g->nrm_scale, (const uint32_t*)g->material_id, (const uint2*)p->texels,
-                           (float4*)hdr_inout, (uint2*)nullptr);
+    {
+        tr_launch L;
+        L.fp = fp;
+        L.dmats = tb.dmats; L.lights = tb.lights; L.cluster_counts = tb.cluster_counts; L.light_indices = tb.light_indices;
+        L.lut_pairs = tb.lut_pairs; L.levels = tb.levels; L.cluster_x = tb.cluster_x; L.cluster_y_term = tb.cluster_y_term;
+        L.pos_depth = (const float4*)g->pos_depth; L.nrm_scale = (const float4*)g->nrm_scale;
+        L.material_id = (const uint32_t*)g->material_id; L.pyramid = (const uint2*)p->texels;
+        L.hdr = hdr_inout; L.mip0 = (uint2*)nullptr;
+        if (format == TR_FORMAT_RGBA16F) hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, L);
+        else hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, L);
+    }
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }

@@ -75,8 +75,10 @@ class OpaquePyramid:
         if st != 0:
             raise _lib.TrError(st, "tr_pyramid_layout")
         self.width, self.height, self.levels = width, height, int(self.desc.levels)
-        self.texels = torch.zeros((nbytes.value // 8, 4), dtype=torch.float16, device=device)
-        self.desc.texels = self.texels.data_ptr()
+        # out_bytes includes one texel of tail padding (the sampler reads 16-byte texel pairs)
+        self._storage = torch.zeros((nbytes.value // 8, 4), dtype=torch.float16, device=device)
+        self.texels = self._storage[:nbytes.value // 8 - 1]
+        self.desc.texels = self._storage.data_ptr()
 
     def level(self, l: int) -> torch.Tensor:
         w, h = max(self.width >> l, 1), max(self.height >> l, 1)
