@@ -88,13 +88,15 @@ def cpu_baseline(scene, lut, width, height, budget_s=12.0):
         oracle.shade_transmission(binding, band, tex, hdr_f16=hdr16, hdr_f32=hdr32, nthreads=cores)
         return time.perf_counter() - t0
 
-    probe_rows = min(height, max(cores, 16))
-    rate = probe_rows * width / run(probe_rows)  # px/s
-    rows = int(min(height, max(probe_rows, budget_s * rate / width)))
-    dt = run(rows)
-    return {"value": rows * width / dt / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/libtr_oracle.so o_shade_transmission, {rows} rows x {width} px of the same frame "
-                      f"({rows * width / 1e6:.2f} Mpx) in {dt:.1f} s, {cores} threads"}
+    run(min(height, max(cores, 16)))                 # warm-up (page in the planes, spin up the threads)
+    dt1 = run(height)                                # one whole frame
+    reps = max(1, min(200, int(budget_s / max(dt1, 1e-3))))   # many-core hosts finish a frame in < 1 s
+    rows = height
+    dt = dt1 + sum(run(rows) for _ in range(reps - 1))
+    rows_total = rows * reps
+    return {"value": rows_total * width / dt / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/libtr_oracle.so o_shade_transmission, {reps} x {rows} rows x {width} px of the same "
+                      f"frame ({rows_total * width / 1e6:.1f} Mpx) in {dt:.1f} s, {cores} threads"}
 
 
 def main():

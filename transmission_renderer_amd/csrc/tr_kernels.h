@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/tr_shade.h"
 
@@ -51,6 +52,13 @@ constexpr float kFrac1Pi = 0.318309886183790671538f;
 constexpr float kLog2e = 1.44269504088896340736f;
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // one v_pk_*_f32 operand
+
+// Profiling builds (-DTR_ABLATION=1) honour fp.ablate (TR_ABLATE env) to switch phases off; in the product
+// build the switches do not exist: a branch around a load makes the s_waitcnt counters imprecise.
+#ifndef TR_ABLATION
+#define TR_ABLATION 0
+#endif
+#define TR_ABLATE(L, bit) (TR_ABLATION && ((L)->fp.ablate & (bit)))
 
 // ---------------------------------------------------------------- digested material (160 B)
 // Index 0 of every pair belongs to the basic_brdf lobe, index 1 to the transmission_btdf lobe.
@@ -210,50 +218,50 @@ template <bool TRANSMISSIVE>
 __device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, const pixel_frame& px, f3 l, f3 I) {
     const f3 n = px.n, v = px.v;
     const float nov_raw = px.nov_raw, nov = px.nov;
-    const v2f nlvl = pk_fma(px.nvz, splat(l.z), pk_fma(px.nvy, splat(l.y), px.nvx * l.x));
-    const float nl_raw = nlvl.x, vl = nlvl.y;
+    const float nl_raw = dot3(n.x, n.y, n.z, l.x, l.y, l.z);
+    const float vl = dot3(v.x, v.y, v.z, l.x, l.y, l.z);
     const float hx = v.x + l.x, hy = v.y + l.y, hz = v.z + l.z;
     const float cx = fmaf(n.y, hz, -(n.z * hy)), cy = fmaf(n.z, hx, -(n.x * hz)), cz = fmaf(n.x, hy, -(n.y * hx));
     const float c2 = dot3(cx, cy, cz, cx, cy, cz);
 
     if constexpr (TRANSMISSIVE) {
-        // lobe 0: basic_brdf (glam-pbr/src/lib.rs:377-423); lobe 1: transmission_btdf (:200-233)
-        const v2f vlp = {vl, fmaf(-2.0f * nl_raw, nov_raw, vl)};            // v.l , v.l'
+        // lobe 0: basic_brdf (glam-pbr/src/lib.rs:377-423); lobe 1: transmission_btdf (:200-233), side by side.
         // |v+l|^2 (|v| = |l| = 1).  It vanishes where v = -l; for the mirrored light that is exactly the
         // specular peak of the reflection lobe (v + l' = (v+l) - 2 (n.l) n = 0 when h = n), so it is hit on
         // real pixels and rounding can push it below zero: floor it (the reference normalises a ~1e-8 vector
         // there and gets an arbitrary but finite h; F' = f90 makes the lobe's weight vanish either way).
-        const v2f s = pk_fma(splat(2.0f), vlp, splat(2.0f));
-        const v2f inv_h = {rsq(fmaxf(s.x, 1e-12f)), rsq(fmaxf(s.y, 1e-12f))};
-        const v2f voh = pk_max((vlp + 1.0f) * inv_h, kEpsilon);            // Dot::new clamps to EPSILON (:93-98)
-        const v2f nol = {fmaxf(nl_raw, kEpsilon), fmaxf(-nl_raw, kEpsilon)};  // n.l , n.l' = -(n.l)
-        const v2f omv = 1.0f - voh;
-        const v2f omv2 = omv * omv;
-        const v2f p = omv2 * omv2 * omv;                                   // fresnel_schlick :137-139
-        const v2f a2 = {m.a2[0], m.a2[1]}, oma2 = {m.oma2[0], m.oma2[1]}, kk = {m.k[0], m.k[1]};
-        const v2f sin2 = (inv_h * inv_h) * c2;
-        v2f f = pk_fma(a2, 1.0f - sin2, sin2);
-        f.x = (nov_raw + nl_raw) > 0.0f ? f.x : 1.0f;
-        f.y = (nov_raw - nl_raw) > 0.0f ? f.y : 1.0f;
+        const float vl0 = vl, vl1 = fmaf(-2.0f * nl_raw, nov_raw, vl);               // v.l , v.l'
+        const float ih0 = rsq(fmaxf(fmaf(2.0f, vl0, 2.0f), 1e-12f)), ih1 = rsq(fmaxf(fmaf(2.0f, vl1, 2.0f), 1e-12f));
+        const float voh0 = fmaxf((vl0 + 1.0f) * ih0, kEpsilon), voh1 = fmaxf((vl1 + 1.0f) * ih1, kEpsilon);  // Dot::new :93-98
+        const float nol0 = fmaxf(nl_raw, kEpsilon), nol1 = fmaxf(-nl_raw, kEpsilon);  // n.l , n.l' = -(n.l)
+        const float om0 = 1.0f - voh0, om1 = 1.0f - voh1;
+        const float q0 = om0 * om0, q1 = om1 * om1;
+        const float p0 = q0 * q0 * om0, p1 = q1 * q1 * om1;                           // fresnel_schlick :137-139
+        const float s20 = (ih0 * ih0) * c2, s21 = (ih1 * ih1) * c2;                   // 1 - (n.h)^2
+        const float f0 = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - s20, s20) : 1.0f;
+        const float f1 = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - s21, s21) : 1.0f;
         // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal per lobe
-        const v2f rb = pk_fma(nol * nol, oma2, a2);
-        const v2f g = nol * px.g_nov + nov * v2f{fast_sqrt(rb.x), fast_sqrt(rb.y)};
-        const v2f den = f * f * g;
-        v2f dv = kk * v2f{rcp(den.x), rcp(den.y)};
-        dv.x = g.x > 0.0f ? dv.x : 0.0f;
-        dv.y = g.y > 0.0f ? dv.y : 0.0f;
-        const v2f w = {nol.x * dv.x, dv.y};  // specular_brdf is weighted by n.l (:414-421), the btdf is not (:232)
-        const v2f F0 = pk_fma(splat(m.df[0]), p, splat(m.f0[0]));          // { F , F' } per channel
-        const v2f F1 = pk_fma(splat(m.df[1]), p, splat(m.f0[1]));
-        const v2f F2 = pk_fma(splat(m.df[2]), p, splat(m.f0[2]));
-        const float wd = nol.x * (1.0f - fmaxf(F0.x, fmaxf(F1.x, F2.x)));  // diffuse_brdf :356-360
+        const float g0 = fmaf(nol0, px.g_nov.x, nov * fast_sqrt(fmaf(nol0 * nol0, m.oma2[0], m.a2[0])));
+        const float g1 = fmaf(nol1, px.g_nov.y, nov * fast_sqrt(fmaf(nol1 * nol1, m.oma2[1], m.a2[1])));
+        float dv0 = m.k[0] * rcp(f0 * f0 * g0), dv1 = m.k[1] * rcp(f1 * f1 * g1);
+        dv0 = g0 > 0.0f ? dv0 : 0.0f;
+        dv1 = g1 > 0.0f ? dv1 : 0.0f;
+        const float ws = nol0 * dv0;  // specular_brdf is weighted by n.l (:414-421), the btdf is not (:232)
+        const float Fx = fmaf(m.df[0], p0, m.f0[0]), Fy = fmaf(m.df[1], p0, m.f0[1]), Fz = fmaf(m.df[2], p0, m.f0[2]);
+        const float Tx = 1.0f - fmaf(m.df[0], p1, m.f0[0]), Ty = 1.0f - fmaf(m.df[1], p1, m.f0[1]),
+                    Tz = 1.0f - fmaf(m.df[2], p1, m.f0[2]);
+        const float wd = nol0 * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));                    // diffuse_brdf :356-360
         acc.d.x = fmaf(I.x, wd, acc.d.x);
         acc.d.y = fmaf(I.y, wd, acc.d.y);
         acc.d.z = fmaf(I.z, wd, acc.d.z);
-        const v2f sgn = {1.0f, -1.0f}, off = {0.0f, 1.0f};                  // { F , 1 - F' }
-        acc.st[0] = pk_fma(pk_fma(F0, sgn, off) * I.x, w, acc.st[0]);
-        acc.st[1] = pk_fma(pk_fma(F1, sgn, off) * I.y, w, acc.st[1]);
-        acc.st[2] = pk_fma(pk_fma(F2, sgn, off) * I.z, w, acc.st[2]);
+        const float Isx = I.x * ws, Isy = I.y * ws, Isz = I.z * ws;
+        const float Itx = I.x * dv1, Ity = I.y * dv1, Itz = I.z * dv1;
+        acc.st[0].x = fmaf(Isx, Fx, acc.st[0].x);
+        acc.st[1].x = fmaf(Isy, Fy, acc.st[1].x);
+        acc.st[2].x = fmaf(Isz, Fz, acc.st[2].x);
+        acc.st[0].y = fmaf(Itx, Tx, acc.st[0].y);
+        acc.st[1].y = fmaf(Ity, Ty, acc.st[1].y);
+        acc.st[2].y = fmaf(Itz, Tz, acc.st[2].y);
     } else {
         const float inv_h = rsq(fmaxf(fmaf(2.0f, vl, 2.0f), 1e-12f));
         const float voh = fmaxf((1.0f + vl) * inv_h, kEpsilon);
@@ -375,23 +383,40 @@ __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __
     pf.narrow1 = w1 < 2u;
 }
 
-// Filters the fetched texels: bilinear per level (lerp form, fp32), then across levels.
+// Filters the fetched texels.  Written as one weighted sum over the 8 taps,
+//   sum_level  lw * ( (1-wx)(1-wy) t00 + wx(1-wy) t10 + (1-wx)wy t01 + wx wy t11 ),  lw = (1-t, t),
+// so that every term is a v_fma_mix_f32 reading the half-precision texel in place (no v_cvt_f32_f16, which
+// runs at half rate, and no subtractions); it equals the lerp form of the oracle up to fp32 rounding.
 __device__ __forceinline__ f3 pyramid_resolve(pyramid_fetch& pf) {
     if (pf.narrow0) { pf.r0[0].z = pf.r0[0].x; pf.r0[0].w = pf.r0[0].y; pf.r1[0].z = pf.r1[0].x; pf.r1[0].w = pf.r1[0].y; }
     if (pf.narrow1) { pf.r0[1].z = pf.r0[1].x; pf.r0[1].w = pf.r0[1].y; pf.r1[1].z = pf.r1[1].x; pf.r1[1].w = pf.r1[1].y; }
+    float w[2][4];
+    const float lw[2] = {1.0f - pf.t, pf.t};
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const float wx = l ? pf.wx.y : pf.wx.x, wy = l ? pf.wy.y : pf.wy.x;
+        const float top = lw[l] - lw[l] * wy, bot = lw[l] * wy;   // lw (1 - wy), lw wy
+        w[l][1] = top * wx;          // t10
+        w[l][0] = top - w[l][1];     // t00
+        w[l][3] = bot * wx;          // t11
+        w[l][2] = bot - w[l][3];     // t01
+    }
     float out[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         auto ch = [c](const uint4& q, int texel) {
-            uint32_t w = (c < 2) ? (texel ? q.z : q.x) : (texel ? q.w : q.y);
-            return (c == 1) ? h2f_hi(w) : h2f_lo(w);
+            uint32_t wd = (c < 2) ? (texel ? q.z : q.x) : (texel ? q.w : q.y);
+            return (c == 1) ? h2f_hi(wd) : h2f_lo(wd);
         };
-        v2f t00 = {ch(pf.r0[0], 0), ch(pf.r0[1], 0)}, t10 = {ch(pf.r0[0], 1), ch(pf.r0[1], 1)};
-        v2f t01 = {ch(pf.r1[0], 0), ch(pf.r1[1], 0)}, t11 = {ch(pf.r1[0], 1), ch(pf.r1[1], 1)};
-        v2f top = pk_fma(t10 - t00, pf.wx, t00);
-        v2f bot = pk_fma(t11 - t01, pf.wx, t01);
-        v2f bl = pk_fma(bot - top, pf.wy, top);
-        out[c] = fmaf(bl.y - bl.x, pf.t, bl.x);
+        float acc = ch(pf.r0[0], 0) * w[0][0];
+        acc = fmaf(ch(pf.r0[0], 1), w[0][1], acc);
+        acc = fmaf(ch(pf.r1[0], 0), w[0][2], acc);
+        acc = fmaf(ch(pf.r1[0], 1), w[0][3], acc);
+        acc = fmaf(ch(pf.r0[1], 0), w[1][0], acc);
+        acc = fmaf(ch(pf.r0[1], 1), w[1][1], acc);
+        acc = fmaf(ch(pf.r1[1], 0), w[1][2], acc);
+        acc = fmaf(ch(pf.r1[1], 1), w[1][3], acc);
+        out[c] = acc;
     }
     return {out[0], out[1], out[2]};
 }
@@ -445,9 +470,16 @@ __device__ __forceinline__ f3 debug_colour_for_id(uint32_t id) {
 // ------------------------------------------------------------------------ one pixel
 // Runs with exec = the lanes of the wave that share material `m` (scalar registers).
 // `lane` = lane id in the wave; `cluster_xy` = cluster x + cluster y * num_clusters.x of this pixel.
-template <bool TRANSMISSIVE>
+//
+// WHOLE_WAVE: all 64 lanes are live and share `m`.  Then `prefetch()` — the loads of the block's NEXT tile —
+// is issued here, after this tile's own loads (light list, pyramid taps, LUT taps): vmcnt retires loads in
+// order, so an `s_waitcnt` for the taps issued after a prefetch would stall on the HBM latency of the
+// prefetch, while one issued before it (vmcnt(5)) leaves the prefetch in flight during the whole light
+// evaluation.  For the same reason the light loop of this path performs no vector load when every lane's
+// cluster holds at most four lights (its list then sits in registers).
+template <bool TRANSMISSIVE, bool WHOLE_WAVE, class Prefetch>
 __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float4 ns, uint32_t lane,
-                                          uint32_t cluster_xy) {
+                                          uint32_t cluster_xy, Prefetch prefetch) {
     // ================= phase 1: frame of the pixel, cluster list request, refraction taps =================
     L = launder(L);
     m = launder(m);
@@ -479,9 +511,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
     const uint32_t csafe = in_range ? cluster : 0u;
     const uint32_t* indices = L->light_indices + (size_t)csafe * TR_MAX_LIGHTS_PER_CLUSTER;  // per-lane reads
     uint32_t num_lights = L->cluster_counts[csafe];
-    uint32_t head = indices[0];
+    const uint4 list4 = *reinterpret_cast<const uint4*>(indices);  // the first four entries (lists are 512-byte aligned)
     num_lights = in_range ? num_lights : 0u;
-    if (L->fp.ablate & 8u) num_lights = 0;
+    if (TR_ABLATE(L, 8u)) num_lights = 0;
 
     // ---- ibl_volume_refraction, part 1 (glam-pbr/src/lib.rs:292-337): where the refracted ray leaves
     //      the volume, projected to the screen; the taps are in flight while the lights are evaluated.
@@ -505,81 +537,107 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
         float tu = fmaf(cx, hw, 0.5f);
         float tv = fmaf(cy, hw, 0.5f);
         float lod = L->fp.log2_fb_width * m->rough_ior; // :334-335
-        if (!(L->fp.ablate & 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod);
+        if (!TR_ABLATE(L, 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod);
         else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
-        if (!(L->fp.ablate & 2u)) lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, *m, nov_raw);
+        if (!TR_ABLATE(L, 2u)) lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, *m, nov_raw);
         else { lf.p0 = lf.p1 = 0x40404040u; lf.fx = nov_raw; }
     }
 
-    // ================= phase 2: the sun (lighting.rs:37-53 / 171-177) =================
-    L = launder(L);
-    m = launder(m);
-    {
-        const v2f ra = pk_fma(splat(nov * nov), v2f{m->oma2[0], m->oma2[1]}, v2f{m->a2[0], m->a2[1]});
-        px.g_nov = v2f{fast_sqrt(ra.x), TRANSMISSIVE ? fast_sqrt(ra.y) : 0.0f};
-    }
+    // ================= phases 2+3: the sun, then the clustered punctual lights =================
+    // Every lane walks its own cluster's list; at each step the lanes whose next light index equals that of the
+    // first pending lane evaluate it together, with the light read through the scalar unit.  When the lists
+    // agree (the normal case, also across cluster boundaries) that is one pass per light.
     light_acc acc = {{0.f, 0.f, 0.f}, {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}};
-    if (!(L->fp.ablate & 4u))
-        eval_light<TRANSMISSIVE>(acc, *m, px, {L->fp.sun_dir[0], L->fp.sun_dir[1], L->fp.sun_dir[2]},
-                                 {L->fp.sun_intensity[0], L->fp.sun_intensity[1], L->fp.sun_intensity[2]});
-
-    // ================= phase 3: clustered punctual lights (lighting.rs:55-92 / 179-217) =================
-    // Every lane walks its own cluster's list (requested in phase 1); at each step the lanes whose next light
-    // index equals that of the first pending lane evaluate it together, with the light read through the scalar
-    // unit.  When the lists agree (the normal case, also across cluster boundaries) that is one pass per light.
-    {
-        L = launder(L);
-        m = launder(m);
-        cdlight* lights = as_constant(L->lights);
+    auto lights_phase = [&](auto list_in_registers) {
+        claunch* L2 = launder(L);
+        cdmat* m2 = launder(m);
+        {
+            const v2f ra = pk_fma(splat(nov * nov), v2f{m2->oma2[0], m2->oma2[1]}, v2f{m2->a2[0], m2->a2[1]});
+            px.g_nov = v2f{fast_sqrt(ra.x), TRANSMISSIVE ? fast_sqrt(ra.y) : 0.0f};
+        }
+        // sun (lighting.rs:37-53 / 171-177)
+        if (!TR_ABLATE(L2, 4u))
+            eval_light<TRANSMISSIVE>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
+                                     {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]});
+        // punctual lights (lighting.rs:55-92 / 179-217)
+        cdlight* lights = as_constant(L2->lights);
         uint32_t i = 0;
+        uint32_t head = list4.x;
         uint64_t pending = __ballot(i < num_lights);
         while (pending) {
             const int l0 = __ffsll((unsigned long long)pending) - 1;
             const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)head, l0);
             const uint64_t group = __ballot(i < num_lights && head == h0);
             if ((group >> lane) & 1ull) {  // membership from the mask keeps h0 scalar (see shade_kernel)
-                const uint32_t next = indices[min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u)];  // in flight during the eval
-                eval_punctual<TRANSMISSIVE>(acc, *m, lights[h0], pos, px);
-                ++i;
-                head = next;
+                if constexpr (decltype(list_in_registers)::value) {
+                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px);
+                    ++i;
+                    head = i == 1u ? list4.y : (i == 2u ? list4.z : list4.w);
+                } else {
+                    const uint32_t next = indices[min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u)];  // in flight during the eval
+                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px);
+                    ++i;
+                    head = next;
+                }
             }
             pending = __ballot(i < num_lights);
         }
-    }
-
+    };
     // ================= phase 4: resolve the taps, composite =================
-    L = launder(L);
-    m = launder(m);
-    f3 diffuse = {acc.d.x * m->c_diff[0], acc.d.y * m->c_diff[1], acc.d.z * m->c_diff[2]};
+    auto finish = [&]() -> f3 {
+        claunch* L4 = launder(L);
+        cdmat* m4 = launder(m);
+        f3 diffuse = {acc.d.x * m4->c_diff[0], acc.d.y * m4->c_diff[1], acc.d.z * m4->c_diff[2]};
 
-    if constexpr (TRANSMISSIVE) {
-        // ---- ibl_volume_refraction, part 2 (:337-353)
-        f3 T = pyramid_resolve(pf);
-        if (m->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
-            T.x *= fast_exp2(m->neg_atten_log2[0] * len);
-            T.y *= fast_exp2(m->neg_atten_log2[1] * len);
-            T.z *= fast_exp2(m->neg_atten_log2[2] * len);
+        if constexpr (TRANSMISSIVE) {
+            // ---- ibl_volume_refraction, part 2 (:337-353)
+            f3 T = pyramid_resolve(pf);
+            if (m4->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
+                T.x *= fast_exp2(m4->neg_atten_log2[0] * len);
+                T.y *= fast_exp2(m4->neg_atten_log2[1] * len);
+                T.z *= fast_exp2(m4->neg_atten_log2[2] * len);
+            }
+            const v2f AB = lut_resolve(lf, m4->lut_fy);
+            // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
+            const float fb = m4->f90 * AB.y;
+            float tx = fmaf(1.0f - fmaf(m4->f0[0], AB.x, fb), T.x, acc.st[0].y) * m4->diffuse[0];
+            float ty = fmaf(1.0f - fmaf(m4->f0[1], AB.x, fb), T.y, acc.st[1].y) * m4->diffuse[1];
+            float tz = fmaf(1.0f - fmaf(m4->f0[2], AB.x, fb), T.z, acc.st[2].y) * m4->diffuse[2];
+            // lib.rs:157-159: real = tf * transmission; diffuse = lerp(diffuse, real, tf)
+            float tf = m4->transmission_factor;
+            diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
+            diffuse.y = fmaf(fmaf(tf, ty, -diffuse.y), tf, diffuse.y);
+            diffuse.z = fmaf(fmaf(tf, tz, -diffuse.z), tf, diffuse.z);
         }
-        const v2f AB = lut_resolve(lf, m->lut_fy);
-        // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
-        const float fb = m->f90 * AB.y;
-        float tx = fmaf(1.0f - fmaf(m->f0[0], AB.x, fb), T.x, acc.st[0].y) * m->diffuse[0];
-        float ty = fmaf(1.0f - fmaf(m->f0[1], AB.x, fb), T.y, acc.st[1].y) * m->diffuse[1];
-        float tz = fmaf(1.0f - fmaf(m->f0[2], AB.x, fb), T.z, acc.st[2].y) * m->diffuse[2];
-        // lib.rs:157-159: real = tf * transmission; diffuse = lerp(diffuse, real, tf)
-        float tf = m->transmission_factor;
-        diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
-        diffuse.y = fmaf(fmaf(tf, ty, -diffuse.y), tf, diffuse.y);
-        diffuse.z = fmaf(fmaf(tf, tz, -diffuse.z), tf, diffuse.z);
-    }
 
-    f3 out = {diffuse.x + acc.st[0].x + m->emission[0], diffuse.y + acc.st[1].x + m->emission[1],
-              diffuse.z + acc.st[2].x + m->emission[2]};
-    if constexpr (!TRANSMISSIVE) {
-        if (L->fp.debug_clusters != 0u) {  // lib.rs:241-245
-            f3 a = debug_colour_for_id(num_lights), b = debug_colour_for_id(cluster);
-            out = {fmaf(b.x - 0.5f, 0.025f, a.x), fmaf(b.y - 0.5f, 0.025f, a.y), fmaf(b.z - 0.5f, 0.025f, a.z)};
+        f3 out = {diffuse.x + acc.st[0].x + m4->emission[0], diffuse.y + acc.st[1].x + m4->emission[1],
+                  diffuse.z + acc.st[2].x + m4->emission[2]};
+        if constexpr (!TRANSMISSIVE) {
+            if (L4->fp.debug_clusters != 0u) {  // lib.rs:241-245
+                f3 a = debug_colour_for_id(num_lights), b = debug_colour_for_id(cluster);
+                out = {fmaf(b.x - 0.5f, 0.025f, a.x), fmaf(b.y - 0.5f, 0.025f, a.y), fmaf(b.z - 0.5f, 0.025f, a.z)};
+            }
         }
+        return out;
+    };
+
+    // The two light-list variants run to the end of the pixel separately (phase 4 is instantiated in both):
+    // joining them before the taps are consumed would make the compiler's s_waitcnt for the taps conservative
+    // (vmcnt(0)), i.e. wait for the prefetch.
+    f3 out;
+    if constexpr (WHOLE_WAVE) {
+        if (__ballot(num_lights > 4u) == 0ull) {   // needs the light count only: the oldest load of this tile
+            prefetch();
+            lights_phase(std::true_type{});
+            out = finish();
+        } else {
+            prefetch();
+            lights_phase(std::false_type{});
+            out = finish();
+        }
+    } else {
+        lights_phase(std::false_type{});
+        out = finish();
     }
     return out;
 }
@@ -593,7 +651,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
 // and the G-buffer of the block's next tile is already in flight while the current one is shaded.
 struct tile_regs {
     float4 pd, ns;
-    uint32_t mat, cluster_xy, px, py;
+    uint32_t mat, cluster_x, cluster_y_term, px, py;  // (the two table values are only added when used)
 };
 
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */>
@@ -622,37 +680,55 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         t.py = F->fp.rect_y0 + tyi * 4u + ly;
         const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
         const size_t gpix = (size_t)(cy - F->fp.g_origin_y) * F->fp.g_width + (cx - F->fp.g_origin_x);
+        if (TR_ABLATE(F, 64u)) {  // profiling only: no G-buffer traffic (synthetic per-lane inputs)
+            t.mat = (tile >> 5) & 15u;
+            t.pd = float4{(float)cx * 1e-3f - 1.5f, 2.0f + (float)cy * 1e-3f, -2.0f, 0.004f};
+            t.ns = float4{0.1f, 0.3f + (float)lx * 1e-2f, 0.9f, 1.0f};
+            t.cluster_x = 5; t.cluster_y_term = 0;
+            return;
+        }
         t.mat = F->material_id[gpix];
         t.pd = F->pos_depth[gpix];
         t.ns = F->nrm_scale[gpix];
-        t.cluster_xy = (uint32_t)F->cluster_x[cx] + F->cluster_y_term[cy];
+        t.cluster_x = (uint32_t)F->cluster_x[cx];
+        t.cluster_y_term = F->cluster_y_term[cy];
     };
 
-    auto shade_tile = [&](const tile_regs& cur) {
+    uint32_t j = blockIdx.x >> 3;
+    if (j >= band_len) return;
+    tile_regs cur, nxt;
+    fetch(j, cur);
+    while (j < band_len) {
+        const uint32_t jn = j + stride;
         claunch* S = launder(L);
         const bool inside = cur.px < S->fp.rect_x1 && cur.py < S->fp.rect_y1;
         const bool active = inside && cur.mat != TR_NOT_COVERED;
-        // One material at a time through the scalar unit; a wave that straddles k materials loops k times.
         f3 out = {0.f, 0.f, 0.f};  // clear colour of the opaque pass (src/main.rs:1592-1601)
         uint64_t todo = __ballot(active);
-        if (S->fp.ablate & 32u) {  // profiling only: pure streaming skeleton
-            todo = 0;
-            out = f3{cur.pd.x + cur.ns.x + (float)cur.mat, cur.pd.y + cur.ns.y + (float)cur.cluster_xy, cur.pd.z + cur.ns.z + cur.pd.w + cur.ns.w};
-        }
         cdmat* dmats = as_constant(S->dmats);
-        while (todo) {
-            const int l0 = __ffsll((unsigned long long)todo) - 1;
-            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)cur.mat, l0);
-            const uint64_t group = __ballot(active && cur.mat == m0);
-            todo &= ~group;
-            // Membership is read back from the ballot mask, not from `mat == m0`: inside `if (mat == m0)` the
-            // optimiser substitutes the per-lane `mat` for the scalar `m0` and the table reads turn into
-            // per-lane vector loads.
-            if ((group >> lane) & 1ull)
-                out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cur.cluster_xy);
+        if (TR_ABLATE(S, 32u)) {  // profiling only: pure streaming skeleton
+            fetch(jn, nxt);
+            todo = 0;
+            out = f3{cur.pd.x + cur.ns.x + (float)cur.mat, cur.pd.y + cur.ns.y + (float)cur.cluster_x, cur.pd.z + cur.ns.z + cur.pd.w + cur.ns.w};
+        } else if (todo) {
+            // One material at a time through the scalar unit; a wave that straddles k materials loops k times.
+            fetch(jn, nxt);
+            while (todo) {
+                const int l0 = __ffsll((unsigned long long)todo) - 1;
+                const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)cur.mat, l0);
+                const uint64_t group = __ballot(active && cur.mat == m0);
+                todo &= ~group;
+                // Membership is read back from the ballot mask, not from `mat == m0`: inside `if (mat == m0)`
+                // the optimiser substitutes the per-lane `mat` for the scalar `m0` and the table reads turn
+                // into per-lane vector loads.
+                if ((group >> lane) & 1ull)
+                    out = shade_pixel<TRANSMISSIVE, false>(L, dmats + m0, cur.pd, cur.ns, lane, cur.cluster_x + cur.cluster_y_term, [] {});
+            }
+        } else {
+            fetch(jn, nxt);
         }
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
-        if (TRANSMISSIVE ? active : inside) {
+        if ((TRANSMISSIVE ? active : inside) && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
             claunch* W = launder(L);
             const size_t pix = (size_t)cur.py * W->fp.width + cur.px;
             OutT* hdr = (OutT*)W->hdr;
@@ -663,22 +739,8 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
                 if (mip0) mip0[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
             }
         }
-    };
-
-    // Two tiles per trip, ping-ponging between two register sets, so the prefetched tile never has to be copied.
-    uint32_t j = blockIdx.x >> 3;
-    if (j >= band_len) return;
-    tile_regs ta, tb2;
-    fetch(j, ta);
-    for (;;) {
-        fetch(j + stride, tb2);  // in flight while `ta` is shaded
-        shade_tile(ta);
-        j += stride;
-        if (j >= band_len) break;
-        fetch(j + stride, ta);
-        shade_tile(tb2);
-        j += stride;
-        if (j >= band_len) break;
+        cur = nxt;
+        j = jn;
     }
 }
 

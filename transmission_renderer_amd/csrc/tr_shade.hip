@@ -193,7 +193,9 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     fp->rect_y1 = rect.y1;
     fp->tiles_x = (rect.x1 - rect.x0 + 63u) / 64u;
     fp->tiles_y = (rect.y1 - rect.y0 + 3u) / 4u;
-    if (const char* e = std::getenv("TR_ABLATE")) fp->ablate = (uint32_t)std::atoi(e);  // profiling only
+#if TR_ABLATION
+    if (const char* e = std::getenv("TR_ABLATE")) fp->ablate = (uint32_t)std::atoi(e);  // profiling builds only
+#endif
     fp->lut_width = ctx->lut_w;
     fp->lut_stride = ctx->lut_stride;
     return TR_OK;
@@ -268,9 +270,15 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
     if (!ctx) return TR_ERR_OUT_OF_MEMORY;
     ctx->device = device_ordinal;
     {
+        // persistent grid: twice the resident blocks per CU (measured best on MI355X: the tail of the sweep is
+        // spread over more, shorter runs), 1/8 of them per XCD
         hipDeviceProp_t prop;
+        int resident = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, shade_kernel<true, uint2>, 256, 0) != hipSuccess ||
+            resident <= 0)
+            resident = 4;
         if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount >= 8)
-            ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * 4u;
+            ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * 2u;
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
     }
     if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess) {
