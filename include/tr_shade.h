@@ -131,6 +131,7 @@ typedef struct tr_cluster_aabb {
 
 /* shared-structs/src/lib.rs:322 */
 #define TR_MAX_LIGHTS_PER_CLUSTER 128u
+#define TR_MAX_DEPTH_SLICES 64u   /* src/main.rs:62 uses 16 */
 
 /* ----------------------------------------------- G-buffer ("TGB-v1" planes) */
 /*
@@ -217,6 +218,27 @@ tr_status tr_set_cluster_tables(tr_context* ctx, const void* cluster_light_count
 
 /* ggx_lut.png as uploaded by src/main.rs:295-330 (R8G8B8A8_UNORM, row 0 first). Host pointer. */
 tr_status tr_upload_ggx_lut(tr_context* ctx, const uint8_t* rgba8_host, uint32_t width, uint32_t height, void* stream);
+
+/* ------------------------------------------------------- clustered-light build */
+
+/*
+ * `write_cluster_data` (shader/src/lib.rs:519-594; recorded at start-up and on resize, src/main.rs:832-840,
+ * 1478-1517): the view-space AABB of every cluster of the num_clusters.x * num_clusters.y * num_depth_slices
+ * grid in `uniforms`.  inverse_perspective is column-major (perspective_matrix.inverse()).
+ * cluster_aabbs_out: device pointer to that many tr_cluster_aabb.
+ */
+tr_status tr_write_cluster_data(tr_context* ctx, const tr_uniforms* uniforms, const float inverse_perspective[16],
+                                const uint32_t screen_dimensions[2], void* cluster_aabbs_out, void* stream);
+
+/*
+ * `assign_lights_to_clusters` (shader/src/lib.rs:596-645; every frame, src/main.rs:1765-1798) for the lights of
+ * the last tr_upload_lights: view_matrix column-major, view_rotation = camera_rotation.inverse() as (x,y,z,w).
+ * Writes counts[num_clusters] and indices[num_clusters * 128] (device pointers; pass them to
+ * tr_set_cluster_tables).  Unlike the reference's atomics, every list comes out sorted by light index.
+ */
+tr_status tr_assign_lights_to_clusters(tr_context* ctx, const float view_matrix[16], const float view_rotation[4],
+                                       const void* cluster_aabbs, uint32_t num_clusters, void* counts_out,
+                                       void* indices_out, void* stream);
 
 /* -------------------------------------------------------------------- passes */
 

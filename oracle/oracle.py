@@ -126,6 +126,10 @@ def load() -> C.CDLL:
     lib.o_fragment_transmission.restype = None
     lib.o_fragment_transmission.argtypes = [C.POINTER(OScene), C.POINTER(OPyramid), Vec3, Vec3, Vec2, u32, f,
                                             C.POINTER(f * 4), C.POINTER(f * 4)]
+    lib.o_write_cluster_data.restype = None
+    lib.o_write_cluster_data.argtypes = [C.POINTER(wire.Uniforms), C.POINTER(f * 16), C.POINTER(u32 * 2), u32, vp]
+    lib.o_assign_lights_to_clusters.restype = None
+    lib.o_assign_lights_to_clusters.argtypes = [vp, u32, vp, u32, C.POINTER(f * 16), C.POINTER(f * 4), vp, vp]
     _bind_passes(lib)
     _lib = lib
     return lib
@@ -250,3 +254,28 @@ def shade_transmission(binding: SceneBinding, g: dict, pyramid_texels: np.ndarra
     (load64() if fp64 else load()).o_shade_transmission(C.byref(binding.struct), C.byref(gs), C.byref(p), r,
                                                         _ptr(f16), _ptr(f32_), nthreads)
     return f16, f32_
+
+
+def write_cluster_data(uniforms: wire.Uniforms, inverse_perspective: np.ndarray, screen_dimensions) -> np.ndarray:
+    """(num_clusters, 8) float32 AABBs (min.xyz, pad, max.xyz, pad): shader/src/lib.rs:519-594."""
+    nz = int(uniforms.light_clustering_coefficients.num_depth_slices)
+    n = int(uniforms.num_clusters[0]) * int(uniforms.num_clusters[1]) * nz
+    out = np.zeros((n, 8), dtype=np.float32)
+    ip = (C.c_float * 16)(*[float(x) for x in np.asarray(inverse_perspective, dtype=np.float32).reshape(-1)])
+    sd = (C.c_uint32 * 2)(int(screen_dimensions[0]), int(screen_dimensions[1]))
+    load().o_write_cluster_data(C.byref(uniforms), C.byref(ip), C.byref(sd), nz, _ptr(out))
+    return out
+
+
+def assign_lights_to_clusters(lights, aabbs: np.ndarray, view_matrix: np.ndarray, view_rotation: np.ndarray):
+    """(counts, indices) with sorted lists: shader/src/lib.rs:596-645."""
+    n = aabbs.shape[0]
+    arr = wire.as_ctypes_array(list(lights) or [wire.Light()], wire.Light)
+    counts = np.zeros(n, dtype=np.uint32)
+    indices = np.zeros(n * wire.MAX_LIGHTS_PER_CLUSTER, dtype=np.uint32)
+    vm = (C.c_float * 16)(*[float(x) for x in np.asarray(view_matrix, dtype=np.float32).reshape(-1)])
+    q = (C.c_float * 4)(*[float(x) for x in np.asarray(view_rotation, dtype=np.float32).reshape(-1)])
+    aabbs = np.ascontiguousarray(aabbs, dtype=np.float32)
+    load().o_assign_lights_to_clusters(C.cast(arr, C.c_void_p), len(lights), _ptr(aabbs), n, C.byref(vm), C.byref(q),
+                                       _ptr(counts), _ptr(indices))
+    return counts, indices

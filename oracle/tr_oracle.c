@@ -521,6 +521,132 @@ void o_generate_mips(const o_pyramid* p, uint16_t* texels) {
 
 static o_vec3 f3(const float* p) { return v3(p[0], p[1], p[2]); }
 
+/* ------------------------------------------------- clustered-light build */
+
+/* shared-structs/src/lib.rs:65-67 `slice_to_depth` */
+real o_slice_to_depth(const tr_light_cluster_coefficients* c, uint32_t slice) {
+    return -(real)c->z_near * R_POW((real)c->z_far / (real)c->z_near, (real)slice / (real)c->num_depth_slices);
+}
+
+/* shader/src/lib.rs:582-594 `line_intersection_to_z_plane` (normal = +z) */
+static o_vec3 line_intersection_to_z_plane(o_vec3 a, o_vec3 b, real z_distance) {
+    o_vec3 normal = v3(R(0.0), R(0.0), R(1.0));
+    o_vec3 a_to_b = v3_sub(b, a);
+    real t = (z_distance - v3_dot(normal, a)) / v3_dot(normal, a_to_b);
+    return v3_add(a, v3_scale(a_to_b, t));
+}
+
+static inline o_vec3 v3_min(o_vec3 a, o_vec3 b) { return v3(R_MIN(a.x, b.x), R_MIN(a.y, b.y), R_MIN(a.z, b.z)); }
+static inline o_vec3 v3_max(o_vec3 a, o_vec3 b) { return v3(R_MAX(a.x, b.x), R_MAX(a.y, b.y), R_MAX(a.z, b.z)); }
+
+/* shader/src/lib.rs:519-580 `write_cluster_data`: one view-space AABB per cluster (x, y, z). */
+void o_write_cluster_data(const tr_uniforms* u, const float inverse_perspective[16], const uint32_t screen_dimensions[2],
+                          uint32_t num_clusters_z, tr_cluster_aabb* out) {
+    real ip[16];
+    for (int k = 0; k < 16; ++k) ip[k] = (real)inverse_perspective[k];
+    const uint32_t nx = u->num_clusters[0], ny = u->num_clusters[1];
+    for (uint32_t z = 0; z < num_clusters_z; ++z)
+        for (uint32_t y = 0; y < ny; ++y)
+            for (uint32_t x = 0; x < nx; ++x) {
+                uint32_t cluster_id = z * nx * ny + y * nx + x;
+                real smin[2] = {(real)x * (real)u->cluster_size_in_pixels[0], (real)y * (real)u->cluster_size_in_pixels[1]};
+                real smax[2] = {(real)(x + 1u) * (real)u->cluster_size_in_pixels[0],
+                                (real)(y + 1u) * (real)u->cluster_size_in_pixels[1]};
+                o_vec3 view_space[2];
+                for (int k = 0; k < 2; ++k) {
+                    const real* p = k ? smax : smin;
+                    /* screen_to_clip :540-544 */
+                    real px = p[0] / (real)screen_dimensions[0], py = p[1] / (real)screen_dimensions[1];
+                    px = px * R(2.0) - R(1.0);
+                    py = py * R(2.0) - R(1.0);
+                    /* clip_to_view :546-550 */
+                    real clip[4] = {px, py, R(0.0), R(1.0)}, v[4];
+                    mat4_mul_vec4(ip, clip, v);
+                    view_space[k] = v3_div(v3(v[0], v[1], v[2]), v[3]);
+                }
+                real z_near = o_slice_to_depth(&u->light_clustering_coefficients, z);
+                real z_far = o_slice_to_depth(&u->light_clustering_coefficients, z + 1u);
+                o_vec3 eye = v3(R(0.0), R(0.0), R(1.0));
+                o_vec3 min_near = line_intersection_to_z_plane(eye, view_space[0], z_near);
+                o_vec3 min_far = line_intersection_to_z_plane(eye, view_space[0], z_far);
+                o_vec3 max_near = line_intersection_to_z_plane(eye, view_space[1], z_near);
+                o_vec3 max_far = line_intersection_to_z_plane(eye, view_space[1], z_far);
+                o_vec3 mn = v3_min(v3_min(v3_min(min_near, min_far), max_near), max_far);
+                o_vec3 mx = v3_max(v3_max(v3_max(min_near, min_far), max_near), max_far);
+                tr_cluster_aabb* o = &out[cluster_id];
+                memset(o, 0, sizeof(*o));
+                o->min[0] = (float)mn.x; o->min[1] = (float)mn.y; o->min[2] = (float)mn.z;
+                o->max[0] = (float)mx.x; o->max[1] = (float)mx.y; o->max[2] = (float)mx.z;
+            }
+}
+
+/* shared-structs/src/lib.rs:290-298 `ClusterAabb::distance_sq` */
+static real aabb_distance_sq(const tr_cluster_aabb* c, o_vec3 point) {
+    o_vec3 mn = f3(c->min), mx = f3(c->max);
+    o_vec3 d = v3_max(v3_max(v3_sub(mn, point), v3_sub(point, mx)), v3_splat(R(0.0)));
+    return v3_dot(d, d);
+}
+
+/* shared-structs/src/lib.rs:300-319 `ClusterAabb::cull_spotlight` */
+static int aabb_cull_spotlight(const tr_cluster_aabb* c, o_vec3 origin, o_vec3 direction, real angle, real range) {
+    o_vec3 mn = f3(c->min), mx = f3(c->max);
+    o_vec3 center = v3_div(v3_add(mn, mx), R(2.0));
+    o_vec3 mc = v3_sub(mx, center);
+    real radius = R_SQRT(v3_dot(mc, mc));
+    o_vec3 vector = v3_sub(center, origin);
+    real vector_len_sq = v3_dot(vector, vector);
+    real vector_1_len = v3_dot(vector, direction);
+    real vector_1_len_sq = vector_1_len * vector_1_len;
+    real distance_closest_point = R_COS(angle) * R_SQRT(vector_len_sq - vector_1_len_sq) - vector_1_len * R_SIN(angle);
+    int angle_cull = distance_closest_point > radius;
+    int front_cull = vector_1_len > radius + range;
+    int back_cull = vector_1_len < -radius;
+    return angle_cull || front_cull || back_cull;
+}
+
+static inline o_vec3 v3_cross(o_vec3 a, o_vec3 b) {
+    return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+
+/* glam 0.19 scalar Quat * Vec3 (q = x, y, z, w) */
+static o_vec3 quat_mul_vec3(const real q[4], o_vec3 v) {
+    real w = q[3];
+    o_vec3 b = v3(q[0], q[1], q[2]);
+    real b2 = v3_dot(b, b);
+    return v3_add(v3_add(v3_scale(v, w * w - b2), v3_scale(b, v3_dot(v, b) * R(2.0))), v3_scale(v3_cross(b, v), w * R(2.0)));
+}
+
+/* shader/src/lib.rs:596-645 `assign_lights_to_clusters`.  The reference appends with atomics in arbitrary
+ * order; here lights are visited in ascending order, so every list comes out sorted (deterministic). */
+void o_assign_lights_to_clusters(const tr_light* lights, uint32_t num_lights, const tr_cluster_aabb* clusters,
+                                 uint32_t num_clusters, const float view_matrix[16], const float view_rotation[4],
+                                 uint32_t* counts, uint32_t* indices) {
+    real vm[16], q[4];
+    for (int k = 0; k < 16; ++k) vm[k] = (real)view_matrix[k];
+    for (int k = 0; k < 4; ++k) q[k] = (real)view_rotation[k];
+    for (uint32_t c = 0; c < num_clusters; ++c) counts[c] = 0;
+    for (uint32_t l = 0; l < num_lights; ++l) {
+        const tr_light* light = &lights[l];
+        real p4[4] = {light->position_and_spotlight_epsilon[0], light->position_and_spotlight_epsilon[1],
+                      light->position_and_spotlight_epsilon[2], R(1.0)}, lp[4];
+        mat4_mul_vec4(vm, p4, lp);
+        o_vec3 light_position = v3(lp[0], lp[1], lp[2]);
+        real falloff_distance_sq = light->colour_emission_and_falloff_distance_sq[3];
+        int is_spot = light->spotlight_direction_and_outer_angle[3] != 0.0f;
+        o_vec3 spot_dir = v3(R(0.0), R(0.0), R(0.0));
+        if (is_spot) spot_dir = quat_mul_vec3(q, f3(light->spotlight_direction_and_outer_angle));
+        for (uint32_t c = 0; c < num_clusters; ++c) {
+            if (aabb_distance_sq(&clusters[c], light_position) > falloff_distance_sq) continue;
+            if (is_spot && aabb_cull_spotlight(&clusters[c], light_position, spot_dir,
+                                               light->spotlight_direction_and_outer_angle[3],
+                                               falloff_distance_sq /* the reference passes the squared value as range */))
+                continue;
+            uint32_t off = counts[c]++;
+            if (off < TR_MAX_LIGHTS_PER_CLUSTER) indices[(size_t)c * TR_MAX_LIGHTS_PER_CLUSTER + off] = l;
+        }
+    }
+}
+
 /* shader/src/lighting.rs:261-301 (untextured: every `textures.* == -1`) */
 static o_material_params get_material_params(const float diffuse[4], const tr_material_info* m) {
     o_material_params mp;

@@ -97,6 +97,14 @@ void     o_light_cluster_coefficients_new(real z_near, real z_far, uint32_t slic
 uint32_t o_get_depth_slice(const tr_light_cluster_coefficients* c, real frag_depth); /* :54-63 */
 real    o_spotlight_factor(const tr_light* l, o_vec3 direction_to_light);      /* :129-138 */
 
+/* ---- clustered-light build ---- */
+real o_slice_to_depth(const tr_light_cluster_coefficients* c, uint32_t slice);  /* shared-structs:65-67 */
+void o_write_cluster_data(const tr_uniforms* u, const float inverse_perspective[16], const uint32_t screen_dimensions[2],
+                          uint32_t num_clusters_z, tr_cluster_aabb* out);       /* shader/src/lib.rs:519-580 */
+void o_assign_lights_to_clusters(const tr_light* lights, uint32_t num_lights, const tr_cluster_aabb* clusters,
+                                 uint32_t num_clusters, const float view_matrix[16], const float view_rotation[4],
+                                 uint32_t* counts, uint32_t* indices);          /* shader/src/lib.rs:596-645, sorted lists */
+
 /* ---- host helpers on the path ---- */
 uint32_t o_mip_levels_for_size(uint32_t w, uint32_t h);           /* src/main.rs:2590-2592 */
 void     o_perspective_matrix_reversed(uint32_t w, uint32_t h, real out_colmajor[16]); /* src/main.rs:39-54 */

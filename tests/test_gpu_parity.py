@@ -60,9 +60,16 @@ def _rmse(e):
     return np.sqrt((e[..., :3] ** 2).mean(axis=(0, 1)))
 
 
-def _check_against_oracles(got32, got16, o32, o64, o16_64, what):
+def _check_against_oracles(got32, got16, o32, o64, o16_64, what, allow_outliers=0.0):
     assert np.isfinite(got32).all(), what
     e64 = _norm_err(got32, o64)
+    if allow_outliers:   # pixels that took a different light list (depth-slice boundary moved by one pixel)
+        out = np.abs(e64).max(axis=2) > 5e-3
+        assert out.mean() <= allow_outliers, (what, "outliers", out.mean())
+        keep = ~out
+        got32, got16, o32, o64, o16_64 = (np.where(keep[..., None], a, 1.0) for a in (got32, got16, o32, o64, o16_64))
+        got16, o16_64 = got16.astype(np.float16), o16_64.astype(np.float16)
+        e64 = _norm_err(got32, o64)
     assert _rmse(e64).max() <= 1e-4, (what, "T1", _rmse(e64))
     assert np.abs(e64).max() <= 5e-3, (what, "T1 max", np.abs(e64).max())
     # T2: the RGBA16F target
@@ -149,6 +156,51 @@ def test_opaque_pass_parity(renderer, ggx_lut, w, h, spot):
     # both attachments get the same value (lib.rs:247-248)
     np.testing.assert_array_equal(pyr.level(0).cpu().numpy().view(np.uint16), got16.view(np.uint16))
     _check_against_oracles(got32, got16, o32, o64, o16_64, f"opaque {w}x{h} spot={spot}")
+
+
+def test_parity_with_assigned_cluster_lists(renderer, ggx_lut):
+    """Light lists built by the f2 kernels (lights with small falloff radii, a spotlight): lists differ from
+    cluster to cluster, so lanes of one wave walk different lists (the deduplicating light loop)."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    w, h = 320, 200
+    scene = synthetic.make_scene(w, h, num_point_lights=0)
+    scene["lights"] = [wire.Light.new_point((0.0, 0.8, 0.0), (1, 0, 0), 5.0),
+                       wire.Light.new_point((0.6, 2.4, -1.6), (0.2, 1.0, 0.3), 0.12),
+                       wire.Light.new_point((-0.8, 2.0, -1.2), (0.3, 0.4, 1.0), 0.08),
+                       wire.Light.new_point((0.1, 1.6, -2.2), (1.0, 0.9, 0.5), 0.05),
+                       wire.Light.new_spot((0.0, 4.0, -1.5), (1, 1, 0.5), 8.0, (0.0, -1.0, 0.0), 0.3, 0.6),
+                       wire.Light.new_point((1.2, 2.9, -0.9), (0.9, 0.2, 0.8), 0.1)]
+    _, view = wire.default_camera()
+    q = wire.view_rotation_inverse(view)
+    r.upload_materials(scene["materials"])
+    r.upload_lights(scene["lights"])
+    aabbs = r.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
+    counts, indices = r.assign_lights_to_clusters(view, q, aabbs)          # binds the tables
+    torch.cuda.synchronize()
+    scene["cluster_counts"] = counts.cpu().numpy().view(np.uint32)
+    scene["light_indices"] = indices.cpu().numpy().view(np.uint32)
+    assert len(np.unique(scene["cluster_counts"])) >= 4                       # lists really differ
+    o_aabbs = oracle.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
+    o_counts, o_idx = oracle.assign_lights_to_clusters(scene["lights"], o_aabbs, view, q)
+    np.testing.assert_array_equal(scene["cluster_counts"], o_counts)
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    b = oracle.SceneBinding(scene, ggx_lut)
+    tex = oracle.new_pyramid(w, h, synthetic.make_opaque_mip0(w, h))
+    oracle.generate_mips(w, h, tex)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.texels.copy_(torch.from_numpy(tex).to(r.device))
+    t32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    t16 = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t16)
+    torch.cuda.synchronize()
+    _, o32 = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8)
+    o16_64, o64 = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8, fp64=True)
+    # lanes whose depth slice differs between v_log_f32 and log2f sit on a slice boundary: compare only pixels
+    # whose light list is the same on both sides (all but a handful)
+    _check_against_oracles(t32.cpu().numpy(), t16.cpu().numpy(), o32, o64, o16_64, "assigned cluster lists",
+                           allow_outliers=2e-3)
 
 
 def test_debug_clusters_and_cluster_lookup_exact(renderer, ggx_lut):

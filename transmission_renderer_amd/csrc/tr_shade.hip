@@ -5,6 +5,7 @@
 // stream.  Nothing here computes pixels on the CPU; without a HIP device tr_context_create
 // fails with TR_ERR_NO_DEVICE and every other entry point needs a context.
 #include "tr_kernels.h"
+#include "tr_cluster_kernels.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -26,10 +27,12 @@ struct tr_context {
     bool dmats_dirty = false;
     std::vector<tr_material_info> stage_materials;
 
-    // lights
+    // lights (as the shading kernels and as the cluster assignment read them)
     tr_dlight* d_lights = nullptr;
+    tr_alight* d_alights = nullptr;
     uint32_t num_lights = 0, cap_lights = 0;
     std::vector<tr_dlight> stage_lights;
+    std::vector<tr_alight> stage_alights;
 
     // cluster tables (borrowed)
     const uint32_t* d_cluster_counts = nullptr;
@@ -296,6 +299,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_materials_raw);
     (void)hipFree(ctx->d_dmats);
     (void)hipFree(ctx->d_lights);
+    (void)hipFree(ctx->d_alights);
     (void)hipFree(ctx->d_lut_rgba8);
     (void)hipFree(ctx->d_lut_pairs);
     (void)hipFree(ctx->d_levels);
@@ -361,13 +365,18 @@ tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_
     uint32_t alloc = count ? count : 1u;
     if (alloc > ctx->cap_lights) {
         (void)hipFree(ctx->d_lights);
+        (void)hipFree(ctx->d_alights);
         ctx->d_lights = nullptr;
+        ctx->d_alights = nullptr;
         ctx->cap_lights = 0;
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_lights, sizeof(tr_dlight) * alloc));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_alights, sizeof(tr_alight) * alloc));
         ctx->cap_lights = alloc;
     }
     ctx->stage_lights.resize(alloc);
+    ctx->stage_alights.resize(alloc);
     std::memset(ctx->stage_lights.data(), 0, sizeof(tr_dlight) * alloc);
+    std::memset(ctx->stage_alights.data(), 0, sizeof(tr_alight) * alloc);
     for (uint32_t i = 0; i < count; ++i) {
         const tr_light& s = lights_host[i];
         tr_dlight& d = ctx->stage_lights[i];
@@ -380,8 +389,19 @@ tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_
         d.is_spot = outer != 0.0f ? 1u : 0u;  // Light::is_a_spotlight, shared-structs/src/lib.rs:125-127
         d.cos_outer = std::cos(outer);
         d.inv_spot_epsilon = 1.0f / s.position_and_spotlight_epsilon[3];
+        tr_alight& a = ctx->stage_alights[i];
+        for (int k = 0; k < 3; ++k) {
+            a.pos[k] = s.position_and_spotlight_epsilon[k];
+            a.spot_dir[k] = s.spotlight_direction_and_outer_angle[k];
+        }
+        a.falloff_distance_sq = s.colour_emission_and_falloff_distance_sq[3];
+        a.is_spot = d.is_spot;
+        a.cos_angle = std::cos(outer);   // ClusterAabb::cull_spotlight, shared-structs/src/lib.rs:312
+        a.sin_angle = std::sin(outer);
     }
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_lights, ctx->stage_lights.data(), sizeof(tr_dlight) * alloc,
+                               hipMemcpyHostToDevice, stream));
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_alights, ctx->stage_alights.data(), sizeof(tr_alight) * alloc,
                                hipMemcpyHostToDevice, stream));
     ctx->num_lights = count;
     return TR_OK;
@@ -420,6 +440,54 @@ tr_status tr_upload_ggx_lut(tr_context* ctx, const uint8_t* rgba8_host, uint32_t
     ctx->lut_h = height;
     ctx->lut_stride = stride;
     ctx->dmats_dirty = ctx->num_materials > 0;  // LUT rows are part of the digested material
+    return TR_OK;
+}
+
+
+tr_status tr_write_cluster_data(tr_context* ctx, const tr_uniforms* u, const float inverse_perspective[16],
+                                const uint32_t screen_dimensions[2], void* cluster_aabbs_out, void* stream_) {
+    if (!ctx || !u || !inverse_perspective || !screen_dimensions || !cluster_aabbs_out) return TR_ERR_INVALID_ARGUMENT;
+    const tr_light_cluster_coefficients& c = u->light_clustering_coefficients;
+    if (c.num_depth_slices == 0 || c.num_depth_slices > TR_MAX_DEPTH_SLICES || u->num_clusters[0] == 0 ||
+        u->num_clusters[1] == 0)
+        return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    tr_cluster_build_params p;
+    std::memset(&p, 0, sizeof(p));
+    std::memcpy(p.inverse_perspective, inverse_perspective, sizeof(p.inverse_perspective));
+    p.cluster_size_px[0] = u->cluster_size_in_pixels[0];
+    p.cluster_size_px[1] = u->cluster_size_in_pixels[1];
+    p.screen_dims[0] = (float)screen_dimensions[0];
+    p.screen_dims[1] = (float)screen_dimensions[1];
+    p.nx = u->num_clusters[0];
+    p.ny = u->num_clusters[1];
+    p.nz = c.num_depth_slices;
+    for (uint32_t s = 0; s <= p.nz; ++s)   // slice_to_depth, shared-structs/src/lib.rs:65-67 (libm powf, like the oracle)
+        p.slice_depth[s] = -c.z_near * std::pow(c.z_far / c.z_near, (float)s / (float)c.num_depth_slices);
+    const uint32_t total = p.nx * p.ny * p.nz;
+    hipLaunchKernelGGL(write_cluster_data_kernel, dim3((total + 63u) / 64u), dim3(64), 0, stream, p,
+                       (tr_cluster_aabb*)cluster_aabbs_out);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_assign_lights_to_clusters(tr_context* ctx, const float view_matrix[16], const float view_rotation[4],
+                                       const void* cluster_aabbs, uint32_t num_clusters, void* counts_out,
+                                       void* indices_out, void* stream_) {
+    if (!ctx || !view_matrix || !view_rotation || !cluster_aabbs || !counts_out || !indices_out || num_clusters == 0)
+        return TR_ERR_INVALID_ARGUMENT;
+    if (!ctx->d_alights) return TR_ERR_TABLES_MISSING;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    tr_assign_params p;
+    std::memcpy(p.view_matrix, view_matrix, sizeof(p.view_matrix));
+    std::memcpy(p.view_rotation, view_rotation, sizeof(p.view_rotation));
+    p.num_lights = ctx->num_lights;
+    p.num_clusters = num_clusters;
+    hipLaunchKernelGGL(assign_lights_kernel, dim3((num_clusters + 3u) / 4u), dim3(256), 0, stream, p, ctx->d_alights,
+                       (const tr_cluster_aabb*)cluster_aabbs, (uint32_t*)counts_out, (uint32_t*)indices_out);
+    TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
 

@@ -146,6 +146,34 @@ class TransmissionRenderer:
         self._check(self.lib.tr_upload_ggx_lut(self._ctx, rgba8.ctypes.data_as(C.c_void_p), w, h, self._stream()),
                     "tr_upload_ggx_lut")
 
+    # ---- clustered-light build
+    def write_cluster_data(self, uniforms: wire.Uniforms, inverse_perspective: np.ndarray, screen_dimensions) -> torch.Tensor:
+        """`write_cluster_data` (shader/src/lib.rs:519-594): (num_clusters, 8) float32 view-space AABBs."""
+        n = int(uniforms.num_clusters[0]) * int(uniforms.num_clusters[1]) * \
+            int(uniforms.light_clustering_coefficients.num_depth_slices)
+        out = torch.empty((n, 8), dtype=torch.float32, device=self.device)
+        ip = (C.c_float * 16)(*[float(x) for x in np.asarray(inverse_perspective, dtype=np.float32).reshape(-1)])
+        sd = (C.c_uint32 * 2)(int(screen_dimensions[0]), int(screen_dimensions[1]))
+        self._check(self.lib.tr_write_cluster_data(self._ctx, C.byref(uniforms), C.byref(ip), C.byref(sd),
+                                                   out.data_ptr(), self._stream()), "tr_write_cluster_data")
+        return out
+
+    def assign_lights_to_clusters(self, view_matrix: np.ndarray, view_rotation: np.ndarray, aabbs: torch.Tensor,
+                                  bind: bool = True):
+        """`assign_lights_to_clusters` (shader/src/lib.rs:596-645) for the uploaded lights; returns
+        (counts, indices) device tensors and (bind=True) makes them the shading passes' cluster tables."""
+        n = int(aabbs.shape[0])
+        counts = torch.zeros(n, dtype=torch.int32, device=self.device)
+        indices = torch.zeros(n * wire.MAX_LIGHTS_PER_CLUSTER, dtype=torch.int32, device=self.device)
+        vm = (C.c_float * 16)(*[float(x) for x in np.asarray(view_matrix, dtype=np.float32).reshape(-1)])
+        q = (C.c_float * 4)(*[float(x) for x in np.asarray(view_rotation, dtype=np.float32).reshape(-1)])
+        self._check(self.lib.tr_assign_lights_to_clusters(self._ctx, C.byref(vm), C.byref(q), aabbs.data_ptr(), n,
+                                                          counts.data_ptr(), indices.data_ptr(), self._stream()),
+                    "tr_assign_lights_to_clusters")
+        if bind:
+            self.set_cluster_tables(counts, indices)
+        return counts, indices
+
     # ---- passes
     @staticmethod
     def _fmt(t: torch.Tensor) -> int:

@@ -259,6 +259,23 @@ def mat4_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return np.einsum("ki,jk->ji", a.astype(f32), b.astype(f32)).astype(f32)
 
 
+def inverse_perspective(width: int, height: int) -> np.ndarray:
+    """perspective_matrix.inverse() (src/main.rs:1506) in [column][row] storage; closed form of the matrix of
+    perspective_matrix_reversed."""
+    p = perspective_matrix_reversed(width, height).astype(np.float64)
+    inv = np.linalg.inv(p.T).T     # p is stored [column][row]; invert the mathematical matrix
+    return inv.astype(f32)
+
+
+def view_rotation_inverse(view: np.ndarray) -> np.ndarray:
+    """camera_rotation.inverse() (src/main.rs:1788) as a quaternion (x, y, z, w): the rotation part of the view
+    matrix."""
+    r = np.array([[view[c][r_] for c in range(3)] for r_ in range(3)], dtype=np.float64)
+    w = np.sqrt(max(0.0, 1.0 + r[0, 0] + r[1, 1] + r[2, 2])) / 2.0
+    return np.array([(r[2, 1] - r[1, 2]) / (4 * w), (r[0, 2] - r[2, 0]) / (4 * w), (r[1, 0] - r[0, 1]) / (4 * w), w],
+                    dtype=f32)
+
+
 def sun_as_normal(pitch=1.1, yaw=4.8) -> np.ndarray:
     """Sun::as_normal (src/main.rs:2715-2722) with the start-up pitch/yaw of src/main.rs:531-534."""
     pitch, yaw = f32(pitch), f32(yaw)
