@@ -850,4 +850,119 @@ __global__ __launch_bounds__(256) void downsample_kernel(const uint2* __restrict
     dst[(size_t)j * wd + i] = pack_rgba16f(o[0], o[1], o[2], o[3]);
 }
 
+// ---- fused mip chain -------------------------------------------------------------------------------------
+// generate_mips in two launches instead of one per level (11 at 4K, each launch bound at ~4 us):
+//   * mip_even_kernel: while both sizes of the parent level are even, a LINEAR blit is an exact 2x2 box filter
+//     and a 32x32 block of level 0 determines a 16x16 / 8x8 / 4x4 / 2x2 / 1x1 block of levels 1..5 on its own.
+//     One workgroup reads its 32x32 tile once (16-byte loads, two texels each), keeps every level it produces
+//     in LDS *as the rounded RGBA16F value the next blit would read back*, and writes each level once.
+//   * mip_tail_kernel: the remaining small levels (120x67 ... 1x1 at 4K) in ONE workgroup, previous level in
+//     LDS, general LINEAR weights (odd sizes), one __syncthreads per level.
+// Arithmetic and rounding are those of downsample_kernel / the oracle (same products, same association).
+__device__ __forceinline__ uint2 box4(uint2 q00, uint2 q10, uint2 q01, uint2 q11) {
+#pragma clang fp contract(off)
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        auto ch = [k](uint2 q) {
+            uint32_t wv = (k < 2) ? q.x : q.y;
+            return __half2float(__ushort_as_half((unsigned short)((k & 1) ? (wv >> 16) : (wv & 0xFFFFu))));
+        };
+        o[k] = (ch(q00) * 0.25f + ch(q10) * 0.25f) + (ch(q01) * 0.25f + ch(q11) * 0.25f);
+    }
+    return pack_rgba16f(o[0], o[1], o[2], o[3]);
+}
+
+struct tr_mip_even_params {
+    uint32_t w0, h0;        // size of the source level
+    uint32_t nlevels;       // 1..5 levels to produce
+    uint32_t src_offset;    // texel offsets from the pyramid base
+    uint32_t dst_offset[5];
+};
+
+__global__ __launch_bounds__(256) void mip_even_kernel(uint2* __restrict__ pyr, const tr_mip_even_params p) {
+    __shared__ uint2 lds[16 * 16 + 8 * 8 + 4 * 4 + 2 * 2 + 1];
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t w1 = p.w0 >> 1, h1 = p.h0 >> 1;
+    const uint32_t i1 = blockIdx.x * 16u + tx, j1 = blockIdx.y * 16u + ty;
+    uint2 r = {0u, 0u};
+    if (i1 < w1 && j1 < h1) {
+        const uint2* src = pyr + p.src_offset;
+        const uint4 a = *reinterpret_cast<const uint4*>(src + (size_t)(2u * j1) * p.w0 + 2u * i1);        // 16-byte aligned
+        const uint4 b = *reinterpret_cast<const uint4*>(src + (size_t)(2u * j1 + 1u) * p.w0 + 2u * i1);
+        r = box4(uint2{a.x, a.y}, uint2{a.z, a.w}, uint2{b.x, b.y}, uint2{b.z, b.w});
+        pyr[p.dst_offset[0] + (size_t)j1 * w1 + i1] = r;
+    }
+    lds[ty * 16u + tx] = r;
+    uint32_t base = 0, side = 16;   // LDS offset and side of the level just produced
+#pragma unroll
+    for (uint32_t l = 1; l < 5u; ++l) {
+        __syncthreads();
+        if (l >= p.nlevels) break;   // uniform
+        const uint32_t half = side >> 1;
+        const uint32_t wl = p.w0 >> (l + 1u), hl = p.h0 >> (l + 1u);
+        if (threadIdx.x < half * half) {
+            const uint32_t x = threadIdx.x % half, y = threadIdx.x / half;
+            const uint32_t gi = blockIdx.x * half + x, gj = blockIdx.y * half + y;
+            const uint2* s = lds + base;
+            const uint2 v = box4(s[(2u * y) * side + 2u * x], s[(2u * y) * side + 2u * x + 1u],
+                                 s[(2u * y + 1u) * side + 2u * x], s[(2u * y + 1u) * side + 2u * x + 1u]);
+            if (gi < wl && gj < hl) pyr[p.dst_offset[l] + (size_t)gj * wl + gi] = v;
+            lds[base + side * side + y * half + x] = v;
+        }
+        base += side * side;
+        side = half;
+    }
+}
+
+struct tr_mip_tail_params {
+    uint32_t first, levels;                  // produce levels first .. levels-1 (first >= 1)
+    uint32_t offset[TR_MAX_MIP_LEVELS], width[TR_MAX_MIP_LEVELS], height[TR_MAX_MIP_LEVELS];
+};
+constexpr uint32_t kMipTailMaxTexels = 12288;   // first tail level must fit: 96 KiB + 24 KiB + ... of LDS
+
+__global__ __launch_bounds__(1024) void mip_tail_kernel(uint2* __restrict__ pyr, const tr_mip_tail_params p) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) uint2 tail_lds[];
+    uint2* cur = tail_lds;                    // level l-1 (when it is in LDS)
+    uint2* nxt = tail_lds;
+    bool src_in_lds = false;
+    for (uint32_t l = p.first; l < p.levels; ++l) {
+        const uint32_t ws = p.width[l - 1], hs = p.height[l - 1], wd = p.width[l], hd = p.height[l];
+        const uint2* gsrc = pyr + p.offset[l - 1];
+        nxt = src_in_lds ? cur + (size_t)ws * hs : tail_lds;
+        const float sx = (float)ws / (float)wd, sy = (float)hs / (float)hd;
+        for (uint32_t t = threadIdx.x; t < wd * hd; t += blockDim.x) {
+            const uint32_t i = t % wd, j = t / wd;
+            float x = ((float)i + 0.5f) * sx - 0.5f;
+            float y = ((float)j + 0.5f) * sy - 0.5f;
+            float fx0 = floorf(x), fy0 = floorf(y);
+            float ax = x - fx0, by = y - fy0;
+            int x0 = (int)fx0, y0 = (int)fy0;
+            int x1 = min(x0 + 1, (int)ws - 1), y1 = min(y0 + 1, (int)hs - 1);
+            x0 = min(max(x0, 0), (int)ws - 1);
+            y0 = min(max(y0, 0), (int)hs - 1);
+            const float w00 = (1.0f - ax) * (1.0f - by), w10 = ax * (1.0f - by), w01 = (1.0f - ax) * by, w11 = ax * by;
+            const uint2* s = src_in_lds ? cur : gsrc;
+            const uint2 q00 = s[(size_t)y0 * ws + x0], q10 = s[(size_t)y0 * ws + x1];
+            const uint2 q01 = s[(size_t)y1 * ws + x0], q11 = s[(size_t)y1 * ws + x1];
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                auto ch = [k](uint2 q) {
+                    uint32_t wv = (k < 2) ? q.x : q.y;
+                    return __half2float(__ushort_as_half((unsigned short)((k & 1) ? (wv >> 16) : (wv & 0xFFFFu))));
+                };
+                o[k] = (ch(q00) * w00 + ch(q10) * w10) + (ch(q01) * w01 + ch(q11) * w11);
+            }
+            const uint2 v = pack_rgba16f(o[0], o[1], o[2], o[3]);
+            pyr[p.offset[l] + t] = v;
+            nxt[t] = v;
+        }
+        __syncthreads();
+        cur = nxt;
+        src_in_lds = true;
+    }
+}
+
 }  // namespace tr

@@ -529,11 +529,55 @@ tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* p, void* stream_) 
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     uint2* base = (uint2*)p->texels;
-    for (uint32_t l = 1; l < p->levels; ++l) {
+    uint32_t l = 1;
+    // (1) leading levels whose parent has even sizes: exact 2x2 boxes, up to five levels per launch from LDS
+    while (l < p->levels) {
+        const uint32_t ws = level_dim(p->width, l - 1), hs = level_dim(p->height, l - 1);
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < 5u && l + k < p->levels; ++k) {
+            const uint32_t wk = ws >> k, hk = hs >> k;
+            if (wk < 2u || hk < 2u || (wk & 1u) || (hk & 1u)) break;
+            ++n;
+        }
+        if (n == 0) break;
+        tr_mip_even_params ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.w0 = ws;
+        ep.h0 = hs;
+        ep.nlevels = n;
+        ep.src_offset = p->level_offset[l - 1];
+        for (uint32_t k = 0; k < n; ++k) ep.dst_offset[k] = p->level_offset[l + k];
+        hipLaunchKernelGGL(mip_even_kernel, dim3(((ws >> 1) + 15u) / 16u, ((hs >> 1) + 15u) / 16u), dim3(256), 0, stream,
+                           base, ep);
+        l += n;
+    }
+    // (2) levels with an odd parent that are still too large for one workgroup: one general LINEAR blit each
+    while (l < p->levels && (uint64_t)level_dim(p->width, l) * level_dim(p->height, l) > kMipTailMaxTexels) {
         const uint32_t ws = level_dim(p->width, l - 1), hs = level_dim(p->height, l - 1);
         const uint32_t wd = level_dim(p->width, l), hd = level_dim(p->height, l);
         hipLaunchKernelGGL(downsample_kernel, dim3((wd + 63) / 64, (hd + 3) / 4), dim3(256), 0, stream,
                            (const uint2*)(base + p->level_offset[l - 1]), base + p->level_offset[l], ws, hs, wd, hd);
+        ++l;
+    }
+    // (3) the tail, one workgroup, previous level in LDS
+    if (l < p->levels) {
+        tr_mip_tail_params tp;
+        std::memset(&tp, 0, sizeof(tp));
+        tp.first = l;
+        tp.levels = p->levels;
+        size_t lds_texels = 0;
+        for (uint32_t k = 0; k < p->levels; ++k) {
+            tp.offset[k] = p->level_offset[k];
+            tp.width[k] = level_dim(p->width, k);
+            tp.height[k] = level_dim(p->height, k);
+            if (k >= l) lds_texels += (size_t)tp.width[k] * tp.height[k];
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)mip_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(mip_tail_kernel, dim3(1), dim3(1024), lds_texels * sizeof(uint2), stream, base, tp);
     }
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
