@@ -155,6 +155,19 @@ typedef struct tr_gbuffer {
 
 #define TR_NOT_COVERED 0xFFFFFFFFu
 
+/* shader/src/tonemapping.rs:29-39 `BakedLottesTonemapperParams` (push constants of fragment_tonemap). */
+typedef struct tr_tonemap_params {
+    float a, b, c, d;
+    float crosstalk, saturation, cross_saturation;
+} tr_tonemap_params;
+
+/* The un-baked parameters (colstodian `LottesTonemapperParams`, un-vendored: its defaults are NOT in the
+ * reference tree, so they are explicit inputs here; tr_lottes_defaults() gives the values of Lottes' talk). */
+typedef struct tr_lottes_params {
+    float contrast, shoulder, hdr_max, mid_in, mid_out;
+    float crosstalk, saturation, cross_saturation;
+} tr_lottes_params;
+
 /* Half-open pixel rectangle [x0,x1) x [y0,y1) in frame coordinates: the screen tile one rank
  * shades.  Must lie inside both the frame and the G-buffer planes. */
 typedef struct tr_rect {
@@ -266,6 +279,19 @@ tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* pyramid, void* str
 tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* gbuffer, const tr_uniforms* uniforms,
                                 const tr_push_constants* push, const tr_pyramid* pyramid,
                                 void* hdr_inout, tr_format format, tr_rect rect, void* stream);
+
+/* ------------------------------------------------------------------ tonemap */
+
+/* Host only: Lottes' curve constants from the un-baked parameters (what colstodian's
+ * `BakedLottesTonemapperParams::from` computes for src/main.rs:506-510). */
+tr_status tr_lottes_defaults(tr_lottes_params* out);
+tr_status tr_bake_lottes_params(const tr_lottes_params* params, tr_tonemap_params* out);
+
+/* "tonemapping": fragment_tonemap (shader/src/lib.rs:683-697, shader/src/tonemapping.rs) over the whole
+ * RGBA16F frame, written as 8-bit sRGB like the reference's B8G8R8A8_SRGB swapchain (src/main.rs:175);
+ * `bgra` != 0 selects that byte order, 0 gives R,G,B,A. */
+tr_status tr_tonemap(tr_context* ctx, const void* hdr_rgba16f, uint32_t width, uint32_t height,
+                     const tr_tonemap_params* params, void* out_rgba8, int32_t bgra, void* stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -130,6 +130,8 @@ def load() -> C.CDLL:
     lib.o_write_cluster_data.argtypes = [C.POINTER(wire.Uniforms), C.POINTER(f * 16), C.POINTER(u32 * 2), u32, vp]
     lib.o_assign_lights_to_clusters.restype = None
     lib.o_assign_lights_to_clusters.argtypes = [vp, u32, vp, u32, C.POINTER(f * 16), C.POINTER(f * 4), vp, vp]
+    lib.o_tonemap_frame.restype = None
+    lib.o_tonemap_frame.argtypes = [vp, u32, C.POINTER(wire.TonemapParams), vp, vp]
     _bind_passes(lib)
     _lib = lib
     return lib
@@ -279,3 +281,13 @@ def assign_lights_to_clusters(lights, aabbs: np.ndarray, view_matrix: np.ndarray
     load().o_assign_lights_to_clusters(C.cast(arr, C.c_void_p), len(lights), _ptr(aabbs), n, C.byref(vm), C.byref(q),
                                        _ptr(counts), _ptr(indices))
     return counts, indices
+
+
+def tonemap_frame(hdr_f16: np.ndarray, params: wire.TonemapParams):
+    """fragment_tonemap over an (H, W, 4) float16 frame: returns (rgba8 sRGB, linear float32 rgb)."""
+    hdr_f16 = np.ascontiguousarray(hdr_f16, dtype=np.float16)
+    n = hdr_f16.shape[0] * hdr_f16.shape[1]
+    rgba8 = np.zeros(hdr_f16.shape[:2] + (4,), dtype=np.uint8)
+    lin = np.zeros(hdr_f16.shape[:2] + (3,), dtype=np.float32)
+    load().o_tonemap_frame(_ptr(hdr_f16), n, C.byref(params), _ptr(rgba8), _ptr(lin))
+    return rgba8, lin

@@ -888,3 +888,44 @@ void o_shade_transmission(const o_scene* s, const o_gbuffer* g, const o_pyramid*
     j.transmissive = 1;
     run_bands(j, nthreads);
 }
+
+/* ------------------------------------------------------------- tonemap */
+
+/* shader/src/tonemapping.rs:8-27 `LottesTonemapper::tonemap` */
+void o_lottes_tonemap(const real color[3], const tr_tonemap_params* p, real out[3]) {
+    o_vec3 c = v3(color[0], color[1], color[2]);
+    real mx = v3_max_element(c);
+    o_vec3 ratio = v3_div(c, mx);
+    real z = R_POW(mx, (real)p->a);                                   /* tonemap_inner :9-12 */
+    real tonemapped_max = z / (R_POW(z, (real)p->d) * (real)p->b + (real)p->c);
+    real e1 = (real)p->saturation / (real)p->cross_saturation;
+    ratio = v3(R_POW(ratio.x, e1), R_POW(ratio.y, e1), R_POW(ratio.z, e1));
+    ratio = v3_lerp(ratio, v3_splat(R(1.0)), R_POW(tonemapped_max, (real)p->crosstalk));
+    real e2 = (real)p->cross_saturation;
+    ratio = v3(R_POW(ratio.x, e2), R_POW(ratio.y, e2), R_POW(ratio.z, e2));
+    o_vec3 r = v3_scale(ratio, tonemapped_max);
+    r = v3_max(v3_min(r, v3_splat(R(1.0))), v3_splat(R(0.0)));        /* .min(ONE).max(ZERO); f32::min/max prefer the number */
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* The sRGB encode of the B8G8R8A8_SRGB swapchain (src/main.rs:175): fixed function, restated from the
+ * Vulkan/Khronos data format specification, round to nearest. */
+uint8_t o_linear_to_srgb8(real x) {
+    if (!(x > R(0.0))) x = R(0.0);
+    if (x > R(1.0)) x = R(1.0);
+    real e = x <= R(0.0031308) ? R(12.92) * x : R(1.055) * R_POW(x, R(1.0) / R(2.4)) - R(0.055);
+    return (uint8_t)(e * R(255.0) + R(0.5));
+}
+
+/* fragment_tonemap over a whole RGBA16F frame -> RGBA8 sRGB (alpha 255) */
+void o_tonemap_frame(const uint16_t* hdr, uint32_t n, const tr_tonemap_params* p, uint8_t* out_rgba8, real* out_linear) {
+    for (uint32_t i = 0; i < n; ++i) {
+        real c[3] = {o_f16_to_f32(hdr[i * 4]), o_f16_to_f32(hdr[i * 4 + 1]), o_f16_to_f32(hdr[i * 4 + 2])}, t[3];
+        o_lottes_tonemap(c, p, t);
+        for (int k = 0; k < 3; ++k) {
+            if (out_linear) out_linear[i * 3 + k] = t[k];
+            if (out_rgba8) out_rgba8[i * 4 + k] = o_linear_to_srgb8(t[k]);
+        }
+        if (out_rgba8) out_rgba8[i * 4 + 3] = 255;
+    }
+}

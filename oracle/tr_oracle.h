@@ -105,6 +105,11 @@ void o_assign_lights_to_clusters(const tr_light* lights, uint32_t num_lights, co
                                  uint32_t num_clusters, const float view_matrix[16], const float view_rotation[4],
                                  uint32_t* counts, uint32_t* indices);          /* shader/src/lib.rs:596-645, sorted lists */
 
+/* ---- tonemap ---- */
+void    o_lottes_tonemap(const real color[3], const tr_tonemap_params* p, real out[3]);  /* shader/src/tonemapping.rs:8-27 */
+uint8_t o_linear_to_srgb8(real x);
+void    o_tonemap_frame(const uint16_t* hdr, uint32_t n, const tr_tonemap_params* p, uint8_t* out_rgba8, real* out_linear);
+
 /* ---- host helpers on the path ---- */
 uint32_t o_mip_levels_for_size(uint32_t w, uint32_t h);           /* src/main.rs:2590-2592 */
 void     o_perspective_matrix_reversed(uint32_t w, uint32_t h, real out_colmajor[16]); /* src/main.rs:39-54 */

@@ -18,7 +18,7 @@ SYMBOLS = (
     "tr_abi_version", "tr_status_string", "tr_last_hip_error", "tr_context_create", "tr_context_destroy",
     "tr_pyramid_layout", "tr_upload_materials", "tr_upload_lights", "tr_set_cluster_tables",
     "tr_upload_ggx_lut", "tr_write_cluster_data", "tr_assign_lights_to_clusters", "tr_shade_opaque",
-    "tr_generate_mips", "tr_shade_transmission",
+    "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap",
 )
 
 _lib = None
@@ -82,6 +82,12 @@ def load() -> C.CDLL:
     lib.tr_shade_transmission.argtypes = [vp, C.POINTER(wire.GBuffer), C.POINTER(wire.Uniforms),
                                           C.POINTER(wire.PushConstants), C.POINTER(wire.Pyramid), vp, i32,
                                           wire.Rect, vp]
+    lib.tr_lottes_defaults.restype = i32
+    lib.tr_lottes_defaults.argtypes = [C.POINTER(wire.LottesParams)]
+    lib.tr_bake_lottes_params.restype = i32
+    lib.tr_bake_lottes_params.argtypes = [C.POINTER(wire.LottesParams), C.POINTER(wire.TonemapParams)]
+    lib.tr_tonemap.restype = i32
+    lib.tr_tonemap.argtypes = [vp, vp, u32, u32, C.POINTER(wire.TonemapParams), vp, i32, vp]
     if lib.tr_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.tr_abi_version()} != 1")
     _lib = lib

@@ -965,4 +965,39 @@ __global__ __launch_bounds__(1024) void mip_tail_kernel(uint2* __restrict__ pyr,
     }
 }
 
+// ---- tonemap ----------------------------------------------------------------------
+// fragment_tonemap (shader/src/lib.rs:683-697) + LottesTonemapper::tonemap (shader/src/tonemapping.rs:8-27);
+// the fullscreen triangle samples texel centres, so the input is the HDR texel itself.  pow = exp2(y log2 x).
+__device__ __forceinline__ float fast_pow(float x, float y) { return fast_exp2(y * fast_log2(x)); }
+
+__device__ __forceinline__ uint32_t linear_to_srgb8(float x) {   // the sRGB target's encode (fixed function)
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    float e = x <= 0.0031308f ? 12.92f * x : fmaf(1.055f, fast_pow(x, 1.0f / 2.4f), -0.055f);
+    return (uint32_t)fmaf(e, 255.0f, 0.5f);
+}
+
+__global__ __launch_bounds__(256) void tonemap_kernel(const uint2* __restrict__ hdr, uint32_t* __restrict__ out,
+                                                      uint32_t n, const tr_tonemap_params p, int bgra) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint2 q = hdr[i];
+    const float r = h2f_lo(q.x), g = h2f_hi(q.x), b = h2f_lo(q.y);
+    const float mx = fmaxf(r, fmaxf(g, b));
+    const float inv = 1.0f / mx;                       // color / max  (0/0 = NaN for black: reference behaviour)
+    const float z = fast_pow(mx, p.a);
+    const float tm = z / fmaf(fast_pow(z, p.d), p.b, p.c);   // tonemap_inner
+    const float e1 = p.saturation / p.cross_saturation;
+    const float t = fast_pow(tm, p.crosstalk);
+    float c[3] = {r * inv, g * inv, b * inv};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float x = fast_pow(c[k], e1);
+        x = fmaf(1.0f - x, t, x);                      // lerp(ratio, 1, tonemapped_max^crosstalk)
+        x = fast_pow(x, p.cross_saturation);
+        c[k] = fmaxf(fminf(x * tm, 1.0f), 0.0f);       // .min(ONE).max(ZERO): NaN -> 1 (v_min/v_max return the number)
+    }
+    const uint32_t R = linear_to_srgb8(c[0]), G = linear_to_srgb8(c[1]), B = linear_to_srgb8(c[2]);
+    out[i] = bgra ? (B | (G << 8) | (R << 16) | 0xFF000000u) : (R | (G << 8) | (B << 16) | 0xFF000000u);
+}
+
 }  // namespace tr

@@ -620,4 +620,46 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     return TR_OK;
 }
 
+tr_status tr_lottes_defaults(tr_lottes_params* out) {
+    if (!out) return TR_ERR_INVALID_ARGUMENT;
+    // T. Lottes, "Advanced Techniques and Optimization of HDR Color Pipelines" (GDC 2016) reference values
+    out->contrast = 1.6f;
+    out->shoulder = 0.977f;
+    out->hdr_max = 8.0f;
+    out->mid_in = 0.18f;
+    out->mid_out = 0.267f;
+    out->crosstalk = 4.0f;
+    out->saturation = out->contrast;
+    out->cross_saturation = out->contrast * 16.0f;
+    return TR_OK;
+}
+
+tr_status tr_bake_lottes_params(const tr_lottes_params* q, tr_tonemap_params* out) {
+    if (!q || !out) return TR_ERR_INVALID_ARGUMENT;
+    const float a = q->contrast, d = q->shoulder;
+    const float mid_in_a = std::pow(q->mid_in, a), mid_in_ad = std::pow(q->mid_in, a * d);
+    const float max_a = std::pow(q->hdr_max, a), max_ad = std::pow(q->hdr_max, a * d);
+    const float denom = (max_ad - mid_in_ad) * q->mid_out;
+    out->a = a;
+    out->d = d;
+    out->b = (-mid_in_a + max_a * q->mid_out) / denom;
+    out->c = (max_ad * mid_in_a - max_a * mid_in_ad * q->mid_out) / denom;
+    out->crosstalk = q->crosstalk;
+    out->saturation = q->saturation;
+    out->cross_saturation = q->cross_saturation;
+    return TR_OK;
+}
+
+tr_status tr_tonemap(tr_context* ctx, const void* hdr, uint32_t width, uint32_t height, const tr_tonemap_params* params,
+                     void* out_rgba8, int32_t bgra, void* stream_) {
+    if (!ctx || !hdr || !params || !out_rgba8 || width == 0 || height == 0) return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = width * height;
+    hipLaunchKernelGGL(tonemap_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint2*)hdr,
+                       (uint32_t*)out_rgba8, n, *params, (int)bgra);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
 }  // extern "C"

@@ -218,6 +218,24 @@ class TransmissionRenderer:
                                                    self._rect(g, rect), self._stream()),
                     "tr_shade_transmission")
 
+    def baked_tonemap_params(self, lottes: Optional[wire.LottesParams] = None) -> wire.TonemapParams:
+        if lottes is None:
+            lottes = wire.LottesParams()
+            self._check(self.lib.tr_lottes_defaults(C.byref(lottes)), "tr_lottes_defaults")
+        out = wire.TonemapParams()
+        self._check(self.lib.tr_bake_lottes_params(C.byref(lottes), C.byref(out)), "tr_bake_lottes_params")
+        return out
+
+    def tonemap(self, hdr: torch.Tensor, params: Optional[wire.TonemapParams] = None, bgra: bool = False) -> torch.Tensor:
+        """"tonemapping": fragment_tonemap (shader/src/lib.rs:683-697) -> (H, W, 4) uint8, sRGB encoded."""
+        assert hdr.dtype == torch.float16 and hdr.is_cuda and hdr.is_contiguous() and hdr.shape[-1] == 4
+        h, w = int(hdr.shape[0]), int(hdr.shape[1])
+        params = params or self.baked_tonemap_params()
+        out = torch.empty((h, w, 4), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.tr_tonemap(self._ctx, hdr.data_ptr(), w, h, C.byref(params), out.data_ptr(), int(bgra),
+                                        self._stream()), "tr_tonemap")
+        return out
+
     def record(self, opaque: GBufferPlanes, transmissive: GBufferPlanes, uniforms: wire.Uniforms,
                push: wire.PushConstants, hdr: torch.Tensor, pyramid: OpaquePyramid, rect=None):
         """The hot-path slice of `record()` in the reference's order (src/main.rs:1969-2124)."""

@@ -167,6 +167,15 @@ class ClusterAabb(C.Structure):  # shared-structs/src/lib.rs:282-288
     _fields_ = [("min", C.c_float * 3), ("_pad0", C.c_float), ("max", C.c_float * 3), ("_pad1", C.c_float)]
 
 
+class TonemapParams(C.Structure):  # shader/src/tonemapping.rs:29-39 BakedLottesTonemapperParams
+    _fields_ = [(n, C.c_float) for n in ("a", "b", "c", "d", "crosstalk", "saturation", "cross_saturation")]
+
+
+class LottesParams(C.Structure):  # colstodian LottesTonemapperParams (un-vendored: explicit inputs)
+    _fields_ = [(n, C.c_float) for n in ("contrast", "shoulder", "hdr_max", "mid_in", "mid_out", "crosstalk",
+                                         "saturation", "cross_saturation")]
+
+
 class GBuffer(C.Structure):  # include/tr_shade.h tr_gbuffer
     _fields_ = [
         ("pos_depth", C.c_void_p),
