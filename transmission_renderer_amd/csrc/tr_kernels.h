@@ -80,7 +80,7 @@ struct alignas(16) tr_dmat {
     float k[2];            // a2 * 0.5 / pi   (numerator of D*V)
     uint32_t lut_row0;     // GGX LUT row offsets into the pair table (entries)
     uint32_t lut_row1;
-    uint32_t flags;        // bit0: has finite attenuation distance
+    uint32_t flags;        // bit0: finite attenuation distance; bit1: transmission_factor != 0
     uint32_t _pad[7];
 };
 static_assert(sizeof(tr_dmat) == 160, "digested material is 160 B");
@@ -215,7 +215,7 @@ struct pixel_frame {
 };
 
 template <bool TRANSMISSIVE>
-__device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, const pixel_frame& px, f3 l, f3 I) {
+__device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, const pixel_frame& px, f3 l, f3 I, bool btdf) {
     const f3 n = px.n, v = px.v;
     const float nov_raw = px.nov_raw, nov = px.nov;
     const float nl_raw = dot3(n.x, n.y, n.z, l.x, l.y, l.z);
@@ -224,68 +224,58 @@ __device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, const pixel
     const float cx = fmaf(n.y, hz, -(n.z * hy)), cy = fmaf(n.z, hx, -(n.x * hz)), cz = fmaf(n.x, hy, -(n.y * hx));
     const float c2 = dot3(cx, cy, cz, cx, cy, cz);
 
-    if constexpr (TRANSMISSIVE) {
-        // lobe 0: basic_brdf (glam-pbr/src/lib.rs:377-423); lobe 1: transmission_btdf (:200-233), side by side.
-        // |v+l|^2 (|v| = |l| = 1).  It vanishes where v = -l; for the mirrored light that is exactly the
-        // specular peak of the reflection lobe (v + l' = (v+l) - 2 (n.l) n = 0 when h = n), so it is hit on
-        // real pixels and rounding can push it below zero: floor it (the reference normalises a ~1e-8 vector
-        // there and gets an arbitrary but finite h; F' = f90 makes the lobe's weight vanish either way).
-        const float vl0 = vl, vl1 = fmaf(-2.0f * nl_raw, nov_raw, vl);               // v.l , v.l'
-        const float ih0 = rsq(fmaxf(fmaf(2.0f, vl0, 2.0f), 1e-12f)), ih1 = rsq(fmaxf(fmaf(2.0f, vl1, 2.0f), 1e-12f));
-        const float voh0 = fmaxf((vl0 + 1.0f) * ih0, kEpsilon), voh1 = fmaxf((vl1 + 1.0f) * ih1, kEpsilon);  // Dot::new :93-98
-        const float nol0 = fmaxf(nl_raw, kEpsilon), nol1 = fmaxf(-nl_raw, kEpsilon);  // n.l , n.l' = -(n.l)
-        const float om0 = 1.0f - voh0, om1 = 1.0f - voh1;
-        const float q0 = om0 * om0, q1 = om1 * om1;
-        const float p0 = q0 * q0 * om0, p1 = q1 * q1 * om1;                           // fresnel_schlick :137-139
-        const float s20 = (ih0 * ih0) * c2, s21 = (ih1 * ih1) * c2;                   // 1 - (n.h)^2
-        const float f0 = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - s20, s20) : 1.0f;
-        const float f1 = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - s21, s21) : 1.0f;
-        // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal per lobe
-        const float g0 = fmaf(nol0, px.g_nov.x, nov * fast_sqrt(fmaf(nol0 * nol0, m.oma2[0], m.a2[0])));
-        const float g1 = fmaf(nol1, px.g_nov.y, nov * fast_sqrt(fmaf(nol1 * nol1, m.oma2[1], m.a2[1])));
-        float dv0 = m.k[0] * rcp(f0 * f0 * g0), dv1 = m.k[1] * rcp(f1 * f1 * g1);
-        dv0 = g0 > 0.0f ? dv0 : 0.0f;
-        dv1 = g1 > 0.0f ? dv1 : 0.0f;
-        const float ws = nol0 * dv0;  // specular_brdf is weighted by n.l (:414-421), the btdf is not (:232)
-        const float Fx = fmaf(m.df[0], p0, m.f0[0]), Fy = fmaf(m.df[1], p0, m.f0[1]), Fz = fmaf(m.df[2], p0, m.f0[2]);
-        const float Tx = 1.0f - fmaf(m.df[0], p1, m.f0[0]), Ty = 1.0f - fmaf(m.df[1], p1, m.f0[1]),
-                    Tz = 1.0f - fmaf(m.df[2], p1, m.f0[2]);
-        const float wd = nol0 * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));                    // diffuse_brdf :356-360
-        acc.d.x = fmaf(I.x, wd, acc.d.x);
-        acc.d.y = fmaf(I.y, wd, acc.d.y);
-        acc.d.z = fmaf(I.z, wd, acc.d.z);
-        const float Isx = I.x * ws, Isy = I.y * ws, Isz = I.z * ws;
-        const float Itx = I.x * dv1, Ity = I.y * dv1, Itz = I.z * dv1;
-        acc.st[0].x = fmaf(Isx, Fx, acc.st[0].x);
-        acc.st[1].x = fmaf(Isy, Fy, acc.st[1].x);
-        acc.st[2].x = fmaf(Isz, Fz, acc.st[2].x);
-        acc.st[0].y = fmaf(Itx, Tx, acc.st[0].y);
-        acc.st[1].y = fmaf(Ity, Ty, acc.st[1].y);
-        acc.st[2].y = fmaf(Itz, Tz, acc.st[2].y);
-    } else {
+    // ---- lobe 0: basic_brdf (glam-pbr/src/lib.rs:377-423)
+    // |v+l|^2 = 2 + 2 v.l (|v| = |l| = 1) vanishes where v = -l; rounding can push it below zero: floor it.
+    {
         const float inv_h = rsq(fmaxf(fmaf(2.0f, vl, 2.0f), 1e-12f));
-        const float voh = fmaxf((1.0f + vl) * inv_h, kEpsilon);
+        const float voh = fmaxf((1.0f + vl) * inv_h, kEpsilon);   // Dot::new clamps to EPSILON (:93-98)
         const float nol = fmaxf(nl_raw, kEpsilon);
-        const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
-        const float sin2 = c2 * (inv_h * inv_h);
+        const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;   // fresnel_schlick :137-139
+        const float sin2 = c2 * (inv_h * inv_h);                   // 1 - (n.h)^2
         const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
-        const float g = nol * px.g_nov.x + nov * fast_sqrt(fmaf(nol * nol, m.oma2[0], m.a2[0]));
+        // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal
+        const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(nol * nol, m.oma2[0], m.a2[0])));
         float dv = m.k[0] * rcp(f * f * g);
         dv = g > 0.0f ? dv : 0.0f;
         const float Fx = fmaf(m.df[0], p, m.f0[0]), Fy = fmaf(m.df[1], p, m.f0[1]), Fz = fmaf(m.df[2], p, m.f0[2]);
-        const float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));
-        const float ws = nol * dv;
+        const float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));  // diffuse_brdf :356-360
+        const float ws = nol * dv;                                 // specular_brdf :362-375 (weighted by n.l :414-421)
         acc.d.x = fmaf(I.x, wd, acc.d.x);
         acc.d.y = fmaf(I.y, wd, acc.d.y);
         acc.d.z = fmaf(I.z, wd, acc.d.z);
-        acc.st[0].x = fmaf(I.x * Fx, ws, acc.st[0].x);
-        acc.st[1].x = fmaf(I.y * Fy, ws, acc.st[1].x);
-        acc.st[2].x = fmaf(I.z * Fz, ws, acc.st[2].x);
+        acc.st[0].x = fmaf(I.x * ws, Fx, acc.st[0].x);
+        acc.st[1].x = fmaf(I.y * ws, Fy, acc.st[1].x);
+        acc.st[2].x = fmaf(I.z * ws, Fz, acc.st[2].x);
+    }
+    // ---- lobe 1: transmission_btdf (:200-233): the light mirrored about the surface,
+    //      n.l' = -(n.l), v.l' = v.l - 2 (n.l)(n.v); no vector is formed.  For the mirrored light |v+l'|^2
+    //      vanishes exactly at the specular peak of lobe 0 (v + l' = (v+l) - 2 (n.l) n = 0 when h = n), so the
+    //      floor is hit on real pixels (the reference normalises a ~1e-8 vector there and gets an arbitrary but
+    //      finite h; F' = f90 makes the lobe's weight vanish either way).
+    //      Skipped (scalar branch) when the material's transmission_factor is 0: lib.rs:157-159 then multiplies
+    //      everything this lobe feeds by zero.
+    if constexpr (TRANSMISSIVE) {
+        if (btdf) {
+            const float vlm = fmaf(-2.0f * nl_raw, nov_raw, vl);
+            const float inv_h = rsq(fmaxf(fmaf(2.0f, vlm, 2.0f), 1e-12f));
+            const float voh = fmaxf((vlm + 1.0f) * inv_h, kEpsilon);
+            const float nolm = fmaxf(-nl_raw, kEpsilon);
+            const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
+            const float sin2 = c2 * (inv_h * inv_h);
+            const float f = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - sin2, sin2) : 1.0f;
+            const float g = fmaf(nolm, px.g_nov.y, nov * fast_sqrt(fmaf(nolm * nolm, m.oma2[1], m.a2[1])));
+            float dv = m.k[1] * rcp(f * f * g);
+            dv = g > 0.0f ? dv : 0.0f;                               // not weighted by n.l (:232)
+            acc.st[0].y = fmaf(I.x * dv, 1.0f - fmaf(m.df[0], p, m.f0[0]), acc.st[0].y);
+            acc.st[1].y = fmaf(I.y * dv, 1.0f - fmaf(m.df[1], p, m.f0[1]), acc.st[1].y);
+            acc.st[2].y = fmaf(I.z * dv, 1.0f - fmaf(m.df[2], p, m.f0[2]), acc.st[2].y);
+        }
     }
 }
 
 template <bool TRANSMISSIVE>
-__device__ __forceinline__ void eval_punctual(light_acc& acc, cdmat& m, cdlight& L, f3 pos, const pixel_frame& px) {
+__device__ __forceinline__ void eval_punctual(light_acc& acc, cdmat& m, cdlight& L, f3 pos, const pixel_frame& px,
+                                              bool btdf) {
     // light_direction_and_attenuation (glam-pbr/src/lib.rs:12-23): bare 1/d^2
     float dx = L.pos[0] - pos.x, dy = L.pos[1] - pos.y, dz = L.pos[2] - pos.z;
     float inv_d = rsq(dot3(dx, dy, dz, dx, dy, dz));
@@ -300,7 +290,7 @@ __device__ __forceinline__ void eval_punctual(light_acc& acc, cdmat& m, cdlight&
         }
     }
     f3 I = {L.colour[0] * att, L.colour[1] * att, L.colour[2] * att};
-    eval_light<TRANSMISSIVE>(acc, m, px, l, I);
+    eval_light<TRANSMISSIVE>(acc, m, px, l, I, btdf);
 }
 
 // ------------------------------------------------------------------ opaque pyramid taps
@@ -520,7 +510,10 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
     pyramid_fetch pf;
     lut_fetch lf;
     float len = 0.0f;
-    if constexpr (TRANSMISSIVE) {
+    // transmission_factor == 0 (scalar): lib.rs:157-159 multiplies the whole transmission term by zero, so the
+    // refraction taps, the LUT and the btdf lobes are skipped for such materials
+    const bool transmits = TRANSMISSIVE && (m->flags & 2u);
+    if (transmits) {
         // refract(-v, n, ior) :248-256 ; unit length by construction (Snell), so no re-normalise
         float eta = m->eta;
         float k = fmaf(-eta * eta, fmaf(-nov_raw, nov_raw, 1.0f), 1.0f);
@@ -558,7 +551,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
         // sun (lighting.rs:37-53 / 171-177)
         if (!TR_ABLATE(L2, 4u))
             eval_light<TRANSMISSIVE>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
-                                     {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]});
+                                     {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, transmits);
         // punctual lights (lighting.rs:55-92 / 179-217)
         cdlight* lights = as_constant(L2->lights);
         uint32_t i = 0;
@@ -570,12 +563,12 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
             const uint64_t group = __ballot(i < num_lights && head == h0);
             if ((group >> lane) & 1ull) {  // membership from the mask keeps h0 scalar (see shade_kernel)
                 if constexpr (decltype(list_in_registers)::value) {
-                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px);
+                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px, transmits);
                     ++i;
                     head = i == 1u ? list4.y : (i == 2u ? list4.z : list4.w);
                 } else {
                     const uint32_t next = indices[min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u)];  // in flight during the eval
-                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px);
+                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px, transmits);
                     ++i;
                     head = next;
                 }
@@ -589,7 +582,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
         cdmat* m4 = launder(m);
         f3 diffuse = {acc.d.x * m4->c_diff[0], acc.d.y * m4->c_diff[1], acc.d.z * m4->c_diff[2]};
 
-        if constexpr (TRANSMISSIVE) {
+        if (transmits) {
             // ---- ibl_volume_refraction, part 2 (:337-353)
             f3 T = pyramid_resolve(pf);
             if (m4->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
@@ -783,7 +776,7 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
     d.thickness = mi.thickness_factor;
     d.rough_ior = rough * ior_clamp;                                 // PerceptualRoughness::apply_ior :157-159
     const bool has_atten = !(mi.attenuation_distance == __builtin_inff());
-    d.flags = has_atten ? 1u : 0u;
+    d.flags = (has_atten ? 1u : 0u) | (mi.transmission_factor != 0.0f ? 2u : 0u);
     for (int k = 0; k < 3; ++k) {
         float coeff = -logf(mi.attenuation_colour[k]) / mi.attenuation_distance;  // :284
         d.neg_atten_log2[k] = has_atten ? (-coeff) * kLog2e : 0.0f;
