@@ -42,13 +42,23 @@ class OPyramid(C.Structure):
                 ("level_offset", C.c_uint32 * wire.MAX_MIP_LEVELS)]
 
 
+class OTexture(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("levels", C.c_uint32),
+                ("srgb", C.c_uint32), ("level_offset", C.c_uint32 * wire.MAX_MIP_LEVELS)]
+
+
+class FragDerivs(C.Structure):
+    _fields_ = [("dpos_dx", Vec3), ("dpos_dy", Vec3), ("duv_dx", Vec2), ("duv_dy", Vec2)]
+
+
 class OScene(C.Structure):
     _fields_ = [("materials", C.c_void_p), ("num_materials", C.c_uint32),
                 ("lights", C.c_void_p), ("num_lights", C.c_uint32),
                 ("cluster_light_counts", C.c_void_p), ("light_indices", C.c_void_p),
                 ("num_clusters_total", C.c_uint32),
                 ("ggx_lut_rgba8", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
-                ("uniforms", wire.Uniforms), ("push", wire.PushConstants)]
+                ("uniforms", wire.Uniforms), ("push", wire.PushConstants),
+                ("textures", C.c_void_p), ("num_textures", C.c_uint32)]
 
 
 class OGBuffer(C.Structure):
@@ -122,10 +132,17 @@ def load() -> C.CDLL:
     lib.o_generate_mips.restype = None
     lib.o_generate_mips.argtypes = [C.POINTER(OPyramid), vp]
     lib.o_fragment.restype = None
-    lib.o_fragment.argtypes = [C.POINTER(OScene), Vec3, Vec3, Vec2, u32, C.POINTER(f * 4), C.POINTER(f * 4)]
+    lib.o_fragment.argtypes = [C.POINTER(OScene), Vec3, Vec3, Vec2, u32, C.POINTER(f * 4), C.POINTER(FragDerivs),
+                               C.POINTER(f * 4)]
     lib.o_fragment_transmission.restype = None
     lib.o_fragment_transmission.argtypes = [C.POINTER(OScene), C.POINTER(OPyramid), Vec3, Vec3, Vec2, u32, f,
-                                            C.POINTER(f * 4), C.POINTER(f * 4)]
+                                            C.POINTER(f * 4), C.POINTER(FragDerivs), C.POINTER(f * 4)]
+    lib.o_texture_layout.restype = None
+    lib.o_texture_layout.argtypes = [u32, u32, C.POINTER(OTexture), C.POINTER(C.c_uint64)]
+    lib.o_generate_texture_mips.restype = None
+    lib.o_generate_texture_mips.argtypes = [C.POINTER(OTexture), vp]
+    lib.o_sample_texture.restype = None
+    lib.o_sample_texture.argtypes = [C.POINTER(OTexture), f, f, Vec2, Vec2, C.POINTER(f * 4)]
     lib.o_write_cluster_data.restype = None
     lib.o_write_cluster_data.argtypes = [C.POINTER(wire.Uniforms), C.POINTER(f * 16), C.POINTER(u32 * 2), u32, vp]
     lib.o_assign_lights_to_clusters.restype = None
@@ -190,7 +207,27 @@ class SceneBinding:
         s.lut_height, s.lut_width = self.lut.shape[:2]
         s.uniforms = scene["uniforms"]
         s.push = scene["push"]
+        # material textures: scene["textures"] = [(level0 rgba8 (H, W, 4) uint8, srgb bool), ...]
+        self.textures = [make_texture(img, srgb) for img, srgb in scene.get("textures", [])]
+        self.texture_structs = (OTexture * max(len(self.textures), 1))(*[t[1] for t in self.textures])
+        s.textures = C.cast(self.texture_structs, C.c_void_p)
+        s.num_textures = len(self.textures)
         self.struct = s
+
+
+def make_texture(level0: np.ndarray, srgb: bool):
+    """(texels (total, 4) uint8 with the full mip chain, OTexture) for an (H, W, 4) uint8 level 0."""
+    level0 = np.ascontiguousarray(level0, dtype=np.uint8)
+    h, w = level0.shape[:2]
+    t = OTexture()
+    total = C.c_uint64()
+    load().o_texture_layout(w, h, C.byref(t), C.byref(total))
+    texels = np.zeros((total.value, 4), dtype=np.uint8)
+    texels[: w * h] = level0.reshape(-1, 4)
+    t.texels = _ptr(texels)
+    t.srgb = 1 if srgb else 0
+    load().o_generate_texture_mips(C.byref(t), _ptr(texels))
+    return texels, t
 
 
 def gbuffer_struct(g: dict) -> OGBuffer:

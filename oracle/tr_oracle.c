@@ -647,16 +647,219 @@ void o_assign_lights_to_clusters(const tr_light* lights, uint32_t num_lights, co
     }
 }
 
-/* shader/src/lighting.rs:261-301 (untextured: every `textures.* == -1`) */
-static o_material_params get_material_params(const float diffuse[4], const tr_material_info* m) {
+
+/* ------------------------------------------------- material textures */
+
+/* R8G8B8A8_SRGB texel decode (Khronos data format spec 13.3), exact in `real` */
+real o_srgb_to_linear(uint8_t c) {
+    real x = (real)c / R(255.0);
+    return x <= R(0.04045) ? x / R(12.92) : R_POW((x + R(0.055)) / R(1.055), R(2.4));
+}
+
+static uint8_t linear_to_srgb8_tex(real x) { return o_linear_to_srgb8(x); }
+
+void o_texture_layout(uint32_t w, uint32_t h, o_texture* out, uint64_t* total_texels) {
+    memset(out, 0, sizeof(*out));
+    out->width = w;
+    out->height = h;
+    out->levels = o_mip_levels_for_size(w, h);   /* src/model_loading.rs:354 */
+    if (out->levels > TR_MAX_MIP_LEVELS) out->levels = TR_MAX_MIP_LEVELS;
+    uint64_t off = 0;
+    for (uint32_t l = 0; l < out->levels; ++l) {
+        out->level_offset[l] = (uint32_t)off;
+        off += (uint64_t)level_dim(w, l) * level_dim(h, l);
+    }
+    if (total_texels) *total_texels = off;
+}
+
+static void decode_texel(const o_texture* t, const uint8_t* p, real out[4]) {
+    for (int k = 0; k < 3; ++k) out[k] = t->srgb ? o_srgb_to_linear(p[k]) : (real)p[k] / R(255.0);
+    out[3] = (real)p[3] / R(255.0);
+}
+
+/* The mip chain `load_image_from_bytes` builds (un-vendored: restated as the vkCmdBlitImage LINEAR chain, like
+ * o_generate_mips); sRGB images are filtered in linear light and re-encoded. UNORM stores round to nearest. */
+void o_generate_texture_mips(const o_texture* t, uint8_t* texels) {
+    for (uint32_t l = 1; l < t->levels; ++l) {
+        uint32_t ws = level_dim(t->width, l - 1), hs = level_dim(t->height, l - 1);
+        uint32_t wd = level_dim(t->width, l), hd = level_dim(t->height, l);
+        const uint8_t* src = texels + (size_t)t->level_offset[l - 1] * 4u;
+        uint8_t* dst = texels + (size_t)t->level_offset[l] * 4u;
+        real sx = (real)ws / (real)wd, sy = (real)hs / (real)hd;
+        for (uint32_t j = 0; j < hd; ++j) {
+            real y = ((real)j + R(0.5)) * sy - R(0.5);
+            real fy0 = R_FLOOR(y), by = y - fy0;
+            int32_t y0 = (int32_t)fy0, y1 = y0 + 1;
+            if (y0 < 0) y0 = 0;
+            if (y0 > (int32_t)hs - 1) y0 = (int32_t)hs - 1;
+            if (y1 > (int32_t)hs - 1) y1 = (int32_t)hs - 1;
+            for (uint32_t i = 0; i < wd; ++i) {
+                real x = ((real)i + R(0.5)) * sx - R(0.5);
+                real fx0 = R_FLOOR(x), ax = x - fx0;
+                int32_t x0 = (int32_t)fx0, x1 = x0 + 1;
+                if (x0 < 0) x0 = 0;
+                if (x0 > (int32_t)ws - 1) x0 = (int32_t)ws - 1;
+                if (x1 > (int32_t)ws - 1) x1 = (int32_t)ws - 1;
+                real w00 = (R(1.0) - ax) * (R(1.0) - by), w10 = ax * (R(1.0) - by), w01 = (R(1.0) - ax) * by, w11 = ax * by;
+                real t00[4], t10[4], t01[4], t11[4];
+                decode_texel(t, src + ((size_t)y0 * ws + (uint32_t)x0) * 4u, t00);
+                decode_texel(t, src + ((size_t)y0 * ws + (uint32_t)x1) * 4u, t10);
+                decode_texel(t, src + ((size_t)y1 * ws + (uint32_t)x0) * 4u, t01);
+                decode_texel(t, src + ((size_t)y1 * ws + (uint32_t)x1) * 4u, t11);
+                for (int k = 0; k < 4; ++k) {
+                    real r = (t00[k] * w00 + t10[k] * w10) + (t01[k] * w01 + t11[k] * w11);
+                    uint8_t b;
+                    if (t->srgb && k < 3) b = linear_to_srgb8_tex(r);
+                    else {
+                        if (!(r > R(0.0))) r = R(0.0);
+                        if (r > R(1.0)) r = R(1.0);
+                        b = (uint8_t)(r * R(255.0) + R(0.5));
+                    }
+                    dst[((size_t)j * wd + i) * 4u + k] = b;
+                }
+            }
+        }
+    }
+}
+
+static void tex_bilinear(const o_texture* t, uint32_t level, real u, real v, real out[4]) {
+    uint32_t w = level_dim(t->width, level), h = level_dim(t->height, level);
+    const uint8_t* base = t->texels + (size_t)t->level_offset[level] * 4u;
+    /* REPEAT (the `sampler` of src/main.rs:683-692 leaves the address mode at its default): wrap the
+     * coordinate to [0,1) first, then the usual x = u*w - 0.5 */
+    real uu = u - R_FLOOR(u), vv = v - R_FLOOR(v);
+    real x = uu * (real)w - R(0.5), y = vv * (real)h - R(0.5);
+    real fx0 = R_FLOOR(x), fy0 = R_FLOOR(y);
+    real fx = x - fx0, fy = y - fy0;
+    int32_t x0 = (int32_t)fx0, y0 = (int32_t)fy0;
+    int32_t x1 = x0 + 1, y1 = y0 + 1;
+    if (x0 < 0) x0 += (int32_t)w;
+    if (y0 < 0) y0 += (int32_t)h;
+    if (x1 >= (int32_t)w) x1 -= (int32_t)w;
+    if (y1 >= (int32_t)h) y1 -= (int32_t)h;
+    if (x0 >= (int32_t)w) x0 = (int32_t)w - 1;   /* only for non-finite coordinates */
+    if (y0 >= (int32_t)h) y0 = (int32_t)h - 1;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 < 0 || x1 >= (int32_t)w) x1 = 0;
+    if (y1 < 0 || y1 >= (int32_t)h) y1 = 0;
+    real t00[4], t10[4], t01[4], t11[4];
+    decode_texel(t, base + ((size_t)y0 * w + (uint32_t)x0) * 4u, t00);
+    decode_texel(t, base + ((size_t)y0 * w + (uint32_t)x1) * 4u, t10);
+    decode_texel(t, base + ((size_t)y1 * w + (uint32_t)x0) * 4u, t01);
+    decode_texel(t, base + ((size_t)y1 * w + (uint32_t)x1) * 4u, t11);
+    for (int k = 0; k < 4; ++k) {
+        real top = t00[k] + (t10[k] - t00[k]) * fx;
+        real bot = t01[k] + (t11[k] - t01[k]) * fx;
+        out[k] = top + (bot - top) * fy;
+    }
+}
+
+/* TextureSampler::sample (shader/src/lib.rs:257-261): `texture.sample(sampler, uv)`, implicit LOD.
+ * Vulkan 1.3 "Scale Factor Operation / LOD Operation" restated (unpinned, driver territory):
+ * rho = max(|(du/dx w, dv/dx h)|, |(du/dy w, dv/dy h)|), lambda = log2(rho), clamped to [0, levels-1],
+ * LINEAR mip filter between floor(lambda) and the next level, LINEAR min/mag. */
+void o_sample_texture(const o_texture* t, real u, real v, o_vec2 duv_dx, o_vec2 duv_dy, real out[4]) {
+    real mxx = duv_dx.x * (real)t->width, mxy = duv_dx.y * (real)t->height;
+    real myx = duv_dy.x * (real)t->width, myy = duv_dy.y * (real)t->height;
+    real rho_x = R_SQRT(mxx * mxx + mxy * mxy), rho_y = R_SQRT(myx * myx + myy * myy);
+    real rho = R_MAX(rho_x, rho_y);
+    real lambda = R_LOG2(rho);
+    real max_lod = (real)(t->levels - 1u);
+    real l = R_MIN(R_MAX(lambda, R(0.0)), max_lod);   /* NaN / -inf -> 0 */
+    real lf = R_FLOOR(l), frac = l - lf;
+    uint32_t l0 = (uint32_t)lf, l1 = l0 + 1u < t->levels ? l0 + 1u : t->levels - 1u;
+    real a[4], b[4];
+    tex_bilinear(t, l0, u, v, a);
+    tex_bilinear(t, l1, u, v, b);
+    for (int k = 0; k < 4; ++k) out[k] = a[k] + (b[k] - a[k]) * frac;
+}
+
+static void sample_material_texture(const o_scene* s, int32_t id, o_vec2 uv, const o_frag_derivs* d, real out[4]) {
+    o_vec2 zero = {R(0.0), R(0.0)};
+    if (id < 0 || (uint32_t)id >= s->num_textures) {   /* unbound slot: robust read */
+        out[0] = out[1] = out[2] = out[3] = R(0.0);
+        return;
+    }
+    o_sample_texture(&s->textures[id], uv.x, uv.y, d ? d->duv_dx : zero, d ? d->duv_dy : zero, out);
+}
+
+/* shader/src/lighting.rs:243-259 `compute_cotangent_frame` + :222-241 `calculate_normal` */
+static o_vec3 calculate_normal(const o_scene* s, o_vec3 interpolated_normal, const tr_material_info* material,
+                               o_vec2 uv, const o_frag_derivs* d) {
+    o_vec3 normal = v3_normalize(interpolated_normal);
+    if (material->textures.normal_map != -1) {
+        real smp[4];
+        sample_material_texture(s, material->textures.normal_map, uv, d, smp);
+        /* `map_normal * 255.0 / 127.0 - 128.0 / 127.0`: the compiled shader (fragment.spv) multiplies by the
+         * folded constant 255/127 = 2.007874 and subtracts the folded 128/127 */
+        o_vec3 map_normal = v3_add_s(v3_scale(v3(smp[0], smp[1], smp[2]), R(255.0) / R(127.0)), -(R(128.0) / R(127.0)));
+        o_vec3 zero3 = v3_splat(R(0.0));
+        o_vec2 zero2 = {R(0.0), R(0.0)};
+        o_vec3 dp1 = d ? d->dpos_dx : zero3, dp2 = d ? d->dpos_dy : zero3;
+        o_vec2 duv1 = d ? d->duv_dx : zero2, duv2 = d ? d->duv_dy : zero2;
+        o_vec3 dp2perp = v3_cross(dp2, normal);
+        o_vec3 dp1perp = v3_cross(normal, dp1);
+        o_vec3 t = v3_add(v3_scale(dp2perp, duv1.x), v3_scale(dp1perp, duv2.x));
+        o_vec3 b = v3_add(v3_scale(dp2perp, duv1.y), v3_scale(dp1perp, duv2.y));
+        real invmax = R(1.0) / R_SQRT(R_MAX(v3_dot(t, t), v3_dot(b, b)));
+        o_vec3 c0 = v3_scale(t, invmax), c1 = v3_scale(b, invmax);
+        /* Mat3::from_cols(c0, c1, normal) * map_normal */
+        o_vec3 r = v3_add(v3_add(v3_scale(c0, map_normal.x), v3_scale(c1, map_normal.y)), v3_scale(normal, map_normal.z));
+        normal = v3_normalize(r);
+    }
+    return normal;
+}
+
+/* shader/src/lighting.rs:261-301 */
+static o_material_params get_material_params(const o_scene* s, const real diffuse[4], const tr_material_info* m,
+                                             o_vec2 uv, const o_frag_derivs* d) {
     o_material_params mp;
+    real metallic = m->metallic_factor, roughness = m->roughness_factor;
+    real smp[4];
+    if (m->textures.metallic_roughness != -1) {
+        sample_material_texture(s, m->textures.metallic_roughness, uv, d, smp);
+        metallic *= smp[2];    /* sample.zy: "These two are switched!" */
+        roughness *= smp[1];
+    }
+    o_vec3 specular_colour = f3(m->specular_colour_factor);
+    if (m->textures.specular_colour != -1) {
+        sample_material_texture(s, m->textures.specular_colour, uv, d, smp);
+        specular_colour = v3_mul(specular_colour, v3(smp[0], smp[1], smp[2]));
+    }
+    real specular_factor = m->specular_factor;
+    if (m->textures.specular != -1) {
+        sample_material_texture(s, m->textures.specular, uv, d, smp);
+        specular_factor *= smp[3];
+    }
     mp.diffuse_colour = v3(diffuse[0], diffuse[1], diffuse[2]);
-    mp.metallic = m->metallic_factor;
-    mp.perceptual_roughness = m->roughness_factor;
+    mp.metallic = metallic;
+    mp.perceptual_roughness = roughness;
     mp.index_of_refraction = m->index_of_refraction;
-    mp.specular_colour = f3(m->specular_colour_factor);
-    mp.specular_factor = m->specular_factor;
+    mp.specular_colour = specular_colour;
+    mp.specular_factor = specular_factor;
     return mp;
+}
+
+/* shader/src/lighting.rs:303-313 */
+static o_vec3 get_emission(const o_scene* s, const tr_material_info* m, o_vec2 uv, const o_frag_derivs* d) {
+    o_vec3 emission = f3(m->emissive_factor);
+    if (m->textures.emissive != -1) {
+        real smp[4];
+        sample_material_texture(s, m->textures.emissive, uv, d, smp);
+        emission = v3_mul(emission, v3(smp[0], smp[1], smp[2]));
+    }
+    return emission;
+}
+
+/* diffuse = material.diffuse_factor; if textured: diffuse *= sample (lib.rs:65-69 / 190-194) */
+static void get_diffuse(const o_scene* s, const tr_material_info* m, o_vec2 uv, const o_frag_derivs* d, real out[4]) {
+    for (int k = 0; k < 4; ++k) out[k] = m->diffuse_factor[k];
+    if (m->textures.diffuse != -1) {
+        real smp[4];
+        sample_material_texture(s, m->textures.diffuse, uv, d, smp);
+        for (int k = 0; k < 4; ++k) out[k] *= smp[k];
+    }
 }
 
 /* cluster index: shader/src/lib.rs:88-98 / 205-215 */
@@ -681,17 +884,17 @@ static const o_vec3 DEBUG_COLOURS[15] = { /* shader/src/lib.rs:647-664 */
 
 /* shader/src/lib.rs:164-249 */
 void o_fragment(const o_scene* s, o_vec3 position, o_vec3 normal_in, o_vec2 uv, uint32_t material_id,
-                const real frag_coord[4], real out_rgba[4]) {
-    (void)uv;
+                const real frag_coord[4], const o_frag_derivs* d, real out_rgba[4]) {
     const tr_material_info* material = &s->materials[material_id];
     const tr_uniforms* u = &s->uniforms;
-    const float* diffuse = material->diffuse_factor;
+    real diffuse[4];
+    get_diffuse(s, material, uv, d, diffuse);
 
     o_vec3 view_vector = v3_sub(f3(s->push.view_position), position);
     o_vec3 view = v3_normalize(view_vector);
-    o_vec3 normal = v3_normalize(normal_in); /* calculate_normal, lighting.rs:222-241, no normal map */
-    o_material_params mp = get_material_params(diffuse, material);
-    o_vec3 emission = f3(material->emissive_factor); /* get_emission, lighting.rs:303-313 */
+    o_vec3 normal = calculate_normal(s, normal_in, material, uv, d);
+    o_material_params mp = get_material_params(s, diffuse, material, uv, d);
+    o_vec3 emission = get_emission(s, material, uv, d);
 
     uint32_t cluster = cluster_index(u, frag_coord);
     uint32_t num_lights = cluster_count(s, cluster);
@@ -741,18 +944,23 @@ static o_vec2 lut_sampler_cb(void* user, real nov, real roughness) {
 /* shader/src/lib.rs:37-162 */
 void o_fragment_transmission(const o_scene* s, const o_pyramid* framebuffer, o_vec3 position,
                              o_vec3 normal_in, o_vec2 uv, uint32_t material_id, real model_scale,
-                             const real frag_coord[4], real out_rgba[4]) {
-    (void)uv;
+                             const real frag_coord[4], const o_frag_derivs* d, real out_rgba[4]) {
     const tr_material_info* material = &s->materials[material_id];
     const tr_uniforms* u = &s->uniforms;
-    const float* diffuse = material->diffuse_factor;
+    real diffuse[4];
+    get_diffuse(s, material, uv, d, diffuse);
     real transmission_factor = material->transmission_factor;
+    if (material->textures.transmission != -1) {   /* lib.rs:73-77 */
+        real smp[4];
+        sample_material_texture(s, material->textures.transmission, uv, d, smp);
+        transmission_factor *= smp[0];
+    }
 
     o_vec3 view_vector = v3_sub(f3(s->push.view_position), position);
     o_vec3 view = v3_normalize(view_vector);
-    o_vec3 normal = v3_normalize(normal_in);
-    o_material_params mp = get_material_params(diffuse, material);
-    o_vec3 emission = f3(material->emissive_factor);
+    o_vec3 normal = calculate_normal(s, normal_in, material, uv, d);
+    o_material_params mp = get_material_params(s, diffuse, material, uv, d);
+    o_vec3 emission = get_emission(s, material, uv, d);
 
     uint32_t cluster = cluster_index(u, frag_coord);
     uint32_t num_lights = cluster_count(s, cluster);
@@ -778,6 +986,11 @@ void o_fragment_transmission(const o_scene* s, const o_pyramid* framebuffer, o_v
     }
 
     real thickness = material->thickness_factor;
+    if (material->textures.thickness != -1) {   /* lib.rs:122-124 */
+        real smp[4];
+        sample_material_texture(s, material->textures.thickness, uv, d, smp);
+        thickness *= smp[1];
+    }
 
     o_ibl_volume_refraction_params ip;
     ip.material_params = mp;
@@ -837,10 +1050,40 @@ static void* band_worker(void* arg) {
                 o_vec3 nrm = f3(&g->nrm_scale[i * 4]);
                 o_vec2 uv = {g->uv[i * 2], g->uv[i * 2 + 1]};
                 real frag_coord[4] = {(real)x + R(0.5), (real)y + R(0.5), g->pos_depth[i * 4 + 3], R(1.0)};
+                /* OpDPdx / OpDPdy restated on the G-buffer: differences inside the pixel's 2x2 quad (frame
+                 * coordinates), value(x|1) - value(x&~1) and value(y|1) - value(y&~1); zero when the partner is
+                 * outside the planes or not covered (a rasteriser would extrapolate a helper invocation). */
+                o_frag_derivs dv;
+                memset(&dv, 0, sizeof(dv));
+                {
+                    uint32_t xa = x & ~1u, xb = x | 1u, ya = y & ~1u, yb = y | 1u;
+                    uint32_t gx1 = g->origin_x + g->width, gy1 = g->origin_y + g->height;
+                    if (xa >= g->origin_x && xb < gx1) {
+                        size_t ia = (size_t)(y - g->origin_y) * g->width + (xa - g->origin_x), ib = ia + 1;
+                        if (g->material_id[ia] != TR_NOT_COVERED && g->material_id[ib] != TR_NOT_COVERED) {
+                            /* the shader differentiates the value -view_vector = -(view_position - position) */
+                            o_vec3 eye = f3(j->s->push.view_position);
+                            dv.dpos_dx = v3_sub(v3_neg(v3_sub(eye, f3(&g->pos_depth[ib * 4]))),
+                                                v3_neg(v3_sub(eye, f3(&g->pos_depth[ia * 4]))));
+                            dv.duv_dx.x = (real)g->uv[ib * 2] - (real)g->uv[ia * 2];
+                            dv.duv_dx.y = (real)g->uv[ib * 2 + 1] - (real)g->uv[ia * 2 + 1];
+                        }
+                    }
+                    if (ya >= g->origin_y && yb < gy1) {
+                        size_t ia = (size_t)(ya - g->origin_y) * g->width + (x - g->origin_x), ib = ia + g->width;
+                        if (g->material_id[ia] != TR_NOT_COVERED && g->material_id[ib] != TR_NOT_COVERED) {
+                            o_vec3 eye = f3(j->s->push.view_position);
+                            dv.dpos_dy = v3_sub(v3_neg(v3_sub(eye, f3(&g->pos_depth[ib * 4]))),
+                                                v3_neg(v3_sub(eye, f3(&g->pos_depth[ia * 4]))));
+                            dv.duv_dy.x = (real)g->uv[ib * 2] - (real)g->uv[ia * 2];
+                            dv.duv_dy.y = (real)g->uv[ib * 2 + 1] - (real)g->uv[ia * 2 + 1];
+                        }
+                    }
+                }
                 if (j->transmissive)
-                    o_fragment_transmission(j->s, j->fb, pos, nrm, uv, mat, g->nrm_scale[i * 4 + 3], frag_coord, rgba);
+                    o_fragment_transmission(j->s, j->fb, pos, nrm, uv, mat, g->nrm_scale[i * 4 + 3], frag_coord, &dv, rgba);
                 else
-                    o_fragment(j->s, pos, nrm, uv, mat, frag_coord, rgba);
+                    o_fragment(j->s, pos, nrm, uv, mat, frag_coord, &dv, rgba);
             }
             for (int k = 0; k < 4; ++k) {
                 if (j->hdr_f32) j->hdr_f32[o * 4 + k] = rgba[k];

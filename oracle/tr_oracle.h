@@ -131,6 +131,26 @@ o_vec3 o_sample_pyramid(const o_pyramid* p, real u, real v, real lod);  /* clamp
 o_vec2 o_sample_lut(const uint8_t* rgba8, uint32_t w, uint32_t h, real u, real v); /* bilinear, clamp */
 void   o_generate_mips(const o_pyramid* p, uint16_t* texels);      /* generate_mips, src/main.rs:2054 */
 
+/* ---- material textures: RGBA8, full chain of mip_levels_for_size levels packed level
+ *      after level; `srgb` selects R8G8B8A8_SRGB decoding (src/model_loading.rs:347-351). ---- */
+typedef struct {
+    const uint8_t* texels;
+    uint32_t width, height, levels, srgb;
+    uint32_t level_offset[TR_MAX_MIP_LEVELS];   /* in texels */
+} o_texture;
+
+/* screen-space derivatives of the interpolants a fragment shader may differentiate (OpDPdx / OpDPdy) */
+typedef struct {
+    o_vec3 dpos_dx, dpos_dy;   /* of the value the shader differentiates: -view_vector = -(view_position - position)
+                                * (lighting.rs:237), i.e. neighbour's value minus this quad partner's value */
+    o_vec2 duv_dx, duv_dy;
+} o_frag_derivs;
+
+void   o_texture_layout(uint32_t w, uint32_t h, o_texture* out, uint64_t* total_texels);
+void   o_generate_texture_mips(const o_texture* t, uint8_t* texels);   /* LINEAR blit chain, sRGB-aware */
+void   o_sample_texture(const o_texture* t, real u, real v, o_vec2 duv_dx, o_vec2 duv_dy, real out_rgba[4]);
+real   o_srgb_to_linear(uint8_t c);
+
 /* ---- scene tables shared by both fragment entry points ---- */
 typedef struct {
     const tr_material_info* materials;  uint32_t num_materials;
@@ -141,15 +161,17 @@ typedef struct {
     const uint8_t* ggx_lut_rgba8; uint32_t lut_width, lut_height;
     tr_uniforms uniforms;
     tr_push_constants push;
+    const o_texture* textures; uint32_t num_textures;   /* bindless `textures[]` (set 0 binding 0) */
 } o_scene;
 
-/* shader/src/lib.rs:164-249 `fragment` (untextured materials: every Textures id == -1). */
+/* shader/src/lib.rs:164-249 `fragment`.  `d` (may be NULL = zero derivatives) feeds implicit-LOD texture
+ * fetches and the normal-map cotangent frame; untextured materials never look at it. */
 void o_fragment(const o_scene* s, o_vec3 position, o_vec3 normal, o_vec2 uv, uint32_t material_id,
-                const real frag_coord[4], real out_rgba[4]);
-/* shader/src/lib.rs:37-162 `fragment_transmission` (untextured materials). */
+                const real frag_coord[4], const o_frag_derivs* d, real out_rgba[4]);
+/* shader/src/lib.rs:37-162 `fragment_transmission`. */
 void o_fragment_transmission(const o_scene* s, const o_pyramid* framebuffer, o_vec3 position,
                              o_vec3 normal, o_vec2 uv, uint32_t material_id, real model_scale,
-                             const real frag_coord[4], real out_rgba[4]);
+                             const real frag_coord[4], const o_frag_derivs* d, real out_rgba[4]);
 
 /* ---- whole passes over TGB-v1 planes (host memory). out_f32 (optional) receives the
  *      un-rounded fp32 RGBA; out_f16 (optional) the RTNE RGBA16F target. ---- */

@@ -29,6 +29,8 @@ def _scene_from_fixture(z):
     scene = {"materials": mats, "lights": lights, "cluster_counts": counts, "light_indices": idx,
              "uniforms": wire.Uniforms.from_buffer_copy(z["uniforms"].tobytes()),
              "push": wire.PushConstants.from_buffer_copy(z["push"].tobytes())}
+    if len(z["texture_srgb"]):
+        scene["textures"] = [(z[f"texture_{i}"], bool(sr)) for i, sr in enumerate(z["texture_srgb"])]
     w, h = int(z["width"]), int(z["height"])
     g = {"pos_depth": np.ascontiguousarray(z["pos_depth"]), "nrm_scale": np.ascontiguousarray(z["nrm_scale"]),
          "uv": np.ascontiguousarray(z["uv"]), "material_id": np.ascontiguousarray(z["material_id"]),
@@ -52,9 +54,10 @@ def test_oracle_matches_reference_spirv(path, ggx_lut):
     oracle.generate_mips(w, h, tex)
     _, t32 = oracle.shade_transmission(b, g, tex)
     _, o32, _ = oracle.shade_opaque(b, g)
-    for name, got, want in (("fragment_transmission", t32, z["spirv_fragment_transmission"]),
-                            ("fragment.hdr", o32, z["spirv_fragment_hdr"]),
-                            ("fragment.opaque_sampled", o32, z["spirv_fragment_opaque_sampled"])):
+    py, px = z["pixels"][:, 0], z["pixels"][:, 1]
+    for name, got, want in (("fragment_transmission", t32[py, px], z["spirv_fragment_transmission"]),
+                            ("fragment.hdr", o32[py, px], z["spirv_fragment_hdr"]),
+                            ("fragment.opaque_sampled", o32[py, px], z["spirv_fragment_opaque_sampled"])):
         assert np.isfinite(want).all() and want.shape == got.shape
         u = _ulps(got, want)
         assert u.max() == 0, (name, "max ulp", int(u.max()), "mismatching values", int((u != 0).sum()), "of", u.size)
@@ -67,3 +70,8 @@ def test_fixture_covers_the_path():
     assert all(len(np.unique(z["material_id"])) >= 8 for z in zs)
     assert any(len(np.unique(z["cluster_counts"])) > 1 for z in zs)             # lists of different length
     assert any((np.frombuffer(z["lights"].tobytes(), dtype=np.float32).reshape(-1, 12)[:, 11] != 0).any() for z in zs)
+    # one case runs the material-texture path: implicit-LOD fetches, sRGB decode, normal mapping (OpDPdx/OpDPdy)
+    tz = [z for z in zs if len(z["texture_srgb"])]
+    assert tz
+    mats = np.frombuffer(tz[0]["materials"].tobytes(), dtype=np.int32).reshape(-1, 40)[:, :9]
+    assert (mats[:, 2] >= 0).any() and (mats[:, 0] >= 0).any() and (mats != -1).sum() >= 12

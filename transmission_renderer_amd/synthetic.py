@@ -69,6 +69,58 @@ def make_materials(num=16, seed=SEED, roughness_override=None):
     return mats
 
 
+def make_textures():
+    """Eight procedural RGBA8 material textures (level 0) with the colour space the reference's loader would give
+    them (src/model_loading.rs:233-291): sizes include non-square and odd ones.  Returns [(image, srgb), ...]."""
+    def grid(w, h):
+        x = (np.arange(w, dtype=np.float64) + 0.5)[None, :] / w
+        y = (np.arange(h, dtype=np.float64) + 0.5)[:, None] / h
+        return x, y
+
+    def pack(*ch):
+        return np.ascontiguousarray(np.stack([np.clip(np.broadcast_to(c, ch[0].shape) * 255.0 + 0.5, 0, 255).astype(np.uint8)
+                                              for c in ch], axis=-1))
+    out = []
+    x, y = grid(64, 64)        # 0 diffuse (sRGB): stripes with alpha
+    out.append((pack(0.5 + 0.5 * np.sin(x * 40) * np.ones_like(y), 0.3 + 0.6 * y * np.ones_like(x), 0.8 * x * y,
+                     0.6 + 0.4 * np.cos(y * 9) * np.ones_like(x)), True))
+    x, y = grid(128, 64)       # 1 metallic (b) / roughness (g), UNORM, non-square
+    out.append((pack(0.0 * x * y, 0.15 + 0.8 * (0.5 + 0.5 * np.sin(x * 25 + y * 7)), 0.5 + 0.5 * np.cos(y * 13) * np.ones_like(x),
+                     1.0 + 0.0 * x * y), False))
+    x, y = grid(96, 96)        # 2 tangent-space normal map, UNORM
+    nx, ny = 0.35 * np.sin(x * 30) * np.ones_like(y), 0.35 * np.cos(y * 26) * np.ones_like(x)
+    nz = np.sqrt(np.clip(1 - nx * nx - ny * ny, 0, 1))
+    out.append((pack(nx * 0.5 + 0.5, ny * 0.5 + 0.5, nz * 0.5 + 0.5, 1.0 + 0 * nx), False))
+    x, y = grid(37, 21)        # 3 emissive (sRGB), odd sizes
+    out.append((pack(0.2 * (x > 0.5) * np.ones_like(y), 0.1 * y * np.ones_like(x), 0.3 * x * (y < 0.4), 1.0 + 0 * x * y), True))
+    x, y = grid(32, 32)        # 4 transmission (r), UNORM
+    out.append((pack(0.4 + 0.6 * (((x * 4).astype(int) + (y * 4).astype(int)) % 2), 0.5 + 0 * x * y, 0.5 + 0 * x * y, 1.0 + 0 * x * y), False))
+    x, y = grid(64, 16)        # 5 thickness (g), UNORM
+    out.append((pack(0.0 * x * y, 0.3 + 0.7 * x * np.ones_like(y), 0.0 * x * y, 1.0 + 0 * x * y), False))
+    x, y = grid(16, 16)        # 6 specular factor (a)
+    out.append((pack(0.5 + 0 * x * y, 0.5 + 0 * x * y, 0.5 + 0 * x * y, 0.4 + 0.6 * x * y), False))
+    x, y = grid(48, 80)        # 7 specular colour (sRGB)
+    out.append((pack(0.6 + 0.4 * x * np.ones_like(y), 0.7 + 0.3 * y * np.ones_like(x), 0.9 - 0.4 * x * y, 1.0 + 0 * x * y), True))
+    return out
+
+
+def apply_textures(materials):
+    """Gives five of the synthetic materials texture slots (ids into make_textures()): one with every slot the
+    shaders read, the others with typical subsets."""
+    T = wire.Textures
+    sets = {2: dict(diffuse=0), 5: dict(metallic_roughness=1, normal_map=2), 7: dict(diffuse=0, emissive=3, transmission=4),
+            9: dict(diffuse=0, metallic_roughness=1, normal_map=2, emissive=3, transmission=4, thickness=5, specular=6,
+                    specular_colour=7),
+            12: dict(thickness=5, specular=6, specular_colour=7)}
+    for i, slots in sets.items():
+        if i < len(materials):
+            t = T(*([-1] * 9))
+            for k, v in slots.items():
+                setattr(t, k, v)
+            materials[i].textures = t
+    return materials
+
+
 def make_lights(num_point_lights: int):
     """The reference's first point light (src/main.rs:451) for N=1, its two for N=2, plus two more for N=4."""
     pool = wire.default_lights() + [
@@ -173,7 +225,7 @@ def make_opaque_mip0(width: int, height: int) -> np.ndarray:
 
 
 def make_scene(width: int, height: int, num_point_lights=1, seed=SEED, roughness_override=None, coverage="full",
-               num_materials=16, with_gbuffer=True):
+               num_materials=16, with_gbuffer=True, textured=False):
     """Everything one frame needs, host side.  Returns a dict of numpy arrays + ctypes structs."""
     scene = {
         "width": width, "height": height,
@@ -182,6 +234,9 @@ def make_scene(width: int, height: int, num_point_lights=1, seed=SEED, roughness
         "uniforms": wire.make_uniforms(width, height),
         "push": wire.make_push_constants(width, height),
     }
+    if textured:
+        scene["textures"] = make_textures()
+        apply_textures(scene["materials"])
     scene["cluster_counts"], scene["light_indices"] = all_lights_cluster_tables(num_point_lights)
     if with_gbuffer:
         scene["gbuffer"] = make_gbuffer(width, height, num_materials, coverage)
