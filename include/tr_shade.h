@@ -195,6 +195,27 @@ typedef struct tr_pyramid {
     uint32_t level_offset[TR_MAX_MIP_LEVELS];    /* in texels, from `texels` */
 } tr_pyramid;
 
+/*
+ * One image of the bindless `textures[]` array (set 0 binding 0): what `load_image_from_bytes`
+ * (src/model_loading.rs:335-390) is given — decoded RGBA8 level 0 and whether the loader asked for
+ * R8G8B8A8_SRGB (diffuse, emissive, specular colour; :233-291) or R8G8B8A8_UNORM.  The index of a texture is its
+ * position in the array passed to tr_upload_textures; MaterialInfo.textures.* index it.
+ */
+typedef struct tr_texture_desc {
+    const uint8_t* rgba8;      /* HOST pointer, width*height*4 bytes, row 0 first */
+    uint32_t width, height;
+    uint32_t srgb;             /* 1 = R8G8B8A8_SRGB, 0 = R8G8B8A8_UNORM */
+    uint32_t _reserved;
+} tr_texture_desc;
+
+/* The packed mip chain of one material texture (levels tightly packed, RGBA8, level l is
+ * max(width>>l,1) x max(height>>l,1)); level count = mip_levels_for_size (src/model_loading.rs:354). */
+typedef struct tr_texture_layout {
+    uint32_t width, height, levels, srgb;
+    uint32_t level_offset[TR_MAX_MIP_LEVELS];    /* in texels */
+    uint32_t total_texels;
+} tr_texture_layout;
+
 typedef struct tr_context tr_context; /* opaque */
 
 /* ------------------------------------------------------------------ context */
@@ -217,7 +238,8 @@ tr_status tr_pyramid_layout(uint32_t width, uint32_t height, tr_pyramid* out_pyr
 /* -------------------------------------------------------------------- tables */
 
 /* materials[] storage buffer (set 0 binding 2; src/main.rs:715-760, filled by
- * src/model_loading.rs:231-333).  Host pointer; copied and pre-digested on `stream`. */
+ * src/model_loading.rs:231-333).  Host pointer; copied and pre-digested on `stream`.  Texture ids (!= -1) refer to
+ * the array given to tr_upload_textures (either upload order; checked when a pass is launched). */
 tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials_host, uint32_t count, void* stream);
 
 /* lights[] storage buffer (set 2 binding 0; src/main.rs:450-496). Host pointer. */
@@ -231,6 +253,22 @@ tr_status tr_set_cluster_tables(tr_context* ctx, const void* cluster_light_count
 
 /* ggx_lut.png as uploaded by src/main.rs:295-330 (R8G8B8A8_UNORM, row 0 first). Host pointer. */
 tr_status tr_upload_ggx_lut(tr_context* ctx, const uint8_t* rgba8_host, uint32_t width, uint32_t height, void* stream);
+
+/*
+ * The bindless material textures (set 0 binding 0; src/model_loading.rs:160-215 pushes them in this order).
+ * Replaces the whole array: level 0 of every image is copied to HBM and its full mip chain is generated on the
+ * device on `stream` (the LINEAR vkCmdBlitImage chain of load_image_from_bytes; sRGB images are filtered in
+ * linear light).  Sampling is the reference's `sampler` (src/main.rs:683-692): LINEAR min/mag/mip, REPEAT,
+ * implicit LOD from the 2x2 quad's uv differences.  count == 0 clears the array.
+ * Passes that shade a material with texture ids need: rect.x0 and rect.y0 even, rect.x1 / rect.y1 even or equal to
+ * the frame size (whole quads), g->uv set, and every id < count (TR_ERR_INVALID_ARGUMENT otherwise).
+ */
+tr_status tr_upload_textures(tr_context* ctx, const tr_texture_desc* textures_host, uint32_t count, void* stream);
+
+/* Layout of texture `index` as uploaded; tr_download_texture copies its whole chain (total_texels*4 bytes) back to
+ * host memory after synchronising `stream` (inspection / tests). */
+tr_status tr_texture_get_layout(const tr_context* ctx, uint32_t index, tr_texture_layout* out);
+tr_status tr_download_texture(tr_context* ctx, uint32_t index, void* rgba8_host_out, size_t capacity_bytes, void* stream);
 
 /* ------------------------------------------------------- clustered-light build */
 

@@ -288,11 +288,6 @@ def test_error_paths(renderer, ggx_lut):
     with pytest.raises(_lib.TrError) as e:      # nothing uploaded yet
         fresh.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr)
     assert e.value.status == 4
-    textured = wire.MaterialInfo.default()
-    textured.textures.diffuse = 3
-    with pytest.raises(_lib.TrError) as e:      # material textures are not on this build's path
-        fresh.upload_materials([textured])
-    assert e.value.status == 6
     fresh.upload_ggx_lut(ggx_lut)
     _upload_scene(fresh, scene)
     with pytest.raises(_lib.TrError) as e:      # rect outside the frame

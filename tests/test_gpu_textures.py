@@ -1,0 +1,257 @@
+"""GPU parity of the material-texture path (run with -m gpu on an MI355X): bindless RGBA8
+textures with device-built mip chains, implicit-LOD sampling from 2x2 quad differences, sRGB decode, normal
+mapping, and the per-pixel material digest, through the C ABI against the CPU oracle — which is itself pinned
+bit-exactly on this path by the reference's compiled shaders (tests/golden/spirv_case_c.npz).
+
+Criteria: byte work (the mip chains) is bit-exact; shaded frames follow T1/T2/T3 of tests/test_gpu_parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle  # noqa: E402
+from transmission_renderer_amd import synthetic, wire  # noqa: E402
+from test_gpu_parity import _check_against_oracles, _norm_err, _rmse, _upload_scene  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def renderer(ggx_lut):
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device: the -m gpu tests must run on the GPU box")
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    r = TransmissionRenderer(0)
+    r.upload_ggx_lut(ggx_lut)
+    yield r
+    r.close()
+
+
+def _random_textures():
+    rng = np.random.default_rng(11)
+    sizes = [(64, 64), (37, 21), (1, 1), (2, 5), (255, 130), (16, 1), (512, 256), (3, 3)]   # (w, h)
+    return [(rng.integers(0, 256, (h, w, 4), dtype=np.uint8), bool(i & 1)) for i, (w, h) in enumerate(sizes)]
+
+
+def test_texture_mip_chains_bit_exact(renderer):
+    """The device's LINEAR blit chain (sRGB images filtered in linear light and re-encoded) is byte-identical to
+    the oracle's, odd and degenerate sizes included; level 0 is the uploaded image."""
+    r = renderer
+    textures = _random_textures() + synthetic.make_textures()
+    r.upload_textures(textures)
+    for i, (img, srgb) in enumerate(textures):
+        lay, levels = r.download_texture(i)
+        want, ot = oracle.make_texture(img, srgb)
+        assert (lay.width, lay.height, lay.srgb) == (img.shape[1], img.shape[0], int(srgb))
+        assert lay.levels == ot.levels == wire.mip_levels_for_size(img.shape[1], img.shape[0])
+        assert [lay.level_offset[l] for l in range(lay.levels)] == [ot.level_offset[l] for l in range(ot.levels)]
+        np.testing.assert_array_equal(levels[0], img)
+        got = np.concatenate([lv.reshape(-1, 4) for lv in levels])
+        np.testing.assert_array_equal(got, want, err_msg=f"texture {i} {img.shape} srgb={srgb}")
+    r.upload_textures([])
+
+
+TEXTURED_CASES = [
+    # (w, h, lights, coverage, uv scale)
+    (256, 256, 2, "full", 1.0),
+    (250, 130, 3, "holes", 0.75),    # ragged tiles, frame edge inside a quad column, uncovered quad partners
+    (192, 108, 1, "full", 6.0),      # minification: upper mip levels, LOD fractions
+    (96, 64, 2, "full", 0.05),       # magnification: level 0 only
+]
+
+
+def _textured_scene(w, h, nl, coverage, uv_scale):
+    scene = synthetic.make_scene(w, h, num_point_lights=nl, coverage=coverage, textured=True)
+    scene["gbuffer"]["uv"] *= np.float32(uv_scale)
+    return scene
+
+
+def _degenerate(materials, material_id):
+    """Normal-mapped pixels with a missing 2x2-quad partner.  Their derivatives are zero, the cotangent frame of
+    lighting.rs:243-259 becomes 0 * (1 / sqrt(0)) = NaN, and what the reference's own arithmetic makes of a NaN
+    normal (its max()-clamped dot products swallow it) is operation-order noise on every implementation.  A
+    rasteriser never produces this (helper invocations supply the partner), so these pixels are not compared."""
+    cov = material_id != wire.NOT_COVERED
+    h, w = cov.shape
+    px, py = np.zeros_like(cov), np.zeros_like(cov)
+    xs, ys = np.arange(w) ^ 1, np.arange(h) ^ 1
+    px[:, xs < w] = cov[:, xs[xs < w]]
+    py[ys < h, :] = cov[ys[ys < h], :]
+    nm = np.array([m.textures.normal_map != -1 for m in materials])
+    has_nm = cov & nm[np.where(cov, material_id, 0)]
+    return has_nm & ~(px & py)
+
+
+def _masked(mask, *arrays):
+    return [np.where(mask[..., None], a, np.asarray(1.0, dtype=a.dtype)) for a in arrays]
+
+
+@pytest.mark.parametrize("w,h,nl,coverage,uv_scale", TEXTURED_CASES)
+def test_textured_transmissive_pass_parity(renderer, ggx_lut, w, h, nl, coverage, uv_scale):
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    scene = _textured_scene(w, h, nl, coverage, uv_scale)
+    _upload_scene(r, scene)
+    r.upload_textures(scene["textures"])
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    b = oracle.SceneBinding(scene, ggx_lut)
+    tex = oracle.new_pyramid(w, h, synthetic.make_opaque_mip0(w, h))
+    oracle.generate_mips(w, h, tex)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.texels.copy_(torch.from_numpy(tex).to(r.device))
+    base = np.full((h, w, 4), 0.125, dtype=np.float32)
+    t32 = torch.from_numpy(base).to(r.device)
+    t16 = torch.from_numpy(base.astype(np.float16)).to(r.device)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t16)
+    torch.cuda.synchronize()
+    o16, o32 = oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=base.astype(np.float16), hdr_f32=base.copy(),
+                                         nthreads=8)
+    o16_64, o64 = oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=base.astype(np.float16),
+                                            hdr_f32=base.astype(np.float64), nthreads=8, fp64=True)
+    got32, got16 = t32.cpu().numpy(), t16.cpu().numpy()
+    holes = scene["gbuffer"]["material_id"] == wire.NOT_COVERED
+    assert (got32[holes] == 0.125).all() and (got16[holes] == np.float16(0.125)).all()
+    ok = ~_degenerate(scene["materials"], scene["gbuffer"]["material_id"])
+    assert ok.mean() >= 0.99
+    got32, o32, o64 = _masked(ok, got32, o32, o64)
+    got16, o16_64 = _masked(ok, got16, o16_64)
+    _check_against_oracles(got32, got16, o32, o64, o16_64, f"textured transmission {w}x{h} uv*{uv_scale}")
+
+
+@pytest.mark.parametrize("w,h,coverage,uv_scale", [(256, 256, "full", 1.0), (250, 130, "holes", 2.5)])
+def test_textured_opaque_pass_parity(renderer, ggx_lut, w, h, coverage, uv_scale):
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    scene = _textured_scene(w, h, 2, coverage, uv_scale)
+    _upload_scene(r, scene)
+    r.upload_textures(scene["textures"])
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    b = oracle.SceneBinding(scene, ggx_lut)
+    pyr = OpaquePyramid(w, h, r.device)
+    h32 = torch.full((h, w, 4), 9.0, dtype=torch.float32, device=r.device)
+    h16 = torch.full((h, w, 4), 9.0, dtype=torch.float16, device=r.device)
+    r.shade_opaque(g, scene["uniforms"], scene["push"], h32, None)
+    r.shade_opaque(g, scene["uniforms"], scene["push"], h16, pyr)
+    torch.cuda.synchronize()
+    _, o32, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8)
+    o16_64, o64, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
+    got32, got16 = h32.cpu().numpy(), h16.cpu().numpy()
+    ok = ~_degenerate(scene["materials"], scene["gbuffer"]["material_id"])
+    assert ok.mean() >= 0.99
+    got32, o32, o64 = _masked(ok, got32, o32, o64)
+    got16, o16_64 = _masked(ok, got16, o16_64)
+    _check_against_oracles(got32, got16, o32, o64, o16_64, f"textured opaque {w}x{h}")
+
+
+def test_textured_pixels_match_the_compiled_shaders(renderer, ggx_lut):
+    """The textured golden case: outputs of the reference's own fragment_transmission.spv / fragment.spv on the
+    fixture's inputs (tests/golden/spirv_case_c.npz), against this library's frames."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    z = np.load(os.path.join(GOLDEN, "spirv_case_c.npz"))
+    w, h = int(z["width"]), int(z["height"])
+    n_mat, n_light = len(z["materials"]) // 160, len(z["lights"]) // 48
+    materials = [wire.MaterialInfo.from_buffer_copy(z["materials"][i * 160:(i + 1) * 160].tobytes()) for i in range(n_mat)]
+    lights = [wire.Light.from_buffer_copy(z["lights"][i * 48:(i + 1) * 48].tobytes()) for i in range(n_light)]
+    uniforms = wire.Uniforms.from_buffer_copy(z["uniforms"].tobytes())
+    push = wire.PushConstants.from_buffer_copy(z["push"].tobytes())
+    counts = z["cluster_counts"].astype(np.uint32)
+    indices = np.tile(z["light_list"].astype(np.uint32), len(counts))
+    r.upload_materials(materials)
+    r.upload_lights(lights)
+    r.set_cluster_tables(torch.from_numpy(counts.view(np.int32)).to(r.device),
+                         torch.from_numpy(indices.view(np.int32)).to(r.device))
+    r.upload_textures([(z[f"texture_{i}"], bool(s)) for i, s in enumerate(z["texture_srgb"])])
+    gb = {"pos_depth": z["pos_depth"], "nrm_scale": z["nrm_scale"], "uv": z["uv"], "material_id": z["material_id"],
+          "width": w, "height": h}
+    g = GBufferPlanes.from_numpy(gb, r.device)
+    tex = oracle.new_pyramid(w, h, z["opaque_mip0"])
+    oracle.generate_mips(w, h, tex)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.texels.copy_(torch.from_numpy(tex).to(r.device))
+    t32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    r.shade_transmission(g, uniforms, push, pyr, t32)
+    o32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    r.shade_opaque(g, uniforms, push, o32, None)
+    torch.cuda.synchronize()
+    ys, xs = z["pixels"][:, 0], z["pixels"][:, 1]
+    keep = ~_degenerate(materials, z["material_id"])[ys, xs]
+    assert keep.mean() >= 0.9
+    for got, want, what in ((t32.cpu().numpy()[ys, xs], z["spirv_fragment_transmission"], "fragment_transmission"),
+                            (o32.cpu().numpy()[ys, xs], z["spirv_fragment_hdr"], "fragment")):
+        assert np.isfinite(got[keep]).all() and np.isfinite(want[keep]).all()
+        e = _norm_err(got[keep][None], want[keep][None])
+        # the fp32 shaders themselves carry up to ~4e-3 of conditioning noise on a few glossy pixels (T3)
+        assert _rmse(e).max() <= 2e-4 and np.quantile(np.abs(e), 0.99) <= 1e-4, (what, _rmse(e), np.abs(e).max())
+
+
+def test_textured_bands_equal_whole_frame(renderer, ggx_lut):
+    """Row bands with even boundaries (whole 2x2 quads) shaded from tile-local G-buffers give the same bits as one
+    whole-frame launch: what the sharded path does when materials are textured."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    w, h = 256, 192
+    scene = _textured_scene(w, h, 2, "holes", 1.5)
+    _upload_scene(r, scene)
+    r.upload_textures(scene["textures"])
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    pyr = OpaquePyramid(w, h, r.device)
+    hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+    r.record(g, g, scene["uniforms"], scene["push"], hdr, pyr)
+    torch.cuda.synchronize()
+    pyr2 = OpaquePyramid(w, h, r.device)
+    hdr2 = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+    bands = [(0, 62), (62, 130), (130, 192)]
+    tiles = []
+    for b in bands:
+        t = synthetic.make_gbuffer(w, h, coverage="holes", rows=b)
+        t["uv"] *= np.float32(1.5)
+        tiles.append(GBufferPlanes.from_numpy(t, r.device))
+    for t in tiles:
+        r.shade_opaque(t, scene["uniforms"], scene["push"], hdr2, pyr2)
+    r.generate_mips(pyr2)
+    for t in tiles:
+        r.shade_transmission(t, scene["uniforms"], scene["push"], pyr2, hdr2)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(hdr2.cpu().numpy().view(np.uint16), hdr.cpu().numpy().view(np.uint16))
+
+
+def test_textured_error_paths(ggx_lut):
+    from transmission_renderer_amd import _lib
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer
+    fresh = TransmissionRenderer(0)
+    fresh.upload_ggx_lut(ggx_lut)
+    w, h = 64, 64
+    scene = _textured_scene(w, h, 1, "full", 1.0)
+    _upload_scene(fresh, scene)
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], fresh.device)
+    pyr = OpaquePyramid(w, h, fresh.device)
+    hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=fresh.device)
+    with pytest.raises(_lib.TrError) as e:      # materials refer to textures that were never uploaded
+        fresh.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr)
+    assert e.value.status == 1
+    fresh.upload_textures(scene["textures"][:3])
+    with pytest.raises(_lib.TrError) as e:      # ... or to ids beyond the array
+        fresh.shade_opaque(g, scene["uniforms"], scene["push"], hdr, None)
+    assert e.value.status == 1
+    fresh.upload_textures(scene["textures"])
+    with pytest.raises(_lib.TrError) as e:      # a rect that cuts 2x2 quads
+        fresh.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr, rect=(0, 1, w, h))
+    assert e.value.status == 1
+    with pytest.raises(_lib.TrError) as e:
+        fresh.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr, rect=(0, 0, w - 1, h))
+    assert e.value.status == 1
+    fresh.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr, rect=(2, 4, w - 2, h))
+    bad = wire.MaterialInfo.default()
+    bad.textures.diffuse = -7
+    with pytest.raises(_lib.TrError) as e:
+        fresh.upload_materials([bad])
+    assert e.value.status == 1
+    torch.cuda.synchronize()
+    fresh.close()

@@ -1,0 +1,56 @@
+// tr_common.h — what every gfx950 device header of this library shares: constants, the scalar-table address
+// space, and the one-instruction math helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/tr_shade.h"
+
+namespace tr {
+
+constexpr float kEpsilon = 1.1920929e-07f;  // core::f32::EPSILON (glam-pbr/src/lib.rs:95)
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kFrac1Pi = 0.318309886183790671538f;
+constexpr float kLog2e = 1.44269504088896340736f;
+
+typedef float v2f __attribute__((ext_vector_type(2)));  // one v_pk_*_f32 operand
+
+// Tables that a whole wave reads at one address (material, lights, cluster lists, level geometry)
+// are addressed through the constant address space: a uniform load from it is always issued on the
+// scalar unit (s_load into SGPRs), also inside the material / cluster loops where the compiler
+// cannot otherwise prove that no store clobbers them.  (Constant and global are the same memory.)
+#define TR_CONSTANT __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const TR_CONSTANT T* as_constant(const T* p) {
+    return (const TR_CONSTANT T*)(p);
+}
+
+// Makes a (uniform) pointer opaque to the optimiser: loads through the result cannot be hoisted above
+// this point, so their live ranges start here.
+template <class T>
+__device__ __forceinline__ T* launder(T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// ------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+__device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_max(v2f a, float b) { return v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
+
+struct f3 {
+    float x, y, z;
+};
+
+}  // namespace tr

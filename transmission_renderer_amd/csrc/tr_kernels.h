@@ -37,21 +37,10 @@
 //   cluster lookup               shader/src/lib.rs:88-98, shared-structs/src/lib.rs:54-63
 #pragma once
 
-#include <hip/hip_runtime.h>
-#include <hip/hip_fp16.h>
-#include <stdint.h>
-#include <type_traits>
-
-#include "../../include/tr_shade.h"
+#include "tr_common.h"
+#include "tr_texture_kernels.h"
 
 namespace tr {
-
-constexpr float kEpsilon = 1.1920929e-07f;  // core::f32::EPSILON (glam-pbr/src/lib.rs:95)
-constexpr float kPi = 3.14159265358979323846f;
-constexpr float kFrac1Pi = 0.318309886183790671538f;
-constexpr float kLog2e = 1.44269504088896340736f;
-
-typedef float v2f __attribute__((ext_vector_type(2)));  // one v_pk_*_f32 operand
 
 // Profiling builds (-DTR_ABLATION=1) honour fp.ablate (TR_ABLATE env) to switch phases off; in the product
 // build the switches do not exist: a branch around a load makes the s_waitcnt counters imprecise.
@@ -80,8 +69,11 @@ struct alignas(16) tr_dmat {
     float k[2];            // a2 * 0.5 / pi   (numerator of D*V)
     uint32_t lut_row0;     // GGX LUT row offsets into the pair table (entries)
     uint32_t lut_row1;
-    uint32_t flags;        // bit0: finite attenuation distance; bit1: transmission_factor != 0
-    uint32_t _pad[7];
+    uint32_t flags;        // bit0: finite attenuation distance; bit1: transmission_factor != 0;
+                           // bit2: the material has texture slots (shaded by the per-pixel material path)
+    float ior_clamp;       // clamp(2 ior - 2, 0, 1)
+    float f0_dielectric;   // ((ior - 1) / (ior + 1))^2
+    uint32_t _pad[5];
 };
 static_assert(sizeof(tr_dmat) == 160, "digested material is 160 B");
 
@@ -122,24 +114,16 @@ struct tr_frame_params {
     uint32_t rect_x0, rect_y0, rect_x1, rect_y1;
     uint32_t tiles_x, tiles_y;   // 64x4 tiles covering the rect
     uint32_t lut_width, lut_stride;  // pair-table stride in entries (= lut_width + 2)
+    uint32_t lut_height;
     uint32_t pyr_levels;
     uint32_t ablate;             // profiling only (TR_ABLATE env): bit0 no pyramid taps, bit1 no LUT, bit2 no sun,
                                  // bit3 no punctual lights, bit4 no refraction math
 };
 
-// Tables that a whole wave reads at one address (material, lights, cluster lists, level geometry)
-// are addressed through the constant address space: a uniform load from it is always issued on the
-// scalar unit (s_load into SGPRs), also inside the material / cluster loops where the compiler
-// cannot otherwise prove that no store clobbers them.  (Constant and global are the same memory.)
-#define TR_CONSTANT __attribute__((address_space(4)))
 typedef const TR_CONSTANT tr_dmat cdmat;
 typedef const TR_CONSTANT tr_dlight cdlight;
 typedef const TR_CONSTANT tr_level_table clevels;
 typedef const TR_CONSTANT uint32_t cu32;
-template <class T>
-__device__ __forceinline__ const TR_CONSTANT T* as_constant(const T* p) {
-    return (const TR_CONSTANT T*)(p);
-}
 
 // The single kernel argument of shade_kernel: frame parameters and every pointer.  The kernel reads it
 // through the kernarg segment pointer, re-"laundered" at the start of each phase (`launder`): a value
@@ -161,34 +145,25 @@ struct tr_launch {
     const uint2* pyramid;
     void* hdr;
     uint2* mip0;
+    // textured materials only (shade_kernel<.., TEXTURED = true>)
+    const float2* uv;
+    const tr_material_info* materials;  // the raw records: factors and texture ids
+    const struct tr_dtex* textures;
+    const uint32_t* tex_arena;          // RGBA8 texels of every chain
+    const float* srgb_to_linear;        // 256 entries
 };
 typedef const TR_CONSTANT tr_launch claunch;
 
-// Makes a (uniform) pointer opaque to the optimiser: loads through the result cannot be hoisted above
-// this point, so their live ranges start here.
-template <class T>
-__device__ __forceinline__ T* launder(T* p) {
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-// ------------------------------------------------------------------------ small helpers
-__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
-    return fmaf(az, bz, fmaf(ay, by, ax * bx));
-}
-__device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f pk_max(v2f a, float b) { return v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
-
-struct f3 {
-    float x, y, z;
+// The material as the per-pixel code reads it when it has texture slots: the same fields as tr_dmat, but
+// per lane (vector registers), digested per pixel from the sampled factors.
+struct lane_dmat {
+    float diffuse[3], f90, c_diff[3], eta, f0[3], transmission_factor, df[3], thickness, emission[3], rough_ior;
+    float neg_atten_log2[3], lut_fy, a2[2], oma2[2], k[2];
+    uint32_t lut_row0, lut_row1, flags;
 };
+__device__ __forceinline__ const lane_dmat* launder(const lane_dmat* p) { return p; }
 
+// ------------------------------------------------------------------------ one light
 // Accumulators of one pixel over its lights.
 struct light_acc {
     f3 d;        // sum I * nol * (1 - max(F))                     (x c_diff/pi at the end)
@@ -214,8 +189,8 @@ struct pixel_frame {
     v2f g_nov;         // sqrt(n.v^2 (1 - a2) + a2) per lobe: the light-independent half of v_smith
 };
 
-template <bool TRANSMISSIVE>
-__device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, const pixel_frame& px, f3 l, f3 I, bool btdf) {
+template <bool TRANSMISSIVE, class Mat /* cdmat (scalar registers) or const lane_dmat (per lane) */>
+__device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_frame& px, f3 l, f3 I, bool btdf) {
     const f3 n = px.n, v = px.v;
     const float nov_raw = px.nov_raw, nov = px.nov;
     const float nl_raw = dot3(n.x, n.y, n.z, l.x, l.y, l.z);
@@ -273,8 +248,8 @@ __device__ __forceinline__ void eval_light(light_acc& acc, cdmat& m, const pixel
     }
 }
 
-template <bool TRANSMISSIVE>
-__device__ __forceinline__ void eval_punctual(light_acc& acc, cdmat& m, cdlight& L, f3 pos, const pixel_frame& px,
+template <bool TRANSMISSIVE, class Mat>
+__device__ __forceinline__ void eval_punctual(light_acc& acc, Mat& m, cdlight& L, f3 pos, const pixel_frame& px,
                                               bool btdf) {
     // light_direction_and_attenuation (glam-pbr/src/lib.rs:12-23): bare 1/d^2
     float dx = L.pos[0] - pos.x, dy = L.pos[1] - pos.y, dz = L.pos[2] - pos.z;
@@ -338,18 +313,13 @@ __device__ __forceinline__ void axis_single(float u, float dimf, float& w, uint3
     i1 = (uint32_t)fminf(fl + 1.0f, dimf - 1.0f);
 }
 
-// Issues the loads of framebuffer.sample_by_lod(clamp_sampler, uv, lod) (shader/src/lib.rs:135-138).
-// `lod` is wave-uniform (it depends on the material only), so level geometry is scalar.  Every row of
+// Issues the loads of framebuffer.sample_by_lod(clamp_sampler, uv, lod) (shader/src/lib.rs:135-138) for the
+// lanes whose lower level is the (scalar) `l0`, so level geometry is scalar.  Every row of
 // every level is one 16-byte load of two adjacent texels; in a level that is a single texel wide the
 // second one belongs to the next row / level (or to the 8 bytes of tail padding tr_pyramid_layout
 // reserves) and is replaced by the first before use.
-__device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __restrict__ texels,
-                                              clevels* lv, uint32_t levels, float u, float v,
-                                              float lod) {
-    float l = fminf(fmaxf(lod, 0.0f), (float)(levels - 1u));
-    float lf = floorf(l);
-    pf.t = l - lf;
-    const uint32_t l0 = __builtin_amdgcn_readfirstlane((uint32_t)lf);
+__device__ __forceinline__ void pyramid_issue_levels(pyramid_fetch& pf, const uint2* __restrict__ texels,
+                                                     clevels* lv, uint32_t levels, float u, float v, uint32_t l0) {
     const uint32_t l1 = min(l0 + 1u, levels - 1u);
     const uint32_t w0 = lv->width[l0], w1 = lv->width[l1];
     const uint2* b0 = texels + lv->offset[l0];
@@ -371,6 +341,31 @@ __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __
     pf.r1[1] = ld(b1 + y11 * w1 + bx[1]);
     pf.narrow0 = w0 < 2u;
     pf.narrow1 = w1 < 2u;
+}
+
+// UNIFORM_LOD: `lod` depends on the material only and the material is in scalar registers, so the whole wave
+// shares the level pair.  Otherwise (roughness from a texture) the wave walks the distinct level pairs of its
+// lanes, normally one or two.
+template <bool UNIFORM_LOD>
+__device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __restrict__ texels,
+                                              clevels* lv, uint32_t levels, float u, float v,
+                                              float lod, uint32_t lane) {
+    float l = fminf(fmaxf(lod, 0.0f), (float)(levels - 1u));
+    float lf = floorf(l);
+    pf.t = l - lf;
+    if constexpr (UNIFORM_LOD) {
+        pyramid_issue_levels(pf, texels, lv, levels, u, v, __builtin_amdgcn_readfirstlane((uint32_t)lf));
+    } else {
+        const uint32_t mine = (uint32_t)lf;
+        uint64_t todo = __ballot(1);
+        while (todo) {
+            const int first = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, first);
+            const uint64_t group = __ballot(mine == l0);
+            todo &= ~group;
+            if ((group >> lane) & 1ull) pyramid_issue_levels(pf, texels, lv, levels, u, v, l0);
+        }
+    }
 }
 
 // Filters the fetched texels.  Written as one weighted sum over the 8 taps,
@@ -418,8 +413,9 @@ struct lut_fetch {
     uint32_t p0, p1;
     float fx;
 };
+template <class Mat>
 __device__ __forceinline__ void lut_issue(lut_fetch& lf, const uint32_t* __restrict__ pairs, float lut_wf,
-                                          cdmat& m, float nov_raw) {
+                                          Mat& m, float nov_raw) {
     float x = fmaf(nov_raw, lut_wf, -0.5f);
     x = fminf(fmaxf(x, -1.0f), lut_wf);
     float fl = floorf(x);
@@ -457,19 +453,58 @@ __device__ __forceinline__ f3 debug_colour_for_id(uint32_t id) {
     return {c[k][0], c[k][1], c[k][2]};
 }
 
+// ------------------------------------------------------------------------ material digestion
+// The part of the digest that depends on the factors a texture can modulate (metallic, roughness, specular,
+// base colour): run once per material at upload for materials without textures (digest_materials_kernel, into
+// scalar-read tr_dmat) and once per pixel for textured ones (into lane_dmat).  Same fp32 operations as the
+// reference where a value is a pure function of its inputs (glam-pbr/src/lib.rs:141-161, 182-198, 425-435).
+template <class D>
+__device__ __forceinline__ void digest_factors(D& d, float metallic, float rough, float ior_clamp, float f0d,
+                                               float specular_factor, float scx, float scy, float scz, float dx,
+                                               float dy, float dz, uint32_t lut_height, uint32_t lut_stride) {
+#pragma clang fp contract(off)
+    const float alpha = rough * rough;
+    const float alpha_t = alpha * ior_clamp;                         // ActualRoughness::apply_ior :144-146
+    d.a2[0] = alpha * alpha;
+    d.a2[1] = alpha_t * alpha_t;
+    for (int k = 0; k < 2; ++k) {
+        d.oma2[k] = 1.0f - d.a2[k];
+        d.k[k] = d.a2[k] * (0.5f * kFrac1Pi);
+    }
+    d.f90 = specular_factor + (1.0f - specular_factor) * metallic;  // calculate_combined_f90
+    const float diffuse[3] = {dx, dy, dz}, spec_colour[3] = {scx, scy, scz};
+    for (int k = 0; k < 3; ++k) {
+        const float diff = diffuse[k];
+        d.diffuse[k] = diff;
+        const float cd = diff + (0.0f - diff) * metallic;            // c_diff = lerp(diffuse, 0, metallic)
+        d.c_diff[k] = cd * kFrac1Pi;
+        const float ds = f0d * spec_colour[k] * specular_factor;
+        d.f0[k] = ds + (diff - ds) * metallic;                       // calculate_combined_f0
+        d.df[k] = d.f90 - d.f0[k];
+    }
+    d.rough_ior = rough * ior_clamp;                                 // PerceptualRoughness::apply_ior :157-159
+    // GGX LUT row (v = perceptual roughness; bilinear, clamp to edge)
+    const float fh = (float)lut_height;
+    float y = rough * fh - 0.5f;
+    y = fminf(fmaxf(y, -1.0f), fh);
+    const float fl = floorf(y);
+    d.lut_fy = y - fl;
+    const int a = (int)fl, mx = (int)lut_height - 1;
+    d.lut_row0 = (uint32_t)min(max(a, 0), mx) * lut_stride;
+    d.lut_row1 = (uint32_t)min(max(a + 1, 0), mx) * lut_stride;
+}
+
 // ------------------------------------------------------------------------ one pixel
 // Runs with exec = the lanes of the wave that share material `m` (scalar registers).
 // `lane` = lane id in the wave; `cluster_xy` = cluster x + cluster y * num_clusters.x of this pixel.
 //
-// WHOLE_WAVE: all 64 lanes are live and share `m`.  Then `prefetch()` — the loads of the block's NEXT tile —
-// is issued here, after this tile's own loads (light list, pyramid taps, LUT taps): vmcnt retires loads in
-// order, so an `s_waitcnt` for the taps issued after a prefetch would stall on the HBM latency of the
-// prefetch, while one issued before it (vmcnt(5)) leaves the prefetch in flight during the whole light
-// evaluation.  For the same reason the light loop of this path performs no vector load when every lane's
-// cluster holds at most four lights (its list then sits in registers).
-template <bool TRANSMISSIVE, bool WHOLE_WAVE, class Prefetch>
-__device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float4 ns, uint32_t lane,
-                                          uint32_t cluster_xy, Prefetch prefetch) {
+// MatP: `cdmat*` — the digested material in scalar registers (materials without textures), or
+// `const lane_dmat*` — per-lane values digested from the sampled textures; `ns.xyz` is then the normal after
+// normal mapping.
+template <bool TRANSMISSIVE, class MatP>
+__device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 ns, uint32_t lane,
+                                          uint32_t cluster_xy) {
+    constexpr bool SCALAR_MATERIAL = std::is_same<MatP, cdmat*>::value;
     // ================= phase 1: frame of the pixel, cluster list request, refraction taps =================
     L = launder(L);
     m = launder(m);
@@ -530,7 +565,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
         float tu = fmaf(cx, hw, 0.5f);
         float tv = fmaf(cy, hw, 0.5f);
         float lod = L->fp.log2_fb_width * m->rough_ior; // :334-335
-        if (!TR_ABLATE(L, 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod);
+        if (!TR_ABLATE(L, 1u)) pyramid_issue<SCALAR_MATERIAL>(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane);
         else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
         if (!TR_ABLATE(L, 2u)) lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, *m, nov_raw);
         else { lf.p0 = lf.p1 = 0x40404040u; lf.fx = nov_raw; }
@@ -541,9 +576,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
     // first pending lane evaluate it together, with the light read through the scalar unit.  When the lists
     // agree (the normal case, also across cluster boundaries) that is one pass per light.
     light_acc acc = {{0.f, 0.f, 0.f}, {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}};
-    auto lights_phase = [&](auto list_in_registers) {
+    auto lights_phase = [&]() {
         claunch* L2 = launder(L);
-        cdmat* m2 = launder(m);
+        MatP m2 = launder(m);
         {
             const v2f ra = pk_fma(splat(nov * nov), v2f{m2->oma2[0], m2->oma2[1]}, v2f{m2->a2[0], m2->a2[1]});
             px.g_nov = v2f{fast_sqrt(ra.x), TRANSMISSIVE ? fast_sqrt(ra.y) : 0.0f};
@@ -562,16 +597,10 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
             const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)head, l0);
             const uint64_t group = __ballot(i < num_lights && head == h0);
             if ((group >> lane) & 1ull) {  // membership from the mask keeps h0 scalar (see shade_kernel)
-                if constexpr (decltype(list_in_registers)::value) {
-                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px, transmits);
-                    ++i;
-                    head = i == 1u ? list4.y : (i == 2u ? list4.z : list4.w);
-                } else {
-                    const uint32_t next = indices[min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u)];  // in flight during the eval
-                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px, transmits);
-                    ++i;
-                    head = next;
-                }
+                const uint32_t next = indices[min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u)];  // in flight during the eval
+                eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px, transmits);
+                ++i;
+                head = next;
             }
             pending = __ballot(i < num_lights);
         }
@@ -579,7 +608,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
     // ================= phase 4: resolve the taps, composite =================
     auto finish = [&]() -> f3 {
         claunch* L4 = launder(L);
-        cdmat* m4 = launder(m);
+        MatP m4 = launder(m);
         f3 diffuse = {acc.d.x * m4->c_diff[0], acc.d.y * m4->c_diff[1], acc.d.z * m4->c_diff[2]};
 
         if (transmits) {
@@ -614,25 +643,117 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
         return out;
     };
 
-    // The two light-list variants run to the end of the pixel separately (phase 4 is instantiated in both):
-    // joining them before the taps are consumed would make the compiler's s_waitcnt for the taps conservative
-    // (vmcnt(0)), i.e. wait for the prefetch.
-    f3 out;
-    if constexpr (WHOLE_WAVE) {
-        if (__ballot(num_lights > 4u) == 0ull) {   // needs the light count only: the oldest load of this tile
-            prefetch();
-            lights_phase(std::true_type{});
-            out = finish();
-        } else {
-            prefetch();
-            lights_phase(std::false_type{});
-            out = finish();
-        }
-    } else {
-        lights_phase(std::false_type{});
-        out = finish();
+    lights_phase();
+    return finish();
+}
+
+// ------------------------------------------------------------------------ one pixel of a textured material
+// Differences inside the pixel's 2x2 quad of the two values the reference's shaders differentiate
+// (OpDPdx / OpDPdy): -view_vector (shader/src/lighting.rs:237) and uv (the implicit LOD of every texture fetch).
+struct quad_derivs {
+    f3 dp_dx, dp_dy;
+    uv_derivs uv;
+};
+
+// The front end of `fragment` / `fragment_transmission` for a material with texture slots (lib.rs:65-76, 120-124,
+// 190-194; lighting.rs:222-313): the (scalar) material record says which slots are bound, the taps of every bound
+// texture are issued together, then the sampled factors are digested per lane and the pixel continues through
+// the same shade_pixel as an untextured one.
+template <bool TRANSMISSIVE>
+__device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material, cdmat* dm, float4 pd, float4 ns,
+                                                   float2 uv, const quad_derivs& qd, uint32_t lane,
+                                                   uint32_t cluster_xy, const float* __restrict__ lds_srgb) {
+    L = launder(L);
+    dm = launder(dm);
+    const TR_CONSTANT tr_material_info* mi = as_constant(L->materials) + material;
+    cdtex* tex = as_constant(L->textures);
+    const uint32_t* __restrict__ arena = L->tex_arena;
+    const int32_t id_diffuse = mi->textures.diffuse, id_mr = mi->textures.metallic_roughness;
+    const int32_t id_normal = mi->textures.normal_map, id_emissive = mi->textures.emissive;
+    const int32_t id_transmission = TRANSMISSIVE ? mi->textures.transmission : -1;
+    const int32_t id_thickness = TRANSMISSIVE ? mi->textures.thickness : -1;
+    const int32_t id_specular = mi->textures.specular, id_spec_colour = mi->textures.specular_colour;
+
+    texture_fetch f_diffuse, f_mr, f_normal, f_emissive, f_transmission, f_thickness, f_specular, f_spec_colour;
+    if (id_diffuse != -1) texture_issue(f_diffuse, arena, tex + id_diffuse, uv.x, uv.y, qd.uv);
+    if (id_mr != -1) texture_issue(f_mr, arena, tex + id_mr, uv.x, uv.y, qd.uv);
+    if (id_normal != -1) texture_issue(f_normal, arena, tex + id_normal, uv.x, uv.y, qd.uv);
+    if (id_emissive != -1) texture_issue(f_emissive, arena, tex + id_emissive, uv.x, uv.y, qd.uv);
+    if (id_transmission != -1) texture_issue(f_transmission, arena, tex + id_transmission, uv.x, uv.y, qd.uv);
+    if (id_thickness != -1) texture_issue(f_thickness, arena, tex + id_thickness, uv.x, uv.y, qd.uv);
+    if (id_specular != -1) texture_issue(f_specular, arena, tex + id_specular, uv.x, uv.y, qd.uv);
+    if (id_spec_colour != -1) texture_issue(f_spec_colour, arena, tex + id_spec_colour, uv.x, uv.y, qd.uv);
+
+    lane_dmat lm;
+    // diffuse = diffuse_factor * sample (lib.rs:65-69)
+    float dr = mi->diffuse_factor[0], dg = mi->diffuse_factor[1], db = mi->diffuse_factor[2];
+    if (id_diffuse != -1) {
+        const bool srgb = tex[id_diffuse].srgb != 0u;
+        dr *= texture_resolve_channel<0>(f_diffuse, srgb, lds_srgb);
+        dg *= texture_resolve_channel<1>(f_diffuse, srgb, lds_srgb);
+        db *= texture_resolve_channel<2>(f_diffuse, srgb, lds_srgb);
     }
-    return out;
+    // get_material_params (lighting.rs:261-301)
+    float metallic = mi->metallic_factor, rough = mi->roughness_factor;
+    if (id_mr != -1) {
+        const bool srgb = tex[id_mr].srgb != 0u;
+        metallic *= texture_resolve_channel<2>(f_mr, srgb, lds_srgb);   // "These two are switched!"
+        rough *= texture_resolve_channel<1>(f_mr, srgb, lds_srgb);
+    }
+    float scx = mi->specular_colour_factor[0], scy = mi->specular_colour_factor[1], scz = mi->specular_colour_factor[2];
+    if (id_spec_colour != -1) {
+        const bool srgb = tex[id_spec_colour].srgb != 0u;
+        scx *= texture_resolve_channel<0>(f_spec_colour, srgb, lds_srgb);
+        scy *= texture_resolve_channel<1>(f_spec_colour, srgb, lds_srgb);
+        scz *= texture_resolve_channel<2>(f_spec_colour, srgb, lds_srgb);
+    }
+    float specular_factor = mi->specular_factor;
+    if (id_specular != -1) specular_factor *= texture_resolve_channel<3>(f_specular, tex[id_specular].srgb != 0u, lds_srgb);
+    digest_factors(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
+                   L->fp.lut_height, L->fp.lut_stride);
+    // get_emission (lighting.rs:303-313)
+    lm.emission[0] = mi->emissive_factor[0];
+    lm.emission[1] = mi->emissive_factor[1];
+    lm.emission[2] = mi->emissive_factor[2];
+    if (id_emissive != -1) {
+        const bool srgb = tex[id_emissive].srgb != 0u;
+        lm.emission[0] *= texture_resolve_channel<0>(f_emissive, srgb, lds_srgb);
+        lm.emission[1] *= texture_resolve_channel<1>(f_emissive, srgb, lds_srgb);
+        lm.emission[2] *= texture_resolve_channel<2>(f_emissive, srgb, lds_srgb);
+    }
+    lm.transmission_factor = mi->transmission_factor;               // lib.rs:71-77
+    if (id_transmission != -1)
+        lm.transmission_factor *= texture_resolve_channel<0>(f_transmission, tex[id_transmission].srgb != 0u, lds_srgb);
+    lm.thickness = mi->thickness_factor;                            // lib.rs:120-124
+    if (id_thickness != -1) lm.thickness *= texture_resolve_channel<1>(f_thickness, tex[id_thickness].srgb != 0u, lds_srgb);
+    lm.eta = dm->eta;
+    lm.neg_atten_log2[0] = dm->neg_atten_log2[0];
+    lm.neg_atten_log2[1] = dm->neg_atten_log2[1];
+    lm.neg_atten_log2[2] = dm->neg_atten_log2[2];
+    lm.flags = (dm->flags & 1u) | (lm.transmission_factor != 0.0f ? 2u : 0u);
+
+    // calculate_normal + compute_cotangent_frame (lighting.rs:222-259)
+    if (id_normal != -1) {
+        const float inv_n = rsq(dot3(ns.x, ns.y, ns.z, ns.x, ns.y, ns.z));
+        const f3 n = {ns.x * inv_n, ns.y * inv_n, ns.z * inv_n};
+        const bool srgb = tex[id_normal].srgb != 0u;
+        // map_normal * 255/127 - 128/127 (the compiled shader folds 255/127 into one multiply)
+        const float mx = fmaf(texture_resolve_channel<0>(f_normal, srgb, lds_srgb), 255.0f / 127.0f, -128.0f / 127.0f);
+        const float my = fmaf(texture_resolve_channel<1>(f_normal, srgb, lds_srgb), 255.0f / 127.0f, -128.0f / 127.0f);
+        const float mz = fmaf(texture_resolve_channel<2>(f_normal, srgb, lds_srgb), 255.0f / 127.0f, -128.0f / 127.0f);
+        auto cross = [](f3 a, f3 b) { return f3{fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y))}; };
+        const f3 dp2perp = cross(qd.dp_dy, n), dp1perp = cross(n, qd.dp_dx);
+        const f3 t = {fmaf(dp2perp.x, qd.uv.dudx, dp1perp.x * qd.uv.dudy), fmaf(dp2perp.y, qd.uv.dudx, dp1perp.y * qd.uv.dudy),
+                      fmaf(dp2perp.z, qd.uv.dudx, dp1perp.z * qd.uv.dudy)};
+        const f3 b = {fmaf(dp2perp.x, qd.uv.dvdx, dp1perp.x * qd.uv.dvdy), fmaf(dp2perp.y, qd.uv.dvdx, dp1perp.y * qd.uv.dvdy),
+                      fmaf(dp2perp.z, qd.uv.dvdx, dp1perp.z * qd.uv.dvdy)};
+        const float invmax = rsq(fmaxf(dot3(t.x, t.y, t.z, t.x, t.y, t.z), dot3(b.x, b.y, b.z, b.x, b.y, b.z)));
+        const float tx = mx * invmax, by_ = my * invmax;            // Mat3::from_cols(t * invmax, b * invmax, n) * map_normal
+        ns.x = fmaf(n.x, mz, fmaf(b.x, by_, t.x * tx));
+        ns.y = fmaf(n.y, mz, fmaf(b.y, by_, t.y * tx));
+        ns.z = fmaf(n.z, mz, fmaf(b.z, by_, t.z * tx));             // shade_pixel normalises
+    }
+    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd, ns, lane, cluster_xy);
 }
 
 // ------------------------------------------------------------------------ the shading kernel
@@ -642,15 +763,26 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, cdmat* m, float4 pd, float
 // window of the screen (and of the opaque pyramid behind it).  A wave is a 16x4 pixel tile — few
 // waves straddle a material or cluster border, every plane row segment is still >= one 128 B line —
 // and the G-buffer of the block's next tile is already in flight while the current one is shaded.
+//
+// TEXTURED (chosen by the host when an uploaded material has texture slots): additionally reads the uv plane,
+// forms the quad differences with two lane swizzles (the 16x4 wave tile holds whole 2x2 quads: partner lanes are
+// lane^1 and lane^16; the host guarantees an even rect origin) before the wave splits by material, and sends
+// materials flagged as textured through shade_pixel_textured.  The sRGB decode table sits in LDS.
 struct tile_regs {
     float4 pd, ns;
+    float2 uv;                                        // TEXTURED only
     uint32_t mat, cluster_x, cluster_y_term, px, py;  // (the two table values are only added when used)
 };
 
-template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */>
+template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, bool TEXTURED = false>
 __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_value) {
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
+    __shared__ float lds_srgb[TEXTURED ? 256 : 1];
+    if constexpr (TEXTURED) {
+        lds_srgb[threadIdx.x] = L->srgb_to_linear[threadIdx.x];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lx = wave * 16u + (lane & 15u), ly = lane >> 4;  // position inside the 64x4 block tile
@@ -683,6 +815,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         t.mat = F->material_id[gpix];
         t.pd = F->pos_depth[gpix];
         t.ns = F->nrm_scale[gpix];
+        if constexpr (TEXTURED) t.uv = F->uv[gpix];
         t.cluster_x = (uint32_t)F->cluster_x[cx];
         t.cluster_y_term = F->cluster_y_term[cy];
     };
@@ -706,6 +839,27 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         } else if (todo) {
             // One material at a time through the scalar unit; a wave that straddles k materials loops k times.
             fetch(jn, nxt);
+            quad_derivs qd;
+            if constexpr (TEXTURED) {
+                // dFdx = value(x|1) - value(x&~1), dFdy likewise, zero where the partner has no fragment (lanes
+                // clamped to the frame edge read the same pixel as their partner: zero as well)
+                const bool covered = cur.mat != TR_NOT_COVERED;
+                auto swz_x = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x041F)); };  // lane ^ 1
+                auto swz_y = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); };  // lane ^ 16
+                // (every swizzle is evaluated by the whole wave, outside any condition: a lane-crossing read under a
+                // short-circuit would run with the uncovered lanes switched off and read zeros from them)
+                const int mat_x = __builtin_amdgcn_ds_swizzle((int)cur.mat, 0x041F);
+                const int mat_y = __builtin_amdgcn_ds_swizzle((int)cur.mat, 0x401F);
+                const bool cov_x = covered & (mat_x != (int)TR_NOT_COVERED), cov_y = covered & (mat_y != (int)TR_NOT_COVERED);
+                const float sgn_x = (lane & 1u) ? -1.0f : 1.0f, sgn_y = (lane & 16u) ? -1.0f : 1.0f;
+                const float nvx = -(S->fp.view_position[0] - cur.pd.x), nvy = -(S->fp.view_position[1] - cur.pd.y),
+                            nvz = -(S->fp.view_position[2] - cur.pd.z);
+                auto ddx = [&](float v) { const float d = (swz_x(v) - v) * sgn_x; return cov_x ? d : 0.0f; };
+                auto ddy = [&](float v) { const float d = (swz_y(v) - v) * sgn_y; return cov_y ? d : 0.0f; };
+                qd.dp_dx = {ddx(nvx), ddx(nvy), ddx(nvz)};
+                qd.dp_dy = {ddy(nvx), ddy(nvy), ddy(nvz)};
+                qd.uv = {ddx(cur.uv.x), ddx(cur.uv.y), ddy(cur.uv.x), ddy(cur.uv.y)};
+            }
             while (todo) {
                 const int l0 = __ffsll((unsigned long long)todo) - 1;
                 const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)cur.mat, l0);
@@ -714,8 +868,17 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
                 // Membership is read back from the ballot mask, not from `mat == m0`: inside `if (mat == m0)`
                 // the optimiser substitutes the per-lane `mat` for the scalar `m0` and the table reads turn
                 // into per-lane vector loads.
-                if ((group >> lane) & 1ull)
-                    out = shade_pixel<TRANSMISSIVE, false>(L, dmats + m0, cur.pd, cur.ns, lane, cur.cluster_x + cur.cluster_y_term, [] {});
+                if ((group >> lane) & 1ull) {
+                    if constexpr (TEXTURED) {
+                        if (dmats[m0].flags & 4u)
+                            out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane,
+                                                                     cur.cluster_x + cur.cluster_y_term, lds_srgb);
+                        else
+                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cur.cluster_x + cur.cluster_y_term);
+                    } else {
+                        out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cur.cluster_x + cur.cluster_y_term);
+                    }
+                }
             }
         } else {
             fetch(jn, nxt);
@@ -748,49 +911,27 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
     if (i >= count) return;
     const tr_material_info mi = in[i];
     tr_dmat d;
-    const float metallic = mi.metallic_factor, rough = mi.roughness_factor, ior = mi.index_of_refraction;
+    const float ior = mi.index_of_refraction;
     const float root = (ior - 1.0f) / (ior + 1.0f);
-    const float f0d = root * root;                                   // to_dielectric_f0 :190-195
-    const float ior_clamp = fminf(fmaxf(ior * 2.0f - 2.0f, 0.0f), 1.0f);
-    const float alpha = rough * rough;
-    const float alpha_t = alpha * ior_clamp;                         // ActualRoughness::apply_ior :144-146
-    d.a2[0] = alpha * alpha;
-    d.a2[1] = alpha_t * alpha_t;
-    for (int k = 0; k < 2; ++k) {
-        d.oma2[k] = 1.0f - d.a2[k];
-        d.k[k] = d.a2[k] * (0.5f * kFrac1Pi);
-    }
-    d.f90 = mi.specular_factor + (1.0f - mi.specular_factor) * metallic;  // calculate_combined_f90
-    for (int k = 0; k < 3; ++k) {
-        float diff = mi.diffuse_factor[k];
-        d.diffuse[k] = diff;
-        float cd = diff + (0.0f - diff) * metallic;                  // c_diff = lerp(diffuse, 0, metallic)
-        d.c_diff[k] = cd * kFrac1Pi;
-        float ds = f0d * mi.specular_colour_factor[k] * mi.specular_factor;
-        d.f0[k] = ds + (diff - ds) * metallic;                       // calculate_combined_f0
-        d.df[k] = d.f90 - d.f0[k];
-        d.emission[k] = mi.emissive_factor[k];
-    }
+    d.f0_dielectric = root * root;                                   // to_dielectric_f0 :190-195
+    d.ior_clamp = fminf(fmaxf(ior * 2.0f - 2.0f, 0.0f), 1.0f);
+    digest_factors(d, mi.metallic_factor, mi.roughness_factor, d.ior_clamp, d.f0_dielectric, mi.specular_factor,
+                   mi.specular_colour_factor[0], mi.specular_colour_factor[1], mi.specular_colour_factor[2],
+                   mi.diffuse_factor[0], mi.diffuse_factor[1], mi.diffuse_factor[2], lut_height, lut_stride);
+    for (int k = 0; k < 3; ++k) d.emission[k] = mi.emissive_factor[k];
     d.eta = 1.0f / ior;
     d.transmission_factor = mi.transmission_factor;
     d.thickness = mi.thickness_factor;
-    d.rough_ior = rough * ior_clamp;                                 // PerceptualRoughness::apply_ior :157-159
     const bool has_atten = !(mi.attenuation_distance == __builtin_inff());
-    d.flags = (has_atten ? 1u : 0u) | (mi.transmission_factor != 0.0f ? 2u : 0u);
+    const tr_textures& t = mi.textures;
+    const bool textured = t.diffuse != -1 || t.metallic_roughness != -1 || t.normal_map != -1 || t.emissive != -1 ||
+                          t.transmission != -1 || t.thickness != -1 || t.specular != -1 || t.specular_colour != -1;
+    d.flags = (has_atten ? 1u : 0u) | (mi.transmission_factor != 0.0f ? 2u : 0u) | (textured ? 4u : 0u);
     for (int k = 0; k < 3; ++k) {
         float coeff = -logf(mi.attenuation_colour[k]) / mi.attenuation_distance;  // :284
         d.neg_atten_log2[k] = has_atten ? (-coeff) * kLog2e : 0.0f;
     }
-    // GGX LUT row (v = perceptual roughness; bilinear, clamp to edge)
-    float fh = (float)lut_height;
-    float y = rough * fh - 0.5f;
-    y = fminf(fmaxf(y, -1.0f), fh);
-    float fl = floorf(y);
-    d.lut_fy = y - fl;
-    int a = (int)fl, mx = (int)lut_height - 1;
-    d.lut_row0 = (uint32_t)min(max(a, 0), mx) * lut_stride;
-    d.lut_row1 = (uint32_t)min(max(a + 1, 0), mx) * lut_stride;
-    for (int k = 0; k < 7; ++k) d._pad[k] = 0u;
+    for (int k = 0; k < 5; ++k) d._pad[k] = 0u;
     out[i] = d;
 }
 

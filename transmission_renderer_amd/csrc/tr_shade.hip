@@ -27,6 +27,16 @@ struct tr_context {
     bool dmats_dirty = false;
     std::vector<tr_material_info> stage_materials;
 
+    bool any_textured = false;      // some material has a texture slot: the TEXTURED kernels are launched
+    int32_t max_texture_id = -1;    // largest texture id a material refers to
+
+    // material textures: one arena of RGBA8 mip chains + a descriptor table
+    uint32_t* d_tex_arena = nullptr;
+    tr_dtex* d_textures = nullptr;
+    uint32_t num_textures = 0;
+    std::vector<tr_dtex> h_textures;
+    tr_colour_tables* d_colour_tables = nullptr;
+
     // lights (as the shading kernels and as the cluster assignment read them)
     tr_dlight* d_lights = nullptr;
     tr_alight* d_alights = nullptr;
@@ -109,6 +119,39 @@ tr_status ensure_levels(tr_context* ctx, const tr_pyramid* p, hipStream_t stream
     ctx->h_levels_count = p->levels;
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_levels, &ctx->h_levels, sizeof(tr_level_table), hipMemcpyHostToDevice, stream));
     return TR_OK;
+}
+
+// The sRGB transfer functions of the Khronos data format specification (13.3), with the host's libm.
+inline float srgb_to_linear(uint32_t byte) {
+    const float x = (float)byte / 255.0f;
+    return x <= 0.04045f ? x / 12.92f : std::pow((x + 0.055f) / 1.055f, 2.4f);
+}
+inline uint32_t linear_to_srgb8(float x) {
+    if (!(x > 0.0f)) x = 0.0f;
+    if (x > 1.0f) x = 1.0f;
+    const float e = x <= 0.0031308f ? 12.92f * x : 1.055f * std::pow(x, 1.0f / 2.4f) - 0.055f;
+    return (uint32_t)(e * 255.0f + 0.5f);
+}
+
+// The decode tables and, for the encode, the smallest float that maps to each byte (found by bisection over the
+// bit patterns of [0, 1]: the encode is monotonic), so the device reproduces the host function with compares.
+void fill_colour_tables(tr_colour_tables* t) {
+    for (uint32_t b = 0; b < 256u; ++b) {
+        t->srgb_to_linear[b] = srgb_to_linear(b);
+        t->unorm[b] = (float)b / 255.0f;
+    }
+    t->srgb_threshold[0] = 0.0f;
+    for (uint32_t b = 1; b < 256u; ++b) {
+        uint32_t lo = 0u, hi = 0x3F800000u;   // bits of 0.0f .. 1.0f; invariant: enc(lo) < b <= enc(hi)
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            float f;
+            std::memcpy(&f, &mid, 4);
+            if (linear_to_srgb8(f) >= b) hi = mid;
+            else lo = mid;
+        }
+        std::memcpy(&t->srgb_threshold[b], &hi, 4);
+    }
 }
 
 // Rust `f32 as u32`: saturating, NaN -> 0
@@ -201,6 +244,7 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
 #endif
     fp->lut_width = ctx->lut_w;
     fp->lut_stride = ctx->lut_stride;
+    fp->lut_height = ctx->lut_h;
     return TR_OK;
 }
 
@@ -212,28 +256,38 @@ uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles) {
     return 8u * k;
 }
 
-struct host_tables {  // the table pointers of one launch (plain global pointers on the host side)
-    const tr_dmat* dmats;
-    const tr_dlight* lights;
-    const uint32_t* cluster_counts;
-    const uint32_t* light_indices;
-    const uint32_t* lut_pairs;
-    const tr_level_table* levels;
-    const uint16_t* cluster_x;
-    const uint32_t* cluster_y_term;
-};
+// Passes that shade textured materials differentiate inside 2x2 pixel quads: the rect must hold whole quads.
+tr_status check_textured_launch(const tr_context* ctx, const tr_gbuffer* g, const tr_frame_params& fp) {
+    if (!ctx->any_textured) return TR_OK;
+    if (!g->uv) return TR_ERR_INVALID_ARGUMENT;
+    if (ctx->max_texture_id >= (int32_t)ctx->num_textures) return TR_ERR_INVALID_ARGUMENT;
+    if ((fp.rect_x0 & 1u) || (fp.rect_y0 & 1u)) return TR_ERR_INVALID_ARGUMENT;
+    if (((fp.rect_x1 & 1u) && fp.rect_x1 != fp.width) || ((fp.rect_y1 & 1u) && fp.rect_y1 != fp.height))
+        return TR_ERR_INVALID_ARGUMENT;
+    return TR_OK;
+}
 
-host_tables make_tables(const tr_context* ctx) {
-    host_tables tb;
-    tb.dmats = ctx->d_dmats;
-    tb.lights = ctx->d_lights;
-    tb.cluster_counts = ctx->d_cluster_counts;
-    tb.light_indices = ctx->d_light_indices;
-    tb.lut_pairs = ctx->d_lut_pairs;
-    tb.levels = ctx->d_levels;
-    tb.cluster_x = ctx->d_cluster_x;
-    tb.cluster_y_term = ctx->d_cluster_y_term;
-    return tb;
+void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp, const tr_gbuffer* g) {
+    L.fp = fp;
+    L.dmats = ctx->d_dmats;
+    L.lights = ctx->d_lights;
+    L.cluster_counts = ctx->d_cluster_counts;
+    L.light_indices = ctx->d_light_indices;
+    L.lut_pairs = ctx->d_lut_pairs;
+    L.levels = ctx->d_levels;
+    L.cluster_x = ctx->d_cluster_x;
+    L.cluster_y_term = ctx->d_cluster_y_term;
+    L.pos_depth = (const float4*)g->pos_depth;
+    L.nrm_scale = (const float4*)g->nrm_scale;
+    L.material_id = (const uint32_t*)g->material_id;
+    L.pyramid = nullptr;
+    L.hdr = nullptr;
+    L.mip0 = nullptr;
+    L.uv = (const float2*)g->uv;
+    L.materials = ctx->d_materials_raw;
+    L.textures = ctx->d_textures;
+    L.tex_arena = ctx->d_tex_arena;
+    L.srgb_to_linear = ctx->d_colour_tables ? ctx->d_colour_tables->srgb_to_linear : nullptr;
 }
 
 bool tables_ready(const tr_context* ctx, bool need_lut) {
@@ -284,9 +338,21 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
             ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * 2u;
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
     }
-    if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_colour_tables, sizeof(tr_colour_tables)) != hipSuccess) {
+        (void)hipFree(ctx->d_levels);
         delete ctx;
         return TR_ERR_OUT_OF_MEMORY;
+    }
+    {
+        tr_colour_tables tables;
+        fill_colour_tables(&tables);
+        if (hipMemcpy(ctx->d_colour_tables, &tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(ctx->d_levels);
+            (void)hipFree(ctx->d_colour_tables);
+            delete ctx;
+            return TR_ERR_NO_DEVICE;
+        }
     }
     *out_ctx = ctx;
     return TR_OK;
@@ -305,6 +371,9 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_levels);
     (void)hipFree(ctx->d_cluster_x);
     (void)hipFree(ctx->d_cluster_y_term);
+    (void)hipFree(ctx->d_tex_arena);
+    (void)hipFree(ctx->d_textures);
+    (void)hipFree(ctx->d_colour_tables);
     delete ctx;
     return TR_OK;
 }
@@ -333,13 +402,21 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
     if (!ctx || !materials_host || count == 0) return TR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
+    bool any_textured = false;
+    int32_t max_id = -1;
     for (uint32_t i = 0; i < count; ++i) {
         const tr_textures& t = materials_host[i].textures;
-        // Material textures (shader/src/lighting.rs:222-313 with ids != -1) are not on this build's path yet.
-        if (t.diffuse != -1 || t.metallic_roughness != -1 || t.normal_map != -1 || t.emissive != -1 ||
-            t.transmission != -1 || t.thickness != -1 || t.specular != -1 || t.specular_colour != -1)
-            return TR_ERR_UNSUPPORTED;
+        // the slots the shaders read (shader/src/lib.rs:65-76, 120-124; lighting.rs:222-313); occlusion is never sampled
+        const int32_t ids[8] = {t.diffuse, t.metallic_roughness, t.normal_map, t.emissive,
+                                t.transmission, t.thickness, t.specular, t.specular_colour};
+        for (int32_t id : ids) {
+            if (id < -1) return TR_ERR_INVALID_ARGUMENT;
+            if (id != -1) any_textured = true;
+            if (id > max_id) max_id = id;
+        }
     }
+    ctx->any_textured = any_textured;
+    ctx->max_texture_id = max_id;
     if (count > ctx->cap_materials) {
         (void)hipFree(ctx->d_materials_raw);
         (void)hipFree(ctx->d_dmats);
@@ -443,6 +520,99 @@ tr_status tr_upload_ggx_lut(tr_context* ctx, const uint8_t* rgba8_host, uint32_t
     return TR_OK;
 }
 
+tr_status tr_upload_textures(tr_context* ctx, const tr_texture_desc* textures_host, uint32_t count, void* stream_) {
+    if (!ctx || (!textures_host && count)) return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<tr_dtex> table(count);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        const tr_texture_desc& d = textures_host[i];
+        if (!d.rgba8 || d.width == 0 || d.height == 0) return TR_ERR_INVALID_ARGUMENT;
+        tr_dtex& t = table[i];
+        std::memset(&t, 0, sizeof(t));
+        t.width = d.width;
+        t.height = d.height;
+        t.srgb = d.srgb ? 1u : 0u;
+        t.levels = mip_levels_for_size(d.width, d.height);           // src/model_loading.rs:354
+        if (t.levels > TR_MAX_MIP_LEVELS) t.levels = TR_MAX_MIP_LEVELS;
+        t.wf = (float)d.width;
+        t.hf = (float)d.height;
+        t.max_lod = (float)(t.levels - 1u);
+        total = (total + 63u) & ~63ull;                              // chains start on 256-byte boundaries
+        for (uint32_t l = 0; l < TR_MAX_MIP_LEVELS + 4u; ++l) {
+            if (l < t.levels) {
+                t.offset[l] = (uint32_t)total;
+                total += (uint64_t)level_dim(d.width, l) * level_dim(d.height, l);
+            } else {
+                t.offset[l] = t.offset[t.levels - 1u];
+            }
+        }
+        if (total > 0xFFFFFFFFull) return TR_ERR_UNSUPPORTED;
+    }
+    // the previous array may still be read by work in flight on another stream
+    TR_HIP(ctx, hipDeviceSynchronize());
+    (void)hipFree(ctx->d_tex_arena);
+    (void)hipFree(ctx->d_textures);
+    ctx->d_tex_arena = nullptr;
+    ctx->d_textures = nullptr;
+    ctx->num_textures = 0;
+    ctx->h_textures.clear();
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_tex_arena, (size_t)total * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_textures, sizeof(tr_dtex) * count));
+    for (uint32_t i = 0; i < count; ++i) {
+        const tr_dtex& t = table[i];
+        TR_HIP(ctx, hipMemcpyAsync(ctx->d_tex_arena + t.offset[0], textures_host[i].rgba8, (size_t)t.width * t.height * 4u,
+                                   hipMemcpyHostToDevice, stream));
+        for (uint32_t l = 1; l < t.levels; ++l) {
+            const uint32_t ws = level_dim(t.width, l - 1), hs = level_dim(t.height, l - 1);
+            const uint32_t wd = level_dim(t.width, l), hd = level_dim(t.height, l);
+            hipLaunchKernelGGL(texture_downsample_kernel, dim3((wd + 63u) / 64u, (hd + 3u) / 4u), dim3(256), 0, stream,
+                               (const uint32_t*)(ctx->d_tex_arena + t.offset[l - 1]), ctx->d_tex_arena + t.offset[l], ws, hs,
+                               wd, hd, t.srgb, (const tr_colour_tables*)ctx->d_colour_tables);
+        }
+    }
+    TR_HIP(ctx, hipGetLastError());
+    ctx->h_textures = table;
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_textures, ctx->h_textures.data(), sizeof(tr_dtex) * count, hipMemcpyHostToDevice,
+                               stream));
+    // the host images are caller memory: do not return before the copies have read them
+    TR_HIP(ctx, hipStreamSynchronize(stream));
+    ctx->num_textures = count;
+    return TR_OK;
+}
+
+tr_status tr_texture_get_layout(const tr_context* ctx, uint32_t index, tr_texture_layout* out) {
+    if (!ctx || !out || index >= ctx->num_textures) return TR_ERR_INVALID_ARGUMENT;
+    const tr_dtex& t = ctx->h_textures[index];
+    std::memset(out, 0, sizeof(*out));
+    out->width = t.width;
+    out->height = t.height;
+    out->levels = t.levels;
+    out->srgb = t.srgb;
+    uint32_t total = 0;
+    for (uint32_t l = 0; l < t.levels; ++l) {
+        out->level_offset[l] = t.offset[l] - t.offset[0];
+        total += level_dim(t.width, l) * level_dim(t.height, l);
+    }
+    out->total_texels = total;
+    return TR_OK;
+}
+
+tr_status tr_download_texture(tr_context* ctx, uint32_t index, void* rgba8_host_out, size_t capacity_bytes, void* stream_) {
+    if (!ctx || !rgba8_host_out || index >= ctx->num_textures) return TR_ERR_INVALID_ARGUMENT;
+    tr_texture_layout lay;
+    tr_status st = tr_texture_get_layout(ctx, index, &lay);
+    if (st != TR_OK) return st;
+    if (capacity_bytes < (size_t)lay.total_texels * 4u) return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    TR_HIP(ctx, hipMemcpyAsync(rgba8_host_out, ctx->d_tex_arena + ctx->h_textures[index].offset[0],
+                               (size_t)lay.total_texels * 4u, hipMemcpyDeviceToHost, stream));
+    TR_HIP(ctx, hipStreamSynchronize(stream));
+    return TR_OK;
+}
 
 tr_status tr_write_cluster_data(tr_context* ctx, const tr_uniforms* u, const float inverse_perspective[16],
                                 const uint32_t screen_dimensions[2], void* cluster_aabbs_out, void* stream_) {
@@ -506,19 +676,23 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     if (st != TR_OK) return st;
     st = ensure_cluster_tables(ctx, u, fp.width, fp.height, stream);
     if (st != TR_OK) return st;
+    st = check_textured_launch(ctx, g, fp);
+    if (st != TR_OK) return st;
     fp.pyr_levels = 1;
-    const host_tables tb = make_tables(ctx);
     const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y)), block(256);
     {
         tr_launch L;
-        L.fp = fp;
-        L.dmats = tb.dmats; L.lights = tb.lights; L.cluster_counts = tb.cluster_counts; L.light_indices = tb.light_indices;
-        L.lut_pairs = tb.lut_pairs; L.levels = tb.levels; L.cluster_x = tb.cluster_x; L.cluster_y_term = tb.cluster_y_term;
-        L.pos_depth = (const float4*)g->pos_depth; L.nrm_scale = (const float4*)g->nrm_scale;
-        L.material_id = (const uint32_t*)g->material_id; L.pyramid = (const uint2*)nullptr;
-        L.hdr = hdr_out; L.mip0 = (uint2*)opaque_mip0_out;
-        if (format == TR_FORMAT_RGBA16F) hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, L);
-        else hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, L);
+        fill_launch(L, ctx, fp, g);
+        L.hdr = hdr_out;
+        L.mip0 = (uint2*)opaque_mip0_out;
+        const bool half = format == TR_FORMAT_RGBA16F;
+        if (ctx->any_textured) {
+            if (half) hipLaunchKernelGGL((shade_kernel<false, uint2, true>), grid, block, 0, stream, L);
+            else hipLaunchKernelGGL((shade_kernel<false, float4, true>), grid, block, 0, stream, L);
+        } else {
+            if (half) hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, L);
+            else hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, L);
+        }
     }
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
@@ -602,19 +776,23 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     if (st != TR_OK) return st;
     st = ensure_cluster_tables(ctx, u, fp.width, fp.height, stream);
     if (st != TR_OK) return st;
+    st = check_textured_launch(ctx, g, fp);
+    if (st != TR_OK) return st;
     fp.pyr_levels = p->levels;
-    const host_tables tb = make_tables(ctx);
     const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y)), block(256);
     {
         tr_launch L;
-        L.fp = fp;
-        L.dmats = tb.dmats; L.lights = tb.lights; L.cluster_counts = tb.cluster_counts; L.light_indices = tb.light_indices;
-        L.lut_pairs = tb.lut_pairs; L.levels = tb.levels; L.cluster_x = tb.cluster_x; L.cluster_y_term = tb.cluster_y_term;
-        L.pos_depth = (const float4*)g->pos_depth; L.nrm_scale = (const float4*)g->nrm_scale;
-        L.material_id = (const uint32_t*)g->material_id; L.pyramid = (const uint2*)p->texels;
-        L.hdr = hdr_inout; L.mip0 = (uint2*)nullptr;
-        if (format == TR_FORMAT_RGBA16F) hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, L);
-        else hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, L);
+        fill_launch(L, ctx, fp, g);
+        L.pyramid = (const uint2*)p->texels;
+        L.hdr = hdr_inout;
+        const bool half = format == TR_FORMAT_RGBA16F;
+        if (ctx->any_textured) {
+            if (half) hipLaunchKernelGGL((shade_kernel<true, uint2, true>), grid, block, 0, stream, L);
+            else hipLaunchKernelGGL((shade_kernel<true, float4, true>), grid, block, 0, stream, L);
+        } else {
+            if (half) hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, L);
+            else hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, L);
+        }
     }
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;

@@ -137,6 +137,32 @@ class TransmissionRenderer:
         self._check(self.lib.tr_set_cluster_tables(self._ctx, counts.data_ptr(), indices.data_ptr(), counts.numel()),
                     "tr_set_cluster_tables")
 
+    def upload_textures(self, textures: Sequence):
+        """The bindless material textures (src/model_loading.rs:160-215): [(HxWx4 uint8 image, srgb), ...]; the
+        index of an entry is the texture id materials refer to.  Mip chains are generated on the device."""
+        imgs = [np.ascontiguousarray(img, dtype=np.uint8) for img, _ in textures]
+        for img in imgs:
+            assert img.ndim == 3 and img.shape[2] == 4
+        descs = (wire.TextureDesc * max(len(imgs), 1))()
+        for i, (img, (_, srgb)) in enumerate(zip(imgs, textures)):
+            descs[i] = wire.TextureDesc(img.ctypes.data, img.shape[1], img.shape[0], 1 if srgb else 0, 0)
+        self._check(self.lib.tr_upload_textures(self._ctx, descs if imgs else None, len(imgs), self._stream()),
+                    "tr_upload_textures")
+
+    def download_texture(self, index: int):
+        """(layout, [level arrays]) of texture `index` as it sits in HBM, mip chain included."""
+        lay = wire.TextureLayout()
+        self._check(self.lib.tr_texture_get_layout(self._ctx, index, C.byref(lay)), "tr_texture_get_layout")
+        buf = np.zeros((int(lay.total_texels), 4), dtype=np.uint8)
+        self._check(self.lib.tr_download_texture(self._ctx, index, buf.ctypes.data, buf.nbytes, self._stream()),
+                    "tr_download_texture")
+        levels = []
+        for l in range(int(lay.levels)):
+            w, h = max(int(lay.width) >> l, 1), max(int(lay.height) >> l, 1)
+            off = int(lay.level_offset[l])
+            levels.append(buf[off:off + w * h].reshape(h, w, 4))
+        return lay, levels
+
     def upload_ggx_lut(self, rgba8: Optional[np.ndarray] = None):
         if rgba8 is None:
             rgba8 = load_ggx_lut()

@@ -23,7 +23,9 @@ import torch.distributed as dist
 
 
 def band_rows(height: int, world: int, rank: int) -> Tuple[int, int]:
-    """Rows [y0, y1) of `rank`.  Equal bands (height must divide): in-place all-gather needs equal counts."""
+    """Rows [y0, y1) of `rank`.  Equal bands (height must divide): in-place all-gather needs equal counts.
+    With textured materials a band must also hold whole 2x2 pixel quads (height / world even): the shading
+    entry points refuse a rect that cuts quads (include/tr_shade.h tr_upload_textures)."""
     if height % world:
         raise ValueError(f"frame height {height} is not a multiple of world size {world}")
     rows = height // world

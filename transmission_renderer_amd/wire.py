@@ -203,6 +203,27 @@ class Pyramid(C.Structure):  # include/tr_shade.h tr_pyramid
     ]
 
 
+class TextureDesc(C.Structure):  # include/tr_shade.h tr_texture_desc
+    _fields_ = [
+        ("rgba8", C.c_void_p),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("srgb", C.c_uint32),
+        ("_reserved", C.c_uint32),
+    ]
+
+
+class TextureLayout(C.Structure):  # include/tr_shade.h tr_texture_layout
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("levels", C.c_uint32),
+        ("srgb", C.c_uint32),
+        ("level_offset", C.c_uint32 * MAX_MIP_LEVELS),
+        ("total_texels", C.c_uint32),
+    ]
+
+
 assert C.sizeof(PushConstants) == 96
 assert C.sizeof(Uniforms) == 96 and Uniforms.sun_dir.offset == 32 and Uniforms.ggx_lut_texture_index.offset == 84
 assert C.sizeof(MaterialInfo) == 160 and MaterialInfo.attenuation_colour.offset == 112
