@@ -129,6 +129,46 @@ typedef struct tr_cluster_aabb {
     float _pad1;
 } tr_cluster_aabb;
 
+/* ---- geometry and draw records (GPU culling architecture, shared-structs/src/lib.rs:238-281) ---- */
+
+/* `Instance` (stride 48 B): PackedSimilarity{translation.xyz, scale; rotation quaternion xyzw}, ids. */
+typedef struct tr_instance {
+    float translation_and_scale[4];  /* @0  */
+    float rotation[4];               /* @16 (x, y, z, w) */
+    uint32_t primitive_id;           /* @32 */
+    uint32_t material_id;            /* @36 */
+    uint32_t _pad[2];
+} tr_instance;
+
+/* `PrimitiveInfo` (stride 32 B): one per drawable primitive; doubles as the draw description. */
+typedef struct tr_primitive_info {
+    float packed_bounding_sphere[4]; /* @0  centre xyz (model space), radius */
+    uint32_t draw_buffer_index;      /* @16 0 opaque, 1 alpha clip, 2 transmission, 3 transmission + alpha clip */
+    uint32_t index_count;            /* @20 */
+    uint32_t first_index;            /* @24 */
+    uint32_t first_instance;         /* @28 */
+} tr_primitive_info;
+
+/* `CullingPushConstants` (shared-structs/src/lib.rs:270-279; filled at src/main.rs:1728-1746). */
+typedef struct tr_culling_push_constants {
+    float view[16];                  /* @0  column-major view matrix */
+    float frustum_x_xz[2];           /* @64 */
+    float frustum_y_yz[2];           /* @72 */
+    float z_near;                    /* @80 */
+    float _pad[3];
+} tr_culling_push_constants;
+
+/* VkDrawIndexedIndirectCommand as demultiplex_draws writes it (shader/src/lib.rs:401-409; 20 B). */
+typedef struct tr_draw_command {
+    uint32_t index_count;
+    uint32_t instance_count;
+    uint32_t first_index;
+    int32_t  vertex_offset;
+    uint32_t first_instance;
+} tr_draw_command;
+
+#define TR_NUM_DRAW_BUFFERS 4u   /* shader/src/lib.rs:467 */
+
 /* shared-structs/src/lib.rs:322 */
 #define TR_MAX_LIGHTS_PER_CLUSTER 128u
 #define TR_MAX_DEPTH_SLICES 64u   /* src/main.rs:62 uses 16 */
@@ -270,6 +310,28 @@ tr_status tr_upload_textures(tr_context* ctx, const tr_texture_desc* textures_ho
 tr_status tr_texture_get_layout(const tr_context* ctx, uint32_t index, tr_texture_layout* out);
 tr_status tr_download_texture(tr_context* ctx, uint32_t index, void* rgba8_host_out, size_t capacity_bytes, void* stream);
 
+/* ------------------------------------------------------- frustum culling */
+
+/*
+ * `frustum_culling` (shader/src/lib.rs:411-465; dispatched at src/main.rs:1716-1763 after the count buffer is
+ * zeroed, :1668-1674): instance_counts[p] = number of instances of primitive p whose transformed bounding sphere
+ * is inside the view frustum.  All pointers are device pointers; instance_counts (num_primitives u32) is zeroed
+ * by this call.
+ */
+tr_status tr_frustum_culling(tr_context* ctx, const void* primitives, uint32_t num_primitives, const void* instances,
+                             uint32_t num_instances, const tr_culling_push_constants* push, void* instance_counts,
+                             void* stream);
+
+/*
+ * `demultiplex_draws` (shader/src/lib.rs:469-517; src/main.rs:1811-1838): one tr_draw_command per primitive with
+ * a non-zero instance count, appended to the draw buffer its draw_buffer_index names.  draw_counts: 4 u32
+ * (zeroed by this call); draws[k]: device arrays with room for every primitive of that kind.  The reference
+ * appends in atomic (arbitrary) order; here commands come out in ascending primitive order (deterministic).
+ */
+tr_status tr_demultiplex_draws(tr_context* ctx, const void* primitives, uint32_t num_primitives,
+                               const void* instance_counts, void* draw_counts, void* const draws[TR_NUM_DRAW_BUFFERS],
+                               void* stream);
+
 /* ------------------------------------------------------- clustered-light build */
 
 /*
@@ -361,6 +423,10 @@ TR_STATIC_ASSERT(offsetof(tr_material_info, attenuation_distance) == 100, "atten
 TR_STATIC_ASSERT(offsetof(tr_material_info, attenuation_colour) == 112, "attenuation_colour @112");
 TR_STATIC_ASSERT(offsetof(tr_material_info, specular_factor) == 128, "specular_factor @128");
 TR_STATIC_ASSERT(offsetof(tr_material_info, specular_colour_factor) == 144, "specular_colour_factor @144");
+TR_STATIC_ASSERT(sizeof(tr_instance) == 48 && offsetof(tr_instance, primitive_id) == 32, "Instance stride is 48 B");
+TR_STATIC_ASSERT(sizeof(tr_primitive_info) == 32 && offsetof(tr_primitive_info, draw_buffer_index) == 16, "PrimitiveInfo is 32 B");
+TR_STATIC_ASSERT(offsetof(tr_culling_push_constants, frustum_x_xz) == 64 && offsetof(tr_culling_push_constants, z_near) == 80, "CullingPushConstants");
+TR_STATIC_ASSERT(sizeof(tr_draw_command) == 20, "VkDrawIndexedIndirectCommand is 20 B");
 TR_STATIC_ASSERT(sizeof(tr_light) == 48, "Light stride is 48 B");
 TR_STATIC_ASSERT(sizeof(tr_cluster_aabb) == 32, "ClusterAabb is 32 B");
 

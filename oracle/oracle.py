@@ -147,6 +147,12 @@ def load() -> C.CDLL:
     lib.o_write_cluster_data.argtypes = [C.POINTER(wire.Uniforms), C.POINTER(f * 16), C.POINTER(u32 * 2), u32, vp]
     lib.o_assign_lights_to_clusters.restype = None
     lib.o_assign_lights_to_clusters.argtypes = [vp, u32, vp, u32, C.POINTER(f * 16), C.POINTER(f * 4), vp, vp]
+    lib.o_frustum_culling.restype = None
+    lib.o_frustum_culling.argtypes = [vp, u32, vp, u32, C.POINTER(wire.CullingPushConstants), vp]
+    lib.o_demultiplex_draws.restype = None
+    lib.o_demultiplex_draws.argtypes = [vp, u32, vp, C.POINTER(u32 * 4), C.POINTER(vp * 4)]
+    lib.o_culling_push_constants.restype = None
+    lib.o_culling_push_constants.argtypes = [C.POINTER(f * 16), C.POINTER(f * 16), f, C.POINTER(wire.CullingPushConstants)]
     lib.o_tonemap_frame.restype = None
     lib.o_tonemap_frame.argtypes = [vp, u32, C.POINTER(wire.TonemapParams), vp, vp]
     _bind_passes(lib)
@@ -328,3 +334,32 @@ def tonemap_frame(hdr_f16: np.ndarray, params: wire.TonemapParams):
     lin = np.zeros(hdr_f16.shape[:2] + (3,), dtype=np.float32)
     load().o_tonemap_frame(_ptr(hdr_f16), n, C.byref(params), _ptr(rgba8), _ptr(lin))
     return rgba8, lin
+
+
+def culling_push_constants(perspective: np.ndarray, view: np.ndarray, z_near=wire.Z_NEAR) -> wire.CullingPushConstants:
+    """src/main.rs:1726-1746 ([column][row] float32 matrices)."""
+    out = wire.CullingPushConstants()
+    P = (C.c_float * 16)(*np.asarray(perspective, dtype=np.float32).reshape(-1))
+    V = (C.c_float * 16)(*np.asarray(view, dtype=np.float32).reshape(-1))
+    load().o_culling_push_constants(C.byref(P), C.byref(V), float(z_near), C.byref(out))
+    return out
+
+
+def frustum_culling(primitives: np.ndarray, instances: np.ndarray, push: wire.CullingPushConstants) -> np.ndarray:
+    primitives = np.ascontiguousarray(primitives, dtype=wire.PRIMITIVE_DTYPE)
+    instances = np.ascontiguousarray(instances, dtype=wire.INSTANCE_DTYPE)
+    counts = np.zeros(len(primitives), dtype=np.uint32)
+    load().o_frustum_culling(_ptr(primitives), len(primitives), _ptr(instances), len(instances), C.byref(push), _ptr(counts))
+    return counts
+
+
+def demultiplex_draws(primitives: np.ndarray, instance_counts: np.ndarray):
+    """(draw_counts[4], [draw command arrays x 4]) in ascending primitive order."""
+    primitives = np.ascontiguousarray(primitives, dtype=wire.PRIMITIVE_DTYPE)
+    instance_counts = np.ascontiguousarray(instance_counts, dtype=np.uint32)
+    n = len(primitives)
+    draws = [np.zeros(max(n, 1), dtype=wire.DRAW_COMMAND_DTYPE) for _ in range(4)]
+    ptrs = (C.c_void_p * 4)(*[d.ctypes.data for d in draws])
+    counts = (C.c_uint32 * 4)()
+    load().o_demultiplex_draws(_ptr(primitives), n, _ptr(instance_counts), C.byref(counts), C.byref(ptrs))
+    return np.array(list(counts), dtype=np.uint32), [d[:counts[k]].copy() for k, d in enumerate(draws)]

@@ -36,14 +36,14 @@ OP = dict(
     ImageSampleImplicitLod=87, ImageSampleExplicitLod=88, ConvertFToU=109, ConvertFToS=110, ConvertSToF=111,
     ConvertUToF=112, Bitcast=124, SNegate=126, FNegate=127, IAdd=128, FAdd=129, ISub=130, FSub=131, IMul=132,
     FMul=133, UDiv=134, SDiv=135, FDiv=136, UMod=137, VectorTimesScalar=142, MatrixTimesVector=145, Dot=148,
-    LogicalOr=166, LogicalAnd=167, LogicalNot=168, Select=169, IEqual=170, INotEqual=171, UGreaterThan=172,
+    LogicalEqual=164, LogicalNotEqual=165, LogicalOr=166, LogicalAnd=167, LogicalNot=168, Select=169, IEqual=170, INotEqual=171, UGreaterThan=172,
     SGreaterThan=173, UGreaterThanEqual=174, SGreaterThanEqual=175, ULessThan=176, SLessThan=177,
     ULessThanEqual=178, SLessThanEqual=179, FOrdEqual=180, FUnordEqual=181, FOrdNotEqual=182, FUnordNotEqual=183,
     FOrdLessThan=184, FUnordLessThan=185, FOrdGreaterThan=186, FUnordGreaterThan=187, FOrdLessThanEqual=188,
     FUnordLessThanEqual=189, FOrdGreaterThanEqual=190, FUnordGreaterThanEqual=191, ShiftRightLogical=194,
     ShiftLeftLogical=196, BitwiseOr=197, BitwiseXor=198, BitwiseAnd=199, Not=200, DPdx=207, DPdy=208,
     AtomicIIncrement=232, AtomicIAdd=234, Phi=245, LoopMerge=246, SelectionMerge=247, Label=248, Branch=249,
-    BranchConditional=250, Kill=252, Return=253, ReturnValue=254, Unreachable=255, IsNan=156, IsInf=157,
+    BranchConditional=250, Switch=251, Kill=252, Return=253, ReturnValue=254, Unreachable=255, IsNan=156, IsInf=157,
 )
 DEC = dict(Block=2, BufferBlock=3, ArrayStride=6, MatrixStride=7, BuiltIn=11, Flat=14, Location=30, Binding=33,
            DescriptorSet=34, Offset=35)
@@ -437,6 +437,14 @@ class Interp:
                 pc = labels[a[0]]
             elif op == OP["BranchConditional"]:
                 pc = labels[a[1] if bool(val(a[0])) else a[2]]
+            elif op == OP["Switch"]:   # selector, default, (literal, label)*  (32-bit selectors)
+                sel = int(val(a[0])) & 0xFFFFFFFF
+                target = a[1]
+                for k in range(2, len(a), 2):
+                    if (a[k] & 0xFFFFFFFF) == sel:
+                        target = a[k + 1]
+                        break
+                pc = labels[target]
             elif op == OP["Return"]:
                 return None
             elif op == OP["ReturnValue"]:
@@ -570,6 +578,10 @@ class Interp:
                 R[a[1]] = bool(val(a[2])) and bool(val(a[3]))
             elif op == OP["LogicalNot"]:
                 R[a[1]] = not bool(val(a[2]))
+            elif op == OP["LogicalEqual"]:
+                R[a[1]] = bool(val(a[2])) == bool(val(a[3]))
+            elif op == OP["LogicalNotEqual"]:
+                R[a[1]] = bool(val(a[2])) != bool(val(a[3]))
             elif op in (OP["IEqual"], OP["INotEqual"]):
                 eq = int(val(a[2])) & 0xFFFFFFFF == int(val(a[3])) & 0xFFFFFFFF
                 R[a[1]] = eq if op == OP["IEqual"] else not eq

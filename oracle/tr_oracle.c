@@ -28,6 +28,7 @@
 #define R_COS cos
 #define R_SIN sin
 #define R_TAN tan
+#define R_ABS fabs
 #else
 #define R(x) x##f
 #define R_SQRT sqrtf
@@ -39,6 +40,7 @@
 #define R_MAX fmaxf
 #define R_MIN fminf
 #define R_COS cosf
+#define R_ABS fabsf
 #define R_SIN sinf
 #define R_TAN tanf
 #endif
@@ -645,6 +647,73 @@ void o_assign_lights_to_clusters(const tr_light* lights, uint32_t num_lights, co
             if (off < TR_MAX_LIGHTS_PER_CLUSTER) indices[(size_t)c * TR_MAX_LIGHTS_PER_CLUSTER + off] = l;
         }
     }
+}
+
+
+/* ------------------------------------------------- frustum culling + demultiplex */
+
+/* `Similarity * Vec3` (shared-structs/src/lib.rs:233-236): translation + (scale * (rotation * vector)) */
+o_vec3 o_similarity_mul_vec3(const tr_instance* inst, o_vec3 v) {
+    real q[4] = {inst->rotation[0], inst->rotation[1], inst->rotation[2], inst->rotation[3]};
+    o_vec3 r = quat_mul_vec3(q, v);
+    return v3_add(f3(inst->translation_and_scale), v3_scale(r, (real)inst->translation_and_scale[3]));
+}
+
+/* shader/src/lib.rs:438-465 `cull` */
+int o_cull(const float packed_bounding_sphere[4], const tr_instance* inst, const tr_culling_push_constants* pc) {
+    o_vec3 center = o_similarity_mul_vec3(inst, f3(packed_bounding_sphere));
+    real vm[16], c4[4] = {center.x, center.y, center.z, R(1.0)}, v[4];
+    for (int k = 0; k < 16; ++k) vm[k] = (real)pc->view[k];
+    mat4_mul_vec4(vm, c4, v);
+    center = v3(v[0], v[1], -v[2]);              /* "in the view, +z = back so we flip it" */
+    real radius = (real)packed_bounding_sphere[3] * (real)inst->translation_and_scale[3];
+    int visible = center.z + radius > (real)pc->z_near;
+    visible &= center.z * (real)pc->frustum_x_xz[1] - R_ABS(center.x) * (real)pc->frustum_x_xz[0] < radius;
+    visible &= center.z * (real)pc->frustum_y_yz[1] - R_ABS(center.y) * (real)pc->frustum_y_yz[0] < radius;
+    return !visible;
+}
+
+/* shader/src/lib.rs:411-436 */
+void o_frustum_culling(const tr_primitive_info* primitives, uint32_t num_primitives, const tr_instance* instances,
+                       uint32_t num_instances, const tr_culling_push_constants* pc, uint32_t* instance_counts) {
+    for (uint32_t p = 0; p < num_primitives; ++p) instance_counts[p] = 0;   /* src/main.rs:1668-1674 */
+    for (uint32_t i = 0; i < num_instances; ++i) {
+        const tr_instance* inst = &instances[i];
+        if (inst->primitive_id >= num_primitives) continue;                  /* unchecked in the reference */
+        if (o_cull(primitives[inst->primitive_id].packed_bounding_sphere, inst, pc)) continue;
+        instance_counts[inst->primitive_id] += 1;
+    }
+}
+
+/* shader/src/lib.rs:469-517; the reference appends with atomics (arbitrary order), here in ascending order */
+void o_demultiplex_draws(const tr_primitive_info* primitives, uint32_t num_primitives, const uint32_t* instance_counts,
+                         uint32_t draw_counts[4], tr_draw_command* const draws[4]) {
+    for (int k = 0; k < 4; ++k) draw_counts[k] = 0;
+    for (uint32_t d = 0; d < num_primitives; ++d) {
+        uint32_t n = instance_counts[d];
+        if (n == 0) continue;
+        const tr_primitive_info* p = &primitives[d];
+        uint32_t b = p->draw_buffer_index < 3u ? p->draw_buffer_index : 3u;   /* `_ =>` arm */
+        tr_draw_command c;
+        c.index_count = p->index_count;
+        c.instance_count = n;
+        c.first_index = p->first_index;
+        c.vertex_offset = 0;
+        c.first_instance = p->first_instance;
+        draws[b][draw_counts[b]++] = c;
+    }
+}
+
+/* src/main.rs:1726-1746: frustum planes from the perspective matrix rows */
+void o_culling_push_constants(const real P[16], const float view_colmajor[16], real z_near, tr_culling_push_constants* out) {
+    /* row(i).truncate() of a column-major matrix: (P[i], P[4+i], P[8+i]) */
+    o_vec3 r0 = v3(P[0], P[4], P[8]), r1 = v3(P[1], P[5], P[9]), r3 = v3(P[3], P[7], P[11]);
+    o_vec3 fx = v3_normalize(v3_add(r3, r0)), fy = v3_normalize(v3_add(r3, r1));
+    memset(out, 0, sizeof(*out));
+    for (int k = 0; k < 16; ++k) out->view[k] = view_colmajor[k];
+    out->frustum_x_xz[0] = (float)fx.x; out->frustum_x_xz[1] = (float)fx.z;
+    out->frustum_y_yz[0] = (float)fy.y; out->frustum_y_yz[1] = (float)fy.z;
+    out->z_near = (float)z_near;
 }
 
 

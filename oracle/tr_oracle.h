@@ -105,6 +105,16 @@ void o_assign_lights_to_clusters(const tr_light* lights, uint32_t num_lights, co
                                  uint32_t num_clusters, const float view_matrix[16], const float view_rotation[4],
                                  uint32_t* counts, uint32_t* indices);          /* shader/src/lib.rs:596-645, sorted lists */
 
+/* ---- frustum culling + draw demultiplex ---- */
+o_vec3 o_similarity_mul_vec3(const tr_instance* inst, o_vec3 v);               /* shared-structs:233-236 */
+int  o_cull(const float packed_bounding_sphere[4], const tr_instance* inst, const tr_culling_push_constants* pc); /* shader/src/lib.rs:438-465 */
+void o_frustum_culling(const tr_primitive_info* primitives, uint32_t num_primitives, const tr_instance* instances,
+                       uint32_t num_instances, const tr_culling_push_constants* pc, uint32_t* instance_counts); /* :411-436 */
+void o_demultiplex_draws(const tr_primitive_info* primitives, uint32_t num_primitives, const uint32_t* instance_counts,
+                         uint32_t draw_counts[4], tr_draw_command* const draws[4]);   /* :469-517, ascending order */
+void o_culling_push_constants(const real perspective_colmajor[16], const float view_colmajor[16], real z_near,
+                              tr_culling_push_constants* out);                        /* src/main.rs:1728-1746 */
+
 /* ---- tonemap ---- */
 void    o_lottes_tonemap(const real color[3], const tr_tonemap_params* p, real out[3]);  /* shader/src/tonemapping.rs:8-27 */
 uint8_t o_linear_to_srgb8(real x);

@@ -6,6 +6,7 @@
 // fails with TR_ERR_NO_DEVICE and every other entry point needs a context.
 #include "tr_kernels.h"
 #include "tr_cluster_kernels.h"
+#include "tr_geometry_kernels.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -611,6 +612,43 @@ tr_status tr_download_texture(tr_context* ctx, uint32_t index, void* rgba8_host_
     TR_HIP(ctx, hipMemcpyAsync(rgba8_host_out, ctx->d_tex_arena + ctx->h_textures[index].offset[0],
                                (size_t)lay.total_texels * 4u, hipMemcpyDeviceToHost, stream));
     TR_HIP(ctx, hipStreamSynchronize(stream));
+    return TR_OK;
+}
+
+tr_status tr_frustum_culling(tr_context* ctx, const void* primitives, uint32_t num_primitives, const void* instances,
+                             uint32_t num_instances, const tr_culling_push_constants* push, void* instance_counts,
+                             void* stream_) {
+    if (!ctx || !primitives || !push || !instance_counts || num_primitives == 0 || (!instances && num_instances))
+        return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    TR_HIP(ctx, hipMemsetAsync(instance_counts, 0, sizeof(uint32_t) * num_primitives, stream));   // src/main.rs:1668-1674
+    if (num_instances == 0) return TR_OK;
+    tr_cull_params p;
+    p.pc = *push;
+    p.num_instances = num_instances;
+    p.num_primitives = num_primitives;
+    hipLaunchKernelGGL(frustum_culling_kernel, dim3((num_instances + 255u) / 256u), dim3(256), 0, stream, p,
+                       (const tr_primitive_info*)primitives, (const tr_instance*)instances, (uint32_t*)instance_counts);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_demultiplex_draws(tr_context* ctx, const void* primitives, uint32_t num_primitives,
+                               const void* instance_counts, void* draw_counts, void* const draws[TR_NUM_DRAW_BUFFERS],
+                               void* stream_) {
+    if (!ctx || !primitives || !instance_counts || !draw_counts || !draws || num_primitives == 0)
+        return TR_ERR_INVALID_ARGUMENT;
+    tr_draw_buffers out;
+    for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k) {
+        if (!draws[k]) return TR_ERR_INVALID_ARGUMENT;
+        out.draws[k] = (tr_draw_command*)draws[k];
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(demultiplex_draws_kernel, dim3(1), dim3(1024), 0, stream, (const tr_primitive_info*)primitives,
+                       (const uint32_t*)instance_counts, num_primitives, (uint32_t*)draw_counts, out);
+    TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
 

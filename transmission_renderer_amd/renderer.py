@@ -163,6 +163,30 @@ class TransmissionRenderer:
             levels.append(buf[off:off + w * h].reshape(h, w, 4))
         return lay, levels
 
+    # ---- GPU culling (src/main.rs:1716-1763, 1811-1838)
+    def frustum_culling(self, primitives: torch.Tensor, instances: torch.Tensor, push: wire.CullingPushConstants):
+        """primitives / instances: uint8 device tensors holding PrimitiveInfo / Instance records.
+        Returns instance_counts (int32 device tensor, one per primitive)."""
+        assert primitives.is_cuda and instances.is_cuda and primitives.dtype == torch.uint8 and instances.dtype == torch.uint8
+        n_prim = primitives.numel() // wire.PRIMITIVE_DTYPE.itemsize
+        n_inst = instances.numel() // wire.INSTANCE_DTYPE.itemsize
+        counts = torch.empty(n_prim, dtype=torch.int32, device=self.device)
+        self._check(self.lib.tr_frustum_culling(self._ctx, primitives.data_ptr(), n_prim, instances.data_ptr(), n_inst,
+                                                C.byref(push), counts.data_ptr(), self._stream()), "tr_frustum_culling")
+        return counts
+
+    def demultiplex_draws(self, primitives: torch.Tensor, instance_counts: torch.Tensor):
+        """Returns (draw_counts int32[4], [4 uint8 tensors of tr_draw_command records, capacity = all primitives])."""
+        n_prim = primitives.numel() // wire.PRIMITIVE_DTYPE.itemsize
+        assert instance_counts.numel() == n_prim and instance_counts.dtype == torch.int32
+        draw_counts = torch.empty(4, dtype=torch.int32, device=self.device)
+        draws = [torch.zeros(n_prim * wire.DRAW_COMMAND_DTYPE.itemsize, dtype=torch.uint8, device=self.device) for _ in range(4)]
+        ptrs = (C.c_void_p * 4)(*[d.data_ptr() for d in draws])
+        self._check(self.lib.tr_demultiplex_draws(self._ctx, primitives.data_ptr(), n_prim, instance_counts.data_ptr(),
+                                                  draw_counts.data_ptr(), C.byref(ptrs), self._stream()),
+                    "tr_demultiplex_draws")
+        return draw_counts, draws
+
     def upload_ggx_lut(self, rgba8: Optional[np.ndarray] = None):
         if rgba8 is None:
             rgba8 = load_ggx_lut()

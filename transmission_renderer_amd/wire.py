@@ -203,6 +203,39 @@ class Pyramid(C.Structure):  # include/tr_shade.h tr_pyramid
     ]
 
 
+# ---- geometry / draw records (shared-structs/src/lib.rs:238-281) as numpy record layouts
+INSTANCE_DTYPE = np.dtype([("translation_and_scale", np.float32, 4), ("rotation", np.float32, 4),
+                           ("primitive_id", np.uint32), ("material_id", np.uint32), ("_pad", np.uint32, 2)])
+PRIMITIVE_DTYPE = np.dtype([("packed_bounding_sphere", np.float32, 4), ("draw_buffer_index", np.uint32),
+                            ("index_count", np.uint32), ("first_index", np.uint32), ("first_instance", np.uint32)])
+DRAW_COMMAND_DTYPE = np.dtype([("index_count", np.uint32), ("instance_count", np.uint32), ("first_index", np.uint32),
+                               ("vertex_offset", np.int32), ("first_instance", np.uint32)])
+assert INSTANCE_DTYPE.itemsize == 48 and PRIMITIVE_DTYPE.itemsize == 32 and DRAW_COMMAND_DTYPE.itemsize == 20
+NUM_DRAW_BUFFERS = 4
+
+
+class CullingPushConstants(C.Structure):  # shared-structs/src/lib.rs:270-279
+    _fields_ = [("view", C.c_float * 16), ("frustum_x_xz", C.c_float * 2), ("frustum_y_yz", C.c_float * 2),
+                ("z_near", C.c_float), ("_pad", C.c_float * 3)]
+
+    @classmethod
+    def new(cls, perspective: np.ndarray, view: np.ndarray, z_near: float = Z_NEAR) -> "CullingPushConstants":
+        """src/main.rs:1726-1746: frustum_x = (row3 + row0).truncate().normalize(), frustum_y likewise with row1.
+        `perspective` and `view` are 4x4 float32 arrays indexed [column][row] like the rest of this module."""
+        p = np.asarray(perspective, dtype=np.float32)
+
+        def plane(i):
+            v = (p[:3, 3] + p[:3, i]).astype(np.float32)
+            return _normalize(v)
+        fx, fy = plane(0), plane(1)
+        out = cls()
+        out.view = (C.c_float * 16)(*np.asarray(view, dtype=np.float32).reshape(-1))   # column-major
+        out.frustum_x_xz = (C.c_float * 2)(float(fx[0]), float(fx[2]))
+        out.frustum_y_yz = (C.c_float * 2)(float(fy[1]), float(fy[2]))
+        out.z_near = float(z_near)
+        return out
+
+
 class TextureDesc(C.Structure):  # include/tr_shade.h tr_texture_desc
     _fields_ = [
         ("rgba8", C.c_void_p),
