@@ -61,6 +61,16 @@ class OScene(C.Structure):
                 ("textures", C.c_void_p), ("num_textures", C.c_uint32)]
 
 
+class OGeometry(C.Structure):
+    _fields_ = [("position", C.c_void_p), ("normal", C.c_void_p), ("uv", C.c_void_p), ("index", C.c_void_p),
+                ("instances", C.c_void_p), ("num_vertices", C.c_uint32), ("num_indices", C.c_uint32),
+                ("num_instances", C.c_uint32)]
+
+
+class OLayer(C.Structure):
+    _fields_ = [("pos_depth", C.c_void_p), ("nrm_scale", C.c_void_p), ("uv", C.c_void_p), ("material_id", C.c_void_p)]
+
+
 class OGBuffer(C.Structure):
     _fields_ = [("pos_depth", C.c_void_p), ("nrm_scale", C.c_void_p), ("uv", C.c_void_p),
                 ("material_id", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32),
@@ -153,6 +163,14 @@ def load() -> C.CDLL:
     lib.o_demultiplex_draws.argtypes = [vp, u32, vp, C.POINTER(u32 * 4), C.POINTER(vp * 4)]
     lib.o_culling_push_constants.restype = None
     lib.o_culling_push_constants.argtypes = [C.POINTER(f * 16), C.POINTER(f * 16), f, C.POINTER(wire.CullingPushConstants)]
+    lib.o_vertex_instanced.restype = None
+    lib.o_vertex_instanced.argtypes = [vp, C.POINTER(f * 16), Vec3, Vec3, C.POINTER(Vec3), C.POINTER(Vec3),
+                                       C.POINTER(f * 4), C.POINTER(f)]
+    lib.o_alpha_clip_kills.restype = C.c_int
+    lib.o_alpha_clip_kills.argtypes = [C.POINTER(OScene), u32, Vec2, Vec2, Vec2]
+    lib.o_rasterize.restype = None
+    lib.o_rasterize.argtypes = [C.POINTER(OScene), C.POINTER(OGeometry), C.POINTER(vp * 4), C.POINTER(u32 * 4), u32, u32,
+                                OLayer, OLayer]
     lib.o_tonemap_frame.restype = None
     lib.o_tonemap_frame.argtypes = [vp, u32, C.POINTER(wire.TonemapParams), vp, vp]
     _bind_passes(lib)
@@ -363,3 +381,43 @@ def demultiplex_draws(primitives: np.ndarray, instance_counts: np.ndarray):
     counts = (C.c_uint32 * 4)()
     load().o_demultiplex_draws(_ptr(primitives), n, _ptr(instance_counts), C.byref(counts), C.byref(ptrs))
     return np.array(list(counts), dtype=np.uint32), [d[:counts[k]].copy() for k, d in enumerate(draws)]
+
+
+def vertex_instanced(instance: np.ndarray, proj_view, position, normal):
+    """vertex_instanced_with_scale on one vertex: (world position, world normal, clip position, scale), fp32."""
+    inst = np.ascontiguousarray(instance, dtype=wire.INSTANCE_DTYPE).reshape(1)
+    pv = (C.c_float * 16)(*np.asarray(proj_view, dtype=np.float32).reshape(-1))
+    op, on, clip, sc = Vec3(), Vec3(), (C.c_float * 4)(), C.c_float()
+    load().o_vertex_instanced(_ptr(inst), C.byref(pv), v3(position), v3(normal), C.byref(op), C.byref(on), C.byref(clip),
+                              C.byref(sc))
+    return op.np(), on.np(), np.array(list(clip), dtype=np.float32), np.float32(sc.value)
+
+
+def alpha_clip_kills(binding: "SceneBinding", material_id: int, uv, duv_dx, duv_dy) -> bool:
+    return bool(load().o_alpha_clip_kills(C.byref(binding.struct), int(material_id), Vec2(float(uv[0]), float(uv[1])),
+                                          Vec2(float(duv_dx[0]), float(duv_dx[1])), Vec2(float(duv_dy[0]), float(duv_dy[1]))))
+
+
+def new_layer(width: int, height: int) -> dict:
+    return {"pos_depth": np.zeros((height, width, 4), np.float32), "nrm_scale": np.zeros((height, width, 4), np.float32),
+            "uv": np.zeros((height, width, 2), np.float32), "material_id": np.zeros((height, width), np.uint32),
+            "width": width, "height": height}
+
+
+def rasterize(binding: "SceneBinding", geometry: dict, draw_counts, draws, width: int, height: int):
+    """(opaque layer, transmissive layer) as TGB-v1 plane dicts; `geometry` holds position / normal / uv / index /
+    instances arrays, `draws` four DRAW_COMMAND_DTYPE arrays (e.g. from demultiplex_draws)."""
+    pos = np.ascontiguousarray(geometry["position"], dtype=np.float32)
+    nrm = np.ascontiguousarray(geometry["normal"], dtype=np.float32)
+    uv = np.ascontiguousarray(geometry["uv"], dtype=np.float32)
+    idx = np.ascontiguousarray(geometry["index"], dtype=np.uint32)
+    inst = np.ascontiguousarray(geometry["instances"], dtype=wire.INSTANCE_DTYPE)
+    geo = OGeometry(_ptr(pos), _ptr(nrm), _ptr(uv), _ptr(idx), _ptr(inst), len(pos), len(idx), len(inst))
+    keep = [np.ascontiguousarray(d, dtype=wire.DRAW_COMMAND_DTYPE) if len(d) else np.zeros(1, wire.DRAW_COMMAND_DTYPE)
+            for d in draws]
+    ptrs = (C.c_void_p * 4)(*[d.ctypes.data for d in keep])
+    counts = (C.c_uint32 * 4)(*[int(c) for c in draw_counts])
+    layers = [new_layer(width, height), new_layer(width, height)]
+    structs = [OLayer(_ptr(l["pos_depth"]), _ptr(l["nrm_scale"]), _ptr(l["uv"]), _ptr(l["material_id"])) for l in layers]
+    load().o_rasterize(C.byref(binding.struct), C.byref(geo), C.byref(ptrs), C.byref(counts), width, height, structs[0], structs[1])
+    return layers[0], layers[1]

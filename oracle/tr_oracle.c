@@ -1201,6 +1201,176 @@ void o_shade_transmission(const o_scene* s, const o_gbuffer* g, const o_pyramid*
     run_bands(j, nthreads);
 }
 
+/* ------------------------------------------------- geometry front end */
+
+/* shader/src/lib.rs:356-385 `vertex_instanced_with_scale` */
+void o_vertex_instanced(const tr_instance* inst, const float proj_view[16], o_vec3 position, o_vec3 normal,
+                        o_vec3* out_position, o_vec3* out_normal, real out_clip[4], real* out_scale) {
+    o_vec3 world = o_similarity_mul_vec3(inst, position);       /* similarity * position */
+    if (out_position) *out_position = world;
+    if (out_normal) {
+        real q[4] = {inst->rotation[0], inst->rotation[1], inst->rotation[2], inst->rotation[3]};
+        *out_normal = quat_mul_vec3(q, normal);                  /* similarity.rotation * normal */
+    }
+    if (out_scale) *out_scale = (real)inst->translation_and_scale[3];
+    real pv[16], p4[4] = {world.x, world.y, world.z, R(1.0)};
+    for (int k = 0; k < 16; ++k) pv[k] = (real)proj_view[k];
+    mat4_mul_vec4(pv, p4, out_clip);                             /* proj_view * position.extend(1.0) */
+}
+
+/* shader/src/lib.rs:269-292 `depth_pre_pass_alpha_clip` */
+int o_alpha_clip_kills(const o_scene* s, uint32_t material_id, o_vec2 uv, o_vec2 duv_dx, o_vec2 duv_dy) {
+    const tr_material_info* m = &s->materials[material_id];
+    o_frag_derivs d;
+    memset(&d, 0, sizeof(d));
+    d.duv_dx = duv_dx;
+    d.duv_dy = duv_dy;
+    real diffuse[4];
+    get_diffuse(s, m, uv, &d, diffuse);
+    return diffuse[3] < (real)m->alpha_clipping_cutoff;
+}
+
+typedef struct {
+    real A[3], B[3], C[3];     /* edge functions, positive inside a front-facing triangle */
+    real z[3], w[3];           /* clip z, w per vertex */
+    int x0, y0, x1, y1;        /* inclusive pixel bounds, clipped to the frame; empty if x0 > x1 */
+    int front;
+} o_tri_setup;
+
+static void tri_setup(real clip[3][4], uint32_t width, uint32_t height, o_tri_setup* t) {
+    real X[3], Y[3], W[3];
+    real hw = R(0.5) * (real)width, hh = R(0.5) * (real)height;
+    for (int i = 0; i < 3; ++i) {
+        X[i] = (clip[i][0] + clip[i][3]) * hw;     /* pixel x times w */
+        Y[i] = (clip[i][1] + clip[i][3]) * hh;
+        W[i] = clip[i][3];
+        t->z[i] = clip[i][2];
+        t->w[i] = clip[i][3];
+    }
+    for (int i = 0; i < 3; ++i) {
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        t->A[i] = Y[k] * W[j] - W[k] * Y[j];        /* (V_k x V_j), V = (X, Y, w) */
+        t->B[i] = W[k] * X[j] - X[k] * W[j];
+        t->C[i] = X[k] * Y[j] - Y[k] * X[j];
+    }
+    real det = (X[0] * t->A[0] + Y[0] * t->B[0]) + W[0] * t->C[0];
+    t->front = det > R(0.0);                        /* counter-clockwise on screen; also rejects degenerate / NaN */
+    t->x0 = 0; t->y0 = 0; t->x1 = (int)width - 1; t->y1 = (int)height - 1;
+    if (W[0] > R(0.0) && W[1] > R(0.0) && W[2] > R(0.0)) {
+        real xs[3] = {X[0] / W[0], X[1] / W[1], X[2] / W[2]}, ys[3] = {Y[0] / W[0], Y[1] / W[1], Y[2] / W[2]};
+        real xmin = R_MIN(xs[0], R_MIN(xs[1], xs[2])), xmax = R_MAX(xs[0], R_MAX(xs[1], xs[2]));
+        real ymin = R_MIN(ys[0], R_MIN(ys[1], ys[2])), ymax = R_MAX(ys[0], R_MAX(ys[1], ys[2]));
+        /* conservative by one pixel on each side; coverage itself is decided by the edge functions */
+        real lim = R(16777216.0);
+        xmin = R_MAX(R_MIN(xmin, lim), -lim); xmax = R_MAX(R_MIN(xmax, lim), -lim);
+        ymin = R_MAX(R_MIN(ymin, lim), -lim); ymax = R_MAX(R_MIN(ymax, lim), -lim);
+        int bx0 = (int)R_FLOOR(xmin) - 1, bx1 = (int)R_FLOOR(xmax) + 1, by0 = (int)R_FLOOR(ymin) - 1, by1 = (int)R_FLOOR(ymax) + 1;
+        if (bx0 > t->x0) t->x0 = bx0;
+        if (by0 > t->y0) t->y0 = by0;
+        if (bx1 < t->x1) t->x1 = bx1;
+        if (by1 < t->y1) t->y1 = by1;
+    }
+}
+
+/* Barycentrics and depth of the triangle at a pixel centre.  Returns 1 when the pixel is covered and inside the
+ * clip volume. */
+static int tri_pixel(const o_tri_setup* t, real pxc, real pyc, real lambda[3], real* depth) {
+    real f[3];
+    int inside = 1;
+    for (int i = 0; i < 3; ++i) {
+        f[i] = (t->A[i] * pxc + t->B[i] * pyc) + t->C[i];
+        int tie = t->A[i] > R(0.0) || (t->A[i] == R(0.0) && t->B[i] > R(0.0));
+        inside &= f[i] > R(0.0) || (f[i] == R(0.0) && tie);
+    }
+    real sum = (f[0] + f[1]) + f[2];
+    real inv = R(1.0) / sum;
+    for (int i = 0; i < 3; ++i) lambda[i] = f[i] * inv;
+    real zc = (lambda[0] * t->z[0] + lambda[1] * t->z[1]) + lambda[2] * t->z[2];
+    real wc = (lambda[0] * t->w[0] + lambda[1] * t->w[1]) + lambda[2] * t->w[2];
+    *depth = zc / wc;
+    return inside && sum > R(0.0) && wc > R(0.0) && zc <= wc && *depth > R(0.0);
+}
+
+void o_rasterize(const o_scene* s, const o_geometry* geo, const tr_draw_command* const draws[4],
+                 const uint32_t draw_counts[4], uint32_t width, uint32_t height, o_layer opaque, o_layer transmissive) {
+    size_t npix = (size_t)width * height;
+    float* depth0 = (float*)calloc(npix, sizeof(float));
+    float* depth1 = (float*)calloc(npix, sizeof(float));
+    uint32_t* key = (uint32_t*)calloc(npix, sizeof(uint32_t));
+    for (int layer = 0; layer < 2; ++layer) {
+        o_layer out = layer ? transmissive : opaque;
+        float* depth = layer ? depth1 : depth0;
+        for (size_t i = 0; i < npix; ++i) { out.material_id[i] = TR_NOT_COVERED; key[i] = 0; }
+        memset(out.pos_depth, 0, npix * 16); memset(out.nrm_scale, 0, npix * 16); memset(out.uv, 0, npix * 8);
+        uint32_t t_id = 0;    /* position of the triangle in the layer's draw stream: later wins depth ties */
+        for (int b = layer * 2; b < layer * 2 + 2; ++b) {
+            for (uint32_t d = 0; d < draw_counts[b]; ++d) {
+                const tr_draw_command* dc = &draws[b][d];
+                for (uint32_t ii = 0; ii < dc->instance_count; ++ii) {
+                    uint32_t inst_id = dc->first_instance + ii;
+                    const tr_instance* inst = &geo->instances[inst_id];
+                    for (uint32_t tri = 0; tri < dc->index_count / 3u; ++tri, ++t_id) {
+                        uint32_t vi[3];
+                        o_vec3 wp[3], wn[3];
+                        o_vec2 vuv[3];
+                        real clip[3][4], scale = R(0.0);
+                        for (int k = 0; k < 3; ++k) {
+                            vi[k] = geo->index[dc->first_index + tri * 3u + (uint32_t)k] + (uint32_t)dc->vertex_offset;
+                            o_vertex_instanced(inst, s->push.proj_view, f3(&geo->position[vi[k] * 3u]), f3(&geo->normal[vi[k] * 3u]),
+                                               &wp[k], &wn[k], clip[k], &scale);
+                            vuv[k].x = geo->uv[vi[k] * 2u]; vuv[k].y = geo->uv[vi[k] * 2u + 1u];
+                        }
+                        o_tri_setup ts;
+                        tri_setup(clip, width, height, &ts);
+                        if (!ts.front) continue;
+                        for (int py = ts.y0; py <= ts.y1; ++py) {
+                            for (int px = ts.x0; px <= ts.x1; ++px) {
+                                real lam[3], dep;
+                                if (!tri_pixel(&ts, (real)px + R(0.5), (real)py + R(0.5), lam, &dep)) continue;
+                                size_t pi = (size_t)py * width + (size_t)px;
+                                float depf = (float)dep;
+                                if (layer == 1 && !(depf > depth0[pi])) continue;     /* behind (or at) the opaque surface */
+                                if (!(depf > depth[pi] || depf == depth[pi])) continue;   /* GREATER, ties: later drawn wins */
+                                o_vec2 uvp = {(lam[0] * vuv[0].x + lam[1] * vuv[1].x) + lam[2] * vuv[2].x,
+                                              (lam[0] * vuv[0].y + lam[1] * vuv[1].y) + lam[2] * vuv[2].y};
+                                if (b & 1) {   /* alpha clip: implicit-LOD fetch from the quad's uv differences */
+                                    o_vec2 quv[2];
+                                    for (int a = 0; a < 2; ++a) {   /* partner in x, partner in y */
+                                        int qx = a == 0 ? (px ^ 1) : px, qy = a == 1 ? (py ^ 1) : py;
+                                        real l2[3], d2;
+                                        tri_pixel(&ts, (real)qx + R(0.5), (real)qy + R(0.5), l2, &d2);   /* helper invocation */
+                                        quv[a].x = (l2[0] * vuv[0].x + l2[1] * vuv[1].x) + l2[2] * vuv[2].x;
+                                        quv[a].y = (l2[0] * vuv[0].y + l2[1] * vuv[1].y) + l2[2] * vuv[2].y;
+                                    }
+                                    real sx = (px & 1) ? R(-1.0) : R(1.0), sy = (py & 1) ? R(-1.0) : R(1.0);
+                                    o_vec2 ddx = {(quv[0].x - uvp.x) * sx, (quv[0].y - uvp.y) * sx};
+                                    o_vec2 ddy = {(quv[1].x - uvp.x) * sy, (quv[1].y - uvp.y) * sy};
+                                    if (o_alpha_clip_kills(s, inst->material_id, uvp, ddx, ddy)) continue;
+                                }
+                                depth[pi] = depf;
+                                key[pi] = t_id;
+                                out.material_id[pi] = inst->material_id;
+                                for (int c = 0; c < 3; ++c) {
+                                    const real* P0 = &wp[0].x; const real* P1 = &wp[1].x; const real* P2 = &wp[2].x;
+                                    const real* N0 = &wn[0].x; const real* N1 = &wn[1].x; const real* N2 = &wn[2].x;
+                                    out.pos_depth[pi * 4 + (size_t)c] = (float)((lam[0] * P0[c] + lam[1] * P1[c]) + lam[2] * P2[c]);
+                                    out.nrm_scale[pi * 4 + (size_t)c] = (float)((lam[0] * N0[c] + lam[1] * N1[c]) + lam[2] * N2[c]);
+                                }
+                                out.pos_depth[pi * 4 + 3] = depf;
+                                out.nrm_scale[pi * 4 + 3] = (float)scale;
+                                out.uv[pi * 2] = (float)uvp.x;
+                                out.uv[pi * 2 + 1] = (float)uvp.y;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    free(depth0); free(depth1); free(key);
+}
+
+
 /* ------------------------------------------------------------- tonemap */
 
 /* shader/src/tonemapping.rs:8-27 `LottesTonemapper::tonemap` */

@@ -196,6 +196,39 @@ void o_shade_opaque(const o_scene* s, const o_gbuffer* g, tr_rect rect,
 void o_shade_transmission(const o_scene* s, const o_gbuffer* g, const o_pyramid* framebuffer, tr_rect rect,
                           uint16_t* hdr_f16, real* hdr_f32, int nthreads);
 
+/* ---- geometry front end: vertex stage + rasterisation into the two TGB-v1 layers ---- */
+typedef struct {
+    const float* position;   /* 3 floats / vertex (binding 0, stride 12; src/pipelines.rs:287-298) */
+    const float* normal;     /* 3 floats / vertex */
+    const float* uv;         /* 2 floats / vertex */
+    const uint32_t* index;   /* UINT32 triangle list (src/main.rs:1893-1898) */
+    const tr_instance* instances;
+    uint32_t num_vertices, num_indices, num_instances;
+} o_geometry;
+
+typedef struct {             /* one writable TGB-v1 layer, whole frame */
+    float* pos_depth; float* nrm_scale; float* uv; uint32_t* material_id;
+} o_layer;
+
+/* vertex_instanced_with_scale (shader/src/lib.rs:356-385); vertex_instanced (:330-354), depth_pre_pass_instanced
+ * (:316-328) and depth_pre_pass_vertex_alpha_clip (:294-314) compute subsets of the same values. */
+void o_vertex_instanced(const tr_instance* inst, const float proj_view[16], o_vec3 position, o_vec3 normal,
+                        o_vec3* out_position, o_vec3* out_normal, real out_clip[4], real* out_scale);
+/* depth_pre_pass_alpha_clip (shader/src/lib.rs:269-292): 1 = the fragment is killed */
+int  o_alpha_clip_kills(const o_scene* s, uint32_t material_id, o_vec2 uv, o_vec2 duv_dx, o_vec2 duv_dy);
+/*
+ * The fixed-function part between the vertex stage and the fragment entry points, restated (unpinned: Vulkan
+ * rasterisation rules, no reference source): back-face culling (front = counter-clockwise, glTF convention),
+ * clip-space (homogeneous) edge functions evaluated at pixel centres with a top-left style tie rule, clip volume
+ * 0 <= z <= w, perspective-correct interpolation, depth = z/w with GREATER against a buffer cleared to 0
+ * (reversed-Z; src/main.rs:1585-1591, src/pipelines.rs:350-398); among equal depths the later-drawn fragment wins.
+ * Layer 0 <- draw buffers 0 (opaque) and 1 (alpha clip); layer 1 <- buffers 2 and 3, kept only where nearer than
+ * layer 0 (the transmissive depth pre-pass runs against the opaque depth; src/main.rs:2005-2042).
+ * `s` supplies materials / textures for the alpha-clip kill and push.proj_view.
+ */
+void o_rasterize(const o_scene* s, const o_geometry* geo, const tr_draw_command* const draws[4],
+                 const uint32_t draw_counts[4], uint32_t width, uint32_t height, o_layer opaque, o_layer transmissive);
+
 #ifdef __cplusplus
 }
 #endif
