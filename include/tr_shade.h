@@ -332,6 +332,53 @@ tr_status tr_demultiplex_draws(tr_context* ctx, const void* primitives, uint32_t
                                const void* instance_counts, void* draw_counts, void* const draws[TR_NUM_DRAW_BUFFERS],
                                void* stream);
 
+/* ------------------------------------------------------- geometry front end */
+
+/*
+ * The model buffers of src/model_loading.rs / `ModelStagingBuffers` (vertex bindings 0-2 of src/pipelines.rs:287-304,
+ * UINT32 indices, `primitives` and `instances` storage buffers).  HOST pointers; copied to HBM on `stream`, and the
+ * per-frame work buffers of the rasteriser are sized from them.  Replaces any previous geometry.
+ */
+typedef struct tr_geometry_desc {
+    const float* position;            /* 3 floats per vertex */
+    const float* normal;              /* 3 floats per vertex */
+    const float* uv;                  /* 2 floats per vertex */
+    uint32_t num_vertices;
+    const uint32_t* index;            /* triangle list */
+    uint32_t num_indices;
+    const tr_primitive_info* primitives;
+    uint32_t num_primitives;
+    const tr_instance* instances;
+    uint32_t num_instances;
+} tr_geometry_desc;
+tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* geometry_host, void* stream);
+
+/* One writable TGB-v1 layer covering the whole frame (push->framebuffer_size): device pointers. */
+typedef struct tr_gbuffer_target {
+    void* pos_depth;    /* float4 */
+    void* nrm_scale;    /* float4 */
+    void* uv;           /* float2 */
+    void* material_id;  /* uint32 */
+} tr_gbuffer_target;
+
+/*
+ * Replaces the depth pre-passes + EQUAL-tested colour-pass rasterisation of src/main.rs:1900-2042 (pipelines
+ * src/pipelines.rs:309-398): runs the vertex stage (vertex_instanced_with_scale, shader/src/lib.rs:356-385) and
+ * rasterises the four demultiplexed draw buffers of the uploaded geometry into the two layers the shading passes
+ * read: `opaque` <- buffers 0 and 1 (nearest fragment, reversed-Z GREATER; buffer 1 with the alpha-clip kill of
+ * depth_pre_pass_alpha_clip), `transmissive` <- buffers 2 and 3 where nearer than the opaque layer.
+ * draw_counts / draws: device pointers as produced by tr_demultiplex_draws.  Materials (and textures, for alpha
+ * clipping) must have been uploaded.  Fixed-function rules restated: see oracle/tr_oracle.h o_rasterize.
+ */
+tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
+                       const tr_push_constants* push, const tr_gbuffer_target* opaque,
+                       const tr_gbuffer_target* transmissive, void* stream);
+
+/* Culling + demultiplex + rasterisation of the uploaded geometry in one call (the per-frame sequence of
+ * src/main.rs:1660-1838 followed by the draws), with the context's own count / draw buffers. */
+tr_status tr_draw_scene(tr_context* ctx, const tr_culling_push_constants* culling, const tr_push_constants* push,
+                        const tr_gbuffer_target* opaque, const tr_gbuffer_target* transmissive, void* stream);
+
 /* ------------------------------------------------------- clustered-light build */
 
 /*

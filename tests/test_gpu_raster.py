@@ -1,0 +1,206 @@
+"""GPU parity of the geometry front end (run with -m gpu on an MI355X): vertex stage,
+rasterisation into the two TGB-v1 layers and the alpha-clip kill through the C ABI against the CPU oracle, whose
+vertex stage / kill logic are pinned bit-exactly by the reference's compiled shaders (tests/test_geometry.py).
+
+Criteria: coverage, material ids, depth and every interpolated attribute are BIT-EXACT (same fp32 operations in the
+same order); the only tolerance is on alpha-clipped primitives, where the kill compares a filtered texture value
+(computed with v_log_f32 / fma on the GPU) against the cutoff: a handful of pixels on the cut-out's rim may differ.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle  # noqa: E402
+from transmission_renderer_amd import meshes, synthetic, wire  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def renderer(ggx_lut):
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device: the -m gpu tests must run on the GPU box")
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    r = TransmissionRenderer(0)
+    r.upload_ggx_lut(ggx_lut)
+    yield r
+    r.close()
+
+
+def _scene(w, h, view, alpha_cutoffs=(0.75, 0.6)):
+    sc = synthetic.make_scene(w, h, num_point_lights=1, textured=True, with_gbuffer=False)
+    sc["materials"][2].alpha_clipping_cutoff = alpha_cutoffs[0]
+    sc["materials"][7].alpha_clipping_cutoff = alpha_cutoffs[1]
+    eye = np.linalg.inv(np.asarray(view, np.float64).T)[:3, 3]
+    sc["push"] = wire.make_push_constants(w, h, eye=eye.astype(np.float32), view=view)
+    return sc
+
+
+def _oracle_layers(geo, sc, w, h, view):
+    b = oracle.SceneBinding(sc, np.zeros((4, 4, 4), np.uint8))
+    push = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+    counts = oracle.frustum_culling(geo["primitives"], geo["instances"], push)
+    dc, draws = oracle.demultiplex_draws(geo["primitives"], counts)
+    return oracle.rasterize(b, geo, dc, draws, w, h), push
+
+
+def _gpu_layers(r, geo, sc, w, h, culling):
+    r.upload_materials(sc["materials"])
+    r.upload_textures(sc["textures"])
+    r.upload_geometry(geo)
+    o, t = r.new_layer(w, h), r.new_layer(w, h)
+    r.draw_scene(culling, sc["push"], o, t)
+    torch.cuda.synchronize()
+    out = []
+    for layer in (o, t):
+        out.append({"pos_depth": layer.pos_depth.cpu().numpy(), "nrm_scale": layer.nrm_scale.cpu().numpy(),
+                    "uv": layer.uv.cpu().numpy(), "material_id": layer.material_id.cpu().numpy().view(np.uint32)})
+    return out
+
+
+def _compare(got, want, alpha_materials=(), max_rim_pixels=0):
+    """Bit-exact, except that up to `max_rim_pixels` pixels may differ where either side shows an alpha-clipped
+    material (the pixel then shows whatever is behind the cut-out on the other side)."""
+    differ = got["material_id"] != want["material_id"]
+    for k in ("pos_depth", "nrm_scale", "uv"):
+        differ |= (got[k].view(np.uint32) != want[k].view(np.uint32)).any(axis=2)
+    if not differ.any():
+        return 0
+    ys, xs = np.nonzero(differ)
+    involved = np.isin(got["material_id"][ys, xs], alpha_materials) | np.isin(want["material_id"][ys, xs], alpha_materials)
+    assert involved.all(), ("pixels differ away from alpha-clipped surfaces", int((~involved).sum()), ys[~involved][:5], xs[~involved][:5])
+    assert differ.sum() <= max_rim_pixels, int(differ.sum())
+    return int(differ.sum())
+
+
+CAMERAS = [
+    ("default", lambda: wire.default_camera()[1]),
+    ("side", lambda: wire.look_at_rh((3.5, 2.0, -6.0), (0.0, 1.2, -3.0), (0.0, 1.0, 0.0))),
+    ("inside", lambda: wire.look_at_rh((0.1, 1.0, -2.6), (0.0, 1.4, -4.0), (0.0, 1.0, 0.0))),   # geometry crosses the near plane
+]
+
+
+@pytest.mark.parametrize("w,h", [(256, 256), (250, 130), (640, 360)])
+@pytest.mark.parametrize("cam", [c[0] for c in CAMERAS])
+def test_layers_bit_exact(renderer, w, h, cam):
+    view = dict(CAMERAS)[cam]()
+    geo = meshes.make_mesh_scene()
+    sc = _scene(w, h, view)
+    (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    got_o, got_t = _gpu_layers(renderer, geo, sc, w, h, culling)
+    budget = max(4, w * h // 20000)
+    n0 = _compare(got_o, want_o, alpha_materials=(2,), max_rim_pixels=budget)
+    n1 = _compare(got_t, want_t, alpha_materials=(7, 2), max_rim_pixels=budget)
+    cov = want_o["material_id"] != wire.NOT_COVERED
+    assert cov.mean() > 0.2, cov.mean()
+    print(f"{cam} {w}x{h}: coverage {cov.mean():.2f} / {(want_t['material_id'] != wire.NOT_COVERED).mean():.2f}, "
+          f"alpha-rim pixels {n0} + {n1}")
+
+
+def test_layers_without_alpha_clip_are_bit_exact_everywhere(renderer):
+    """Cutoff 0 switches every kill off: then there is no tolerance at all."""
+    w, h = 512, 288
+    view = wire.default_camera()[1]
+    geo = meshes.make_mesh_scene()
+    sc = _scene(w, h, view, alpha_cutoffs=(0.0, 0.0))
+    (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    got_o, got_t = _gpu_layers(renderer, geo, sc, w, h, culling)
+    assert _compare(got_o, want_o) == 0 and _compare(got_t, want_t) == 0
+
+
+def test_many_small_triangles_and_depth_ties(renderer):
+    """Finely tessellated spheres (sub-pixel triangles), coplanar duplicates (equal depths: the later-drawn triangle
+    must win on both sides) and a large floor in one frame."""
+    w, h = 384, 216
+    view = wire.default_camera()[1]
+    mb = meshes.ModelBuffers()
+    S = meshes.Similarity
+    f32 = np.float32
+    mb.add_primitive(meshes.plane(30.0, 30.0, cells=2), 0, [(S(np.array([0, 0.6, -3.0], f32)), 3)])
+    fine = meshes.uv_sphere(1.0, 160, 80)
+    mb.add_primitive(fine, 0, [(S(np.array([-0.9, 1.6, -2.6], f32), 0.55), 1), (S(np.array([1.1, 1.4, -3.4], f32), 0.7), 6)])
+    quad = meshes.plane(1.5, 1.5, cells=3)
+    tilt = meshes.quat_from_axis_angle([1, 0, 0], 1.3)
+    for mat in (8, 9, 10):            # three coplanar copies: material 10 is drawn last
+        mb.add_primitive(quad, 0, [(S(np.array([0.0, 2.3, -3.0], f32), 1.0, tilt), mat)])
+    mb.add_primitive(meshes.uv_sphere(1.0, 96, 48), 2, [(S(np.array([0.15, 1.7, -1.9], f32), 0.6), 4)])
+    geo = mb.finish()
+    sc = _scene(w, h, view, alpha_cutoffs=(0.0, 0.0))
+    (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    got_o, got_t = _gpu_layers(renderer, geo, sc, w, h, culling)
+    assert _compare(got_o, want_o) == 0 and _compare(got_t, want_t) == 0
+    assert (want_o["material_id"] == 10).sum() > 50 and not (want_o["material_id"] == 8).any()
+
+
+def test_rasterize_then_shade_end_to_end(renderer, ggx_lut):
+    """glTF-shaped path: geometry -> layers -> opaque pass -> mips -> transmissive pass, GPU vs the oracle doing the
+    same from its own layers (T1-style bound on the final RGBA16F frame)."""
+    from transmission_renderer_amd.renderer import OpaquePyramid
+    r = renderer
+    w, h = 320, 180
+    view = wire.default_camera()[1]
+    geo = meshes.make_mesh_scene()
+    sc = _scene(w, h, view, alpha_cutoffs=(0.0, 0.0))
+    sc["lights"] = synthetic.make_lights(2)
+    sc["cluster_counts"], sc["light_indices"] = synthetic.all_lights_cluster_tables(2)
+    (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    r.upload_materials(sc["materials"])
+    r.upload_textures(sc["textures"])
+    r.upload_lights(sc["lights"])
+    r.set_cluster_tables(torch.from_numpy(sc["cluster_counts"].view(np.int32)).to(r.device),
+                         torch.from_numpy(sc["light_indices"].view(np.int32)).to(r.device))
+    r.upload_geometry(geo)
+    o, t = r.new_layer(w, h), r.new_layer(w, h)
+    r.draw_scene(culling, sc["push"], o, t)
+    pyr = OpaquePyramid(w, h, r.device)
+    hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+    r.record(o, t, sc["uniforms"], sc["push"], hdr, pyr)
+    torch.cuda.synchronize()
+    b = oracle.SceneBinding(sc, ggx_lut)
+    for layer in (want_o, want_t):
+        layer["width"], layer["height"] = w, h
+    o16, _, mip0 = oracle.shade_opaque(b, want_o, nthreads=8, fp64=True)
+    tex = oracle.new_pyramid(w, h, mip0)
+    oracle.generate_mips(w, h, tex)
+    oracle.shade_transmission(b, want_t, tex, hdr_f16=o16, nthreads=8, fp64=True)
+    got, want = hdr.cpu().numpy().astype(np.float64), o16.astype(np.float64)
+    fin = np.isfinite(got).all(axis=2) & np.isfinite(want).all(axis=2)
+    assert fin.mean() > 0.995
+    e = np.where(fin[..., None], (got - want) / np.maximum(np.abs(want), 1.0), 0.0)
+    rmse = np.sqrt((e[..., :3] ** 2).mean(axis=(0, 1))).max()
+    assert rmse <= 2e-3, rmse     # silhouettes: quad partners from different surfaces change LODs / TBN frames
+    assert np.quantile(np.abs(e), 0.98) <= 2e-3
+
+
+def test_raster_error_paths(ggx_lut):
+    from transmission_renderer_amd import _lib
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    fresh = TransmissionRenderer(0)
+    w, h = 64, 64
+    view = wire.default_camera()[1]
+    sc = _scene(w, h, view)
+    geo = meshes.make_mesh_scene()
+    culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+    o, t = fresh.new_layer(w, h), fresh.new_layer(w, h)
+    with pytest.raises(_lib.TrError) as e:      # no geometry yet
+        fresh.draw_scene(culling, sc["push"], o, t)
+    assert e.value.status == 4
+    bad = dict(geo)
+    bad["index"] = geo["index"].copy()
+    bad["index"][5] = len(geo["position"]) + 3
+    with pytest.raises(_lib.TrError) as e:      # an index beyond the vertex buffer is refused at upload
+        fresh.upload_geometry(bad)
+    assert e.value.status == 1
+    fresh.upload_geometry(geo)
+    with pytest.raises(_lib.TrError) as e:      # materials missing
+        fresh.draw_scene(culling, sc["push"], o, t)
+    assert e.value.status == 4
+    fresh.upload_materials(sc["materials"])
+    with pytest.raises(_lib.TrError) as e:      # textured materials without their textures
+        fresh.draw_scene(culling, sc["push"], o, t)
+    assert e.value.status == 1
+    fresh.upload_textures(sc["textures"])
+    fresh.draw_scene(culling, sc["push"], o, t)
+    torch.cuda.synchronize()
+    fresh.close()

@@ -18,6 +18,7 @@ SYMBOLS = (
     "tr_abi_version", "tr_status_string", "tr_last_hip_error", "tr_context_create", "tr_context_destroy",
     "tr_pyramid_layout", "tr_upload_materials", "tr_upload_lights", "tr_set_cluster_tables",
     "tr_upload_ggx_lut", "tr_upload_textures", "tr_texture_get_layout", "tr_download_texture", "tr_frustum_culling", "tr_demultiplex_draws",
+    "tr_upload_geometry", "tr_rasterize", "tr_draw_scene",
     "tr_write_cluster_data", "tr_assign_lights_to_clusters", "tr_shade_opaque",
     "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap",
 )
@@ -78,6 +79,14 @@ def load() -> C.CDLL:
     lib.tr_frustum_culling.argtypes = [vp, vp, u32, vp, u32, C.POINTER(wire.CullingPushConstants), vp, vp]
     lib.tr_demultiplex_draws.restype = i32
     lib.tr_demultiplex_draws.argtypes = [vp, vp, u32, vp, vp, C.POINTER(vp * 4), vp]
+    lib.tr_upload_geometry.restype = i32
+    lib.tr_upload_geometry.argtypes = [vp, C.POINTER(wire.GeometryDesc), vp]
+    lib.tr_rasterize.restype = i32
+    lib.tr_rasterize.argtypes = [vp, vp, C.POINTER(vp * 4), C.POINTER(wire.PushConstants), C.POINTER(wire.GBufferTarget),
+                                 C.POINTER(wire.GBufferTarget), vp]
+    lib.tr_draw_scene.restype = i32
+    lib.tr_draw_scene.argtypes = [vp, C.POINTER(wire.CullingPushConstants), C.POINTER(wire.PushConstants),
+                                  C.POINTER(wire.GBufferTarget), C.POINTER(wire.GBufferTarget), vp]
     lib.tr_write_cluster_data.restype = i32
     lib.tr_write_cluster_data.argtypes = [vp, C.POINTER(wire.Uniforms), C.POINTER(C.c_float * 16),
                                           C.POINTER(C.c_uint32 * 2), vp, vp]

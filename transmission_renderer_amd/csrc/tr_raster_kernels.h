@@ -1,0 +1,374 @@
+// tr_raster_kernels.h — geometry front end for gfx950: vertex stage, triangle setup, a
+// visibility-buffer rasteriser and the resolve into the two TGB-v1 layers the shading kernels read.
+//
+// Reference behaviour being replaced (file:line relative to the reference root):
+//   vertex_instanced[_with_scale], depth_pre_pass_*        shader/src/lib.rs:269-385
+//   depth pre-pass (GREATER, write) + colour pass (EQUAL)  src/pipelines.rs:309-398, src/main.rs:1900-2042
+//   indirect draws from the demultiplexed buffers          src/main.rs:1811-1838, 1921-2040
+// The fixed-function part (clipping, rasterisation rules, interpolation) has no reference source; it is restated
+// here exactly as in oracle/tr_oracle.c `o_rasterize` (same fp32 operations, contraction off), so coverage,
+// depth and every interpolated attribute are bit-identical to the CPU restatement.
+//
+// Shape of the work (one layer = two of the four draw buffers):
+//   scan_draws     one workgroup: triangles per draw -> prefix, so triangle t of the layer's draw stream is known
+//   setup          one thread per triangle: vertex stage, clip-space edge functions, bounds, work-item count
+//   scan_items     one workgroup: work items per triangle -> prefix
+//   raster         persistent waves; a work item is one 8-pixel-tall row of a triangle's bounds, at most 512 pixels
+//                  wide; a wave covers it in 8x8 pixel blocks and resolves visibility with one 64-bit atomicMax of
+//                  (depth bits << 32 | t) per covered pixel: reversed-Z GREATER, and among equal depths the
+//                  later-drawn triangle wins, independent of execution order (deterministic)
+//   resolve        one thread per pixel: winner -> barycentrics -> TGB-v1 planes
+#pragma once
+
+#include "tr_geometry_kernels.h"
+#include "tr_texture_kernels.h"
+
+namespace tr {
+
+struct tr_geometry_view {
+    const float* position;   // 3 floats per vertex
+    const float* normal;
+    const float* uv;         // 2 floats per vertex
+    const uint32_t* index;
+    const tr_instance* instances;
+};
+
+struct alignas(16) tr_tri_record {
+    float A[3], B[3], C[3];   // edge functions (positive inside)
+    float z[3], w[3];         // clip z, w per vertex
+    uint16_t x0, y0, x1, y1;  // inclusive pixel bounds (x0 > x1: culled / empty)
+    uint32_t v[3];            // vertex indices
+    uint32_t instance;
+    uint32_t flags;           // bit0: alpha clipped draw
+    uint32_t _pad[2];
+};
+static_assert(sizeof(tr_tri_record) == 96, "tr_tri_record is 96 B");
+
+struct tr_layer_counts {      // written by scan_draws / scan_items, read by the later kernels of the layer
+    uint32_t num_draws_first;  // draws taken from the layer's first buffer
+    uint32_t num_draws;        // ... from both
+    uint32_t num_triangles;
+    uint32_t num_items;
+};
+
+constexpr uint32_t kItemWidthBlocks = 64u;   // a work item spans at most 64 8x8 blocks horizontally
+
+// ------------------------------------------------------------------------ block-wide exclusive scan
+// 1024 threads; returns the exclusive prefix of `v` over the block and the block total (in every thread).
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave /*[17]*/, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63u) lds_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t t = lds_wave[w];
+            lds_wave[w] = run;
+            run += t;
+        }
+        lds_wave[16] = run;
+    }
+    __syncthreads();
+    const uint32_t result = lds_wave[wave] + incl - v;
+    total = lds_wave[16];
+    __syncthreads();
+    return result;
+}
+
+// tri_base[d] = number of triangles before draw d of the layer's stream (first buffer's draws, then the second's)
+__global__ __launch_bounds__(1024) void raster_scan_draws_kernel(const tr_draw_command* __restrict__ draws_a,
+                                                                 const tr_draw_command* __restrict__ draws_b,
+                                                                 const uint32_t* __restrict__ draw_counts, uint32_t buffer_a,
+                                                                 uint32_t capacity_draws, uint32_t capacity_triangles,
+                                                                 uint32_t* __restrict__ tri_base,
+                                                                 tr_layer_counts* __restrict__ counts) {
+    __shared__ uint32_t lds[17];
+    const uint32_t na = min(draw_counts[buffer_a], capacity_draws);
+    const uint32_t nb = min(draw_counts[buffer_a + 1u], capacity_draws - na);
+    const uint32_t n = na + nb;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < n; base += 1024u) {
+        const uint32_t d = base + threadIdx.x;
+        uint32_t tris = 0;
+        if (d < n) {
+            const tr_draw_command c = d < na ? draws_a[d] : draws_b[d - na];
+            const uint64_t t64 = (uint64_t)(c.index_count / 3u) * c.instance_count;
+            tris = (uint32_t)min(t64, (uint64_t)capacity_triangles);
+        }
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(tris, lds, total);
+        if (d < n) tri_base[d] = min(running + ex, capacity_triangles);
+        running = min(running + total, capacity_triangles);
+    }
+    if (threadIdx.x == 0) {
+        tri_base[n] = running;
+        counts->num_draws_first = na;
+        counts->num_draws = n;
+        counts->num_triangles = running;   // never above the capacity the host sized the records for
+        counts->num_items = 0;
+    }
+}
+
+// largest i in [0, n) with base[i] <= x  (base ascending, base[0] == 0)
+__device__ __forceinline__ uint32_t upper_index(const uint32_t* __restrict__ base, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (base[mid] <= x) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+struct tr_raster_frame {
+    float proj_view[16];
+    uint32_t width, height;
+};
+
+// vertex_instanced_with_scale for one vertex: world position, clip position (and the rotated normal when asked)
+__device__ __forceinline__ void vertex_stage(const tr_geometry_view& g, const tr_instance& inst, const float* pv,
+                                             uint32_t vi, float world[3], float clip[4]) {
+#pragma clang fp contract(off)
+    similarity_apply(inst, g.position[vi * 3u], g.position[vi * 3u + 1u], g.position[vi * 3u + 2u], world);
+    mat4_mul_point(pv, world[0], world[1], world[2], clip);
+}
+
+__global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_view g, const tr_raster_frame f,
+                                                           const tr_draw_command* __restrict__ draws_a,
+                                                           const tr_draw_command* __restrict__ draws_b,
+                                                           const uint32_t* __restrict__ tri_base,
+                                                           const tr_layer_counts* __restrict__ counts, uint32_t alpha_buffer_b,
+                                                           tr_tri_record* __restrict__ records,
+                                                           uint32_t* __restrict__ item_counts) {
+#pragma clang fp contract(off)
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= counts->num_triangles) return;
+    const uint32_t d = upper_index(tri_base, counts->num_draws, t);
+    const bool second = d >= counts->num_draws_first;
+    const tr_draw_command c = second ? draws_b[d - counts->num_draws_first] : draws_a[d];
+    const uint32_t local = t - tri_base[d], ntri = c.index_count / 3u;
+    const uint32_t inst_id = c.first_instance + local / ntri, tri = local % ntri;
+    const tr_instance inst = g.instances[inst_id];
+    tr_tri_record r;
+    float X[3], Y[3], W[3];
+    const float hw = 0.5f * (float)f.width, hh = 0.5f * (float)f.height;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.v[k] = g.index[c.first_index + tri * 3u + (uint32_t)k] + (uint32_t)c.vertex_offset;
+        float world[3], clip[4];
+        vertex_stage(g, inst, f.proj_view, r.v[k], world, clip);
+        X[k] = (clip[0] + clip[3]) * hw;
+        Y[k] = (clip[1] + clip[3]) * hh;
+        W[k] = clip[3];
+        r.z[k] = clip[2];
+        r.w[k] = clip[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        r.A[i] = Y[k] * W[j] - W[k] * Y[j];
+        r.B[i] = W[k] * X[j] - X[k] * W[j];
+        r.C[i] = X[k] * Y[j] - Y[k] * X[j];
+    }
+    const float det = (X[0] * r.A[0] + Y[0] * r.B[0]) + W[0] * r.C[0];
+    const bool front = det > 0.0f;
+    int x0 = 0, y0 = 0, x1 = (int)f.width - 1, y1 = (int)f.height - 1;
+    if (W[0] > 0.0f && W[1] > 0.0f && W[2] > 0.0f) {
+        const float xs0 = X[0] / W[0], xs1 = X[1] / W[1], xs2 = X[2] / W[2];
+        const float ys0 = Y[0] / W[0], ys1 = Y[1] / W[1], ys2 = Y[2] / W[2];
+        const float lim = 16777216.0f;
+        const float xmin = fmaxf(fminf(fminf(xs0, fminf(xs1, xs2)), lim), -lim), xmax = fmaxf(fminf(fmaxf(xs0, fmaxf(xs1, xs2)), lim), -lim);
+        const float ymin = fmaxf(fminf(fminf(ys0, fminf(ys1, ys2)), lim), -lim), ymax = fmaxf(fminf(fmaxf(ys0, fmaxf(ys1, ys2)), lim), -lim);
+        x0 = max(x0, (int)floorf(xmin) - 1);
+        y0 = max(y0, (int)floorf(ymin) - 1);
+        x1 = min(x1, (int)floorf(xmax) + 1);
+        y1 = min(y1, (int)floorf(ymax) + 1);
+    }
+    uint32_t items = 0;
+    if (front && x0 <= x1 && y0 <= y1) {
+        r.x0 = (uint16_t)x0; r.y0 = (uint16_t)y0; r.x1 = (uint16_t)x1; r.y1 = (uint16_t)y1;
+        const uint32_t rows = (uint32_t)(y1 >> 3) - (uint32_t)(y0 >> 3) + 1u;
+        const uint32_t cols = (uint32_t)(x1 >> 3) - (uint32_t)(x0 >> 3) + 1u;
+        items = rows * ((cols + kItemWidthBlocks - 1u) / kItemWidthBlocks);
+    } else {
+        r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0;
+    }
+    r.instance = inst_id;
+    r.flags = (second && alpha_buffer_b) ? 1u : 0u;
+    r._pad[0] = r._pad[1] = 0u;
+    records[t] = r;
+    item_counts[t] = items;
+}
+
+__global__ __launch_bounds__(1024) void raster_scan_items_kernel(const uint32_t* __restrict__ item_counts,
+                                                                 uint32_t* __restrict__ item_base,
+                                                                 tr_layer_counts* __restrict__ counts) {
+    __shared__ uint32_t lds[17];
+    const uint32_t n = counts->num_triangles;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < n; base += 1024u) {
+        const uint32_t t = base + threadIdx.x;
+        const uint32_t v = t < n ? item_counts[t] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, lds, total);
+        if (t < n) item_base[t] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) {
+        item_base[n] = running;
+        counts->num_items = running;
+    }
+}
+
+// Barycentrics and depth at a pixel centre (oracle: tri_pixel).  `rec` is wave-uniform in the raster kernel
+// (scalar registers) and per lane in the resolve.
+template <class Rec>
+__device__ __forceinline__ bool tri_pixel(const Rec& rec, float pxc, float pyc, float lambda[3], float& depth) {
+#pragma clang fp contract(off)
+    float fv[3];
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        fv[i] = (rec.A[i] * pxc + rec.B[i] * pyc) + rec.C[i];
+        const bool tie = rec.A[i] > 0.0f || (rec.A[i] == 0.0f && rec.B[i] > 0.0f);
+        inside &= fv[i] > 0.0f || (fv[i] == 0.0f && tie);
+    }
+    const float sum = (fv[0] + fv[1]) + fv[2];
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lambda[i] = fv[i] * inv;
+    const float zc = (lambda[0] * rec.z[0] + lambda[1] * rec.z[1]) + lambda[2] * rec.z[2];
+    const float wc = (lambda[0] * rec.w[0] + lambda[1] * rec.w[1]) + lambda[2] * rec.w[2];
+    depth = zc / wc;
+    return inside && sum > 0.0f && wc > 0.0f && zc <= wc && depth > 0.0f;
+}
+
+struct tr_alpha_tables {        // what the alpha-clip kill reads (depth_pre_pass_alpha_clip, shader/src/lib.rs:269-292)
+    const tr_material_info* materials;
+    const tr_dtex* textures;
+    const uint32_t* tex_arena;
+    uint32_t num_textures;
+};
+
+__global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, const tr_raster_frame f,
+                                                     const tr_tri_record* __restrict__ records,
+                                                     const uint32_t* __restrict__ item_base,
+                                                     const tr_layer_counts* __restrict__ counts,
+                                                     const tr_alpha_tables alpha,
+                                                     const unsigned long long* __restrict__ behind /* layer 0's buffer or null */,
+                                                     unsigned long long* __restrict__ vis) {
+#pragma clang fp contract(off)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * 4u;
+    const uint32_t n_items = counts->num_items, n_tris = counts->num_triangles;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));   // wave-uniform
+    for (uint32_t item = first; item < n_items; item += waves) {
+        const uint32_t t = __builtin_amdgcn_readfirstlane(upper_index(item_base, n_tris, item));
+        const TR_CONSTANT tr_tri_record& rec = *as_constant(records + t);
+        const uint32_t local = item - item_base[t];
+        const uint32_t bx0 = rec.x0 >> 3, by0 = rec.y0 >> 3, bx1 = rec.x1 >> 3;
+        const uint32_t groups = ((bx1 - bx0 + 1u) + kItemWidthBlocks - 1u) / kItemWidthBlocks;
+        const uint32_t row = local / groups, group = local - row * groups;
+        const uint32_t by = by0 + row;
+        const uint32_t bstart = bx0 + group * kItemWidthBlocks, bend = min(bstart + kItemWidthBlocks - 1u, bx1);
+        const uint32_t py = by * 8u + (lane >> 3);
+        const bool alpha_clip = (rec.flags & 1u) != 0u;
+        for (uint32_t bx = bstart; bx <= bend; ++bx) {
+            const uint32_t px = bx * 8u + (lane & 7u);
+            float lam[3], depth;
+            bool hit = tri_pixel(rec, (float)px + 0.5f, (float)py + 0.5f, lam, depth);
+            hit = hit && px >= rec.x0 && px <= rec.x1 && py >= rec.y0 && py <= rec.y1;
+            const size_t pix = (size_t)py * f.width + px;
+            if (hit && behind) hit = depth > __uint_as_float((uint32_t)(behind[pix] >> 32));   // nearer than the opaque surface
+            if (hit && alpha_clip) {
+                // implicit-LOD fetch of the diffuse texture: uv at the two quad partners from the same triangle
+                // (what helper invocations compute), differences oriented like dFdx / dFdy
+                const tr_instance& inst = g.instances[rec.instance];
+                const tr_material_info& m = alpha.materials[inst.material_id];
+                float alpha_v = m.diffuse_factor[3];
+                const int32_t tex_id = m.textures.diffuse;
+                if (tex_id >= 0 && (uint32_t)tex_id < alpha.num_textures) {
+                    float uvv[3][2];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        uvv[k][0] = g.uv[rec.v[k] * 2u];
+                        uvv[k][1] = g.uv[rec.v[k] * 2u + 1u];
+                    }
+                    auto uv_at = [&](const float l[3], int c) { return (l[0] * uvv[0][c] + l[1] * uvv[1][c]) + l[2] * uvv[2][c]; };
+                    float lx[3], ly[3], dd;
+                    tri_pixel(rec, (float)(px ^ 1u) + 0.5f, (float)py + 0.5f, lx, dd);
+                    tri_pixel(rec, (float)px + 0.5f, (float)(py ^ 1u) + 0.5f, ly, dd);
+                    const float u = uv_at(lam, 0), v = uv_at(lam, 1);
+                    const float sx = (px & 1u) ? -1.0f : 1.0f, sy = (py & 1u) ? -1.0f : 1.0f;
+                    uv_derivs dv;
+                    dv.dudx = (uv_at(lx, 0) - u) * sx;
+                    dv.dvdx = (uv_at(lx, 1) - v) * sx;
+                    dv.dudy = (uv_at(ly, 0) - u) * sy;
+                    dv.dvdy = (uv_at(ly, 1) - v) * sy;
+                    texture_fetch tf;
+                    texture_issue(tf, alpha.tex_arena, as_constant(alpha.textures) + tex_id, u, v, dv);
+                    alpha_v *= texture_resolve_channel<3>(tf, false, nullptr);
+                } else if (tex_id != -1) {
+                    alpha_v = 0.0f;   // unbound slot reads as zero
+                }
+                hit = !(alpha_v < m.alpha_clipping_cutoff);
+            }
+            if (hit) atomicMax(&vis[pix], ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)t);
+        }
+    }
+}
+
+struct tr_layer_planes {
+    float4* pos_depth;
+    float4* nrm_scale;
+    float2* uv;
+    uint32_t* material_id;
+};
+
+// One thread per pixel: the winning triangle's attributes at the pixel centre (vertex_instanced_with_scale outputs,
+// perspective-correct), or "no fragment".
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f,
+                                                             const tr_tri_record* __restrict__ records,
+                                                             const unsigned long long* __restrict__ vis,
+                                                             const tr_layer_planes out) {
+#pragma clang fp contract(off)
+    const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (px >= f.width || py >= f.height) return;
+    const size_t pix = (size_t)py * f.width + px;
+    const unsigned long long key = vis[pix];
+    if (key == 0ull) {
+        out.pos_depth[pix] = float4{0.f, 0.f, 0.f, 0.f};
+        out.nrm_scale[pix] = float4{0.f, 0.f, 0.f, 0.f};
+        out.uv[pix] = float2{0.f, 0.f};
+        out.material_id[pix] = TR_NOT_COVERED;
+        return;
+    }
+    const tr_tri_record rec = records[(uint32_t)key];
+    const tr_instance inst = g.instances[rec.instance];
+    float lam[3], depth;
+    tri_pixel(rec, (float)px + 0.5f, (float)py + 0.5f, lam, depth);
+    float P[3][3], N[3][3], T[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t vi = rec.v[k];
+        similarity_apply(inst, g.position[vi * 3u], g.position[vi * 3u + 1u], g.position[vi * 3u + 2u], P[k]);
+        quat_rotate(inst.rotation, g.normal[vi * 3u], g.normal[vi * 3u + 1u], g.normal[vi * 3u + 2u], N[k]);
+        T[k][0] = g.uv[vi * 2u];
+        T[k][1] = g.uv[vi * 2u + 1u];
+    }
+    auto mix = [&](float a, float b, float c) { return (lam[0] * a + lam[1] * b) + lam[2] * c; };
+    out.pos_depth[pix] = float4{mix(P[0][0], P[1][0], P[2][0]), mix(P[0][1], P[1][1], P[2][1]), mix(P[0][2], P[1][2], P[2][2]),
+                                __uint_as_float((uint32_t)(key >> 32))};
+    out.nrm_scale[pix] = float4{mix(N[0][0], N[1][0], N[2][0]), mix(N[0][1], N[1][1], N[2][1]), mix(N[0][2], N[1][2], N[2][2]),
+                                inst.translation_and_scale[3]};
+    out.uv[pix] = float2{mix(T[0][0], T[1][0], T[2][0]), mix(T[0][1], T[1][1], T[2][1])};
+    out.material_id[pix] = inst.material_id;
+}
+
+}  // namespace tr

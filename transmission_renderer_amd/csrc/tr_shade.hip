@@ -7,7 +7,9 @@
 #include "tr_kernels.h"
 #include "tr_cluster_kernels.h"
 #include "tr_geometry_kernels.h"
+#include "tr_raster_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -37,6 +39,27 @@ struct tr_context {
     uint32_t num_textures = 0;
     std::vector<tr_dtex> h_textures;
     tr_colour_tables* d_colour_tables = nullptr;
+
+    // geometry (model buffers) + the rasteriser's per-frame work buffers
+    float* d_position = nullptr;
+    float* d_normal = nullptr;
+    float* d_uv = nullptr;
+    uint32_t* d_index = nullptr;
+    tr_primitive_info* d_primitives = nullptr;
+    tr_instance* d_instances = nullptr;
+    uint32_t num_vertices = 0, num_indices = 0, num_primitives = 0, num_instances = 0;
+    uint32_t max_triangles[2] = {0, 0};       // per layer, if every instance is visible
+    uint32_t* d_instance_counts = nullptr;
+    uint32_t* d_draw_counts = nullptr;
+    tr_draw_command* d_draws[TR_NUM_DRAW_BUFFERS] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* d_tri_base = nullptr;
+    tr_tri_record* d_records = nullptr;
+    uint32_t* d_item_counts = nullptr;
+    uint32_t* d_item_base = nullptr;
+    tr_layer_counts* d_layer_counts = nullptr;
+    unsigned long long* d_vis[2] = {nullptr, nullptr};
+    size_t vis_pixels = 0;
+    uint32_t num_cus = 256;
 
     // lights (as the shading kernels and as the cluster assignment read them)
     tr_dlight* d_lights = nullptr;
@@ -257,6 +280,35 @@ uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles) {
     return 8u * k;
 }
 
+void free_geometry(tr_context* ctx) {
+    (void)hipFree(ctx->d_position);
+    (void)hipFree(ctx->d_normal);
+    (void)hipFree(ctx->d_uv);
+    (void)hipFree(ctx->d_index);
+    (void)hipFree(ctx->d_primitives);
+    (void)hipFree(ctx->d_instances);
+    (void)hipFree(ctx->d_instance_counts);
+    (void)hipFree(ctx->d_draw_counts);
+    for (auto& d : ctx->d_draws) {
+        (void)hipFree(d);
+        d = nullptr;
+    }
+    (void)hipFree(ctx->d_tri_base);
+    (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_item_counts);
+    (void)hipFree(ctx->d_item_base);
+    (void)hipFree(ctx->d_layer_counts);
+    ctx->d_position = ctx->d_normal = ctx->d_uv = nullptr;
+    ctx->d_index = nullptr;
+    ctx->d_primitives = nullptr;
+    ctx->d_instances = nullptr;
+    ctx->d_instance_counts = ctx->d_draw_counts = ctx->d_tri_base = ctx->d_item_counts = ctx->d_item_base = nullptr;
+    ctx->d_records = nullptr;
+    ctx->d_layer_counts = nullptr;
+    ctx->num_vertices = ctx->num_indices = ctx->num_primitives = ctx->num_instances = 0;
+    ctx->max_triangles[0] = ctx->max_triangles[1] = 0;
+}
+
 // Passes that shade textured materials differentiate inside 2x2 pixel quads: the rect must hold whole quads.
 tr_status check_textured_launch(const tr_context* ctx, const tr_gbuffer* g, const tr_frame_params& fp) {
     if (!ctx->any_textured) return TR_OK;
@@ -335,8 +387,10 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, shade_kernel<true, uint2>, 256, 0) != hipSuccess ||
             resident <= 0)
             resident = 4;
-        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount >= 8)
+        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount >= 8) {
             ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * 2u;
+            ctx->num_cus = (uint32_t)prop.multiProcessorCount;
+        }
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
     }
     if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
@@ -375,6 +429,9 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_tex_arena);
     (void)hipFree(ctx->d_textures);
     (void)hipFree(ctx->d_colour_tables);
+    free_geometry(ctx);
+    (void)hipFree(ctx->d_vis[0]);
+    (void)hipFree(ctx->d_vis[1]);
     delete ctx;
     return TR_OK;
 }
@@ -650,6 +707,148 @@ tr_status tr_demultiplex_draws(tr_context* ctx, const void* primitives, uint32_t
                        (const uint32_t*)instance_counts, num_primitives, (uint32_t*)draw_counts, out);
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
+}
+
+tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* stream_) {
+    if (!ctx || !g || !g->position || !g->normal || !g->uv || !g->index || !g->primitives || !g->instances ||
+        g->num_vertices == 0 || g->num_indices == 0 || g->num_primitives == 0 || g->num_instances == 0)
+        return TR_ERR_INVALID_ARGUMENT;
+    // every index / id is checked once here, so the kernels can index unchecked like the reference's shaders
+    for (uint32_t i = 0; i < g->num_indices; ++i)
+        if (g->index[i] >= g->num_vertices) return TR_ERR_INVALID_ARGUMENT;
+    std::vector<uint32_t> per_primitive(g->num_primitives, 0u);
+    for (uint32_t i = 0; i < g->num_instances; ++i) {
+        if (g->instances[i].primitive_id >= g->num_primitives) return TR_ERR_INVALID_ARGUMENT;
+        per_primitive[g->instances[i].primitive_id] += 1u;
+    }
+    uint64_t max_tris[2] = {0, 0};
+    for (uint32_t p = 0; p < g->num_primitives; ++p) {
+        const tr_primitive_info& pi = g->primitives[p];
+        if ((uint64_t)pi.first_index + pi.index_count > g->num_indices) return TR_ERR_INVALID_ARGUMENT;
+        if ((uint64_t)pi.first_instance + per_primitive[p] > g->num_instances) return TR_ERR_INVALID_ARGUMENT;
+        max_tris[pi.draw_buffer_index >= 2u ? 1 : 0] += (uint64_t)(pi.index_count / 3u) * per_primitive[p];
+    }
+    if (max_tris[0] > 0xFFFFFFF0ull || max_tris[1] > 0xFFFFFFF0ull) return TR_ERR_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    TR_HIP(ctx, hipDeviceSynchronize());
+    free_geometry(ctx);
+    const size_t nv = g->num_vertices, ni = g->num_indices, np_ = g->num_primitives, nn = g->num_instances;
+    const size_t cap = (size_t)std::max<uint64_t>(std::max(max_tris[0], max_tris[1]), 1ull);
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_position, nv * 12u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_normal, nv * 12u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_uv, nv * 8u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_index, ni * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_primitives, np_ * sizeof(tr_primitive_info)));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_instances, nn * sizeof(tr_instance)));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_instance_counts, np_ * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_draw_counts, TR_NUM_DRAW_BUFFERS * 4u));
+    for (auto& d : ctx->d_draws) TR_HIP(ctx, hipMalloc((void**)&d, np_ * sizeof(tr_draw_command)));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_tri_base, (np_ + 1u) * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_records, cap * sizeof(tr_tri_record)));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_counts, cap * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_base, (cap + 1u) * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_layer_counts, sizeof(tr_layer_counts)));
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_position, g->position, nv * 12u, hipMemcpyHostToDevice, stream));
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_normal, g->normal, nv * 12u, hipMemcpyHostToDevice, stream));
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_uv, g->uv, nv * 8u, hipMemcpyHostToDevice, stream));
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_index, g->index, ni * 4u, hipMemcpyHostToDevice, stream));
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_primitives, g->primitives, np_ * sizeof(tr_primitive_info), hipMemcpyHostToDevice, stream));
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_instances, g->instances, nn * sizeof(tr_instance), hipMemcpyHostToDevice, stream));
+    TR_HIP(ctx, hipStreamSynchronize(stream));   // the host arrays are caller memory
+    ctx->num_vertices = g->num_vertices;
+    ctx->num_indices = g->num_indices;
+    ctx->num_primitives = g->num_primitives;
+    ctx->num_instances = g->num_instances;
+    ctx->max_triangles[0] = (uint32_t)max_tris[0];
+    ctx->max_triangles[1] = (uint32_t)max_tris[1];
+    return TR_OK;
+}
+
+tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
+                       const tr_push_constants* push, const tr_gbuffer_target* opaque,
+                       const tr_gbuffer_target* transmissive, void* stream_) {
+    if (!ctx || !draw_counts || !draws || !push || !opaque || !transmissive) return TR_ERR_INVALID_ARGUMENT;
+    for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k)
+        if (!draws[k]) return TR_ERR_INVALID_ARGUMENT;
+    const tr_gbuffer_target* targets[2] = {opaque, transmissive};
+    for (const tr_gbuffer_target* t : targets)
+        if (!t->pos_depth || !t->nrm_scale || !t->uv || !t->material_id) return TR_ERR_INVALID_ARGUMENT;
+    const uint32_t w = push->framebuffer_size[0], h = push->framebuffer_size[1];
+    if (w == 0 || h == 0 || w > 65535u || h > 65535u) return TR_ERR_INVALID_ARGUMENT;
+    if (!ctx->d_position || ctx->num_materials == 0) return TR_ERR_TABLES_MISSING;
+    if (ctx->max_texture_id >= (int32_t)ctx->num_textures) return TR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)w * h;
+    if (npix > ctx->vis_pixels) {
+        TR_HIP(ctx, hipDeviceSynchronize());
+        (void)hipFree(ctx->d_vis[0]);
+        (void)hipFree(ctx->d_vis[1]);
+        ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
+        ctx->vis_pixels = 0;
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], npix * 8u));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[1], npix * 8u));
+        ctx->vis_pixels = npix;
+    }
+    tr_geometry_view gv;
+    gv.position = ctx->d_position;
+    gv.normal = ctx->d_normal;
+    gv.uv = ctx->d_uv;
+    gv.index = ctx->d_index;
+    gv.instances = ctx->d_instances;
+    tr_raster_frame fr;
+    std::memcpy(fr.proj_view, push->proj_view, sizeof(fr.proj_view));
+    fr.width = w;
+    fr.height = h;
+    tr_alpha_tables at;
+    at.materials = ctx->d_materials_raw;
+    at.textures = ctx->d_textures;
+    at.tex_arena = ctx->d_tex_arena;
+    at.num_textures = ctx->num_textures;
+    for (uint32_t layer = 0; layer < 2u; ++layer) {
+        const tr_draw_command* da = (const tr_draw_command*)draws[layer * 2u];
+        const tr_draw_command* db = (const tr_draw_command*)draws[layer * 2u + 1u];
+        const uint32_t cap = ctx->max_triangles[layer];
+        TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[layer], 0, npix * 8u, stream));
+        if (cap > 0u) {
+            hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1), dim3(1024), 0, stream, da, db, (const uint32_t*)draw_counts,
+                               layer * 2u, ctx->num_primitives, cap, ctx->d_tri_base, ctx->d_layer_counts);
+            hipLaunchKernelGGL(raster_setup_kernel, dim3((cap + 255u) / 256u), dim3(256), 0, stream, gv, fr, da, db,
+                               (const uint32_t*)ctx->d_tri_base, (const tr_layer_counts*)ctx->d_layer_counts, 1u,
+                               ctx->d_records, ctx->d_item_counts);
+            hipLaunchKernelGGL(raster_scan_items_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)ctx->d_item_counts,
+                               ctx->d_item_base, ctx->d_layer_counts);
+            hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * 8u), dim3(256), 0, stream, gv, fr,
+                               (const tr_tri_record*)ctx->d_records, (const uint32_t*)ctx->d_item_base,
+                               (const tr_layer_counts*)ctx->d_layer_counts, at,
+                               layer ? (const unsigned long long*)ctx->d_vis[0] : (const unsigned long long*)nullptr,
+                               ctx->d_vis[layer]);
+        }
+        tr_layer_planes planes;
+        planes.pos_depth = (float4*)targets[layer]->pos_depth;
+        planes.nrm_scale = (float4*)targets[layer]->nrm_scale;
+        planes.uv = (float2*)targets[layer]->uv;
+        planes.material_id = (uint32_t*)targets[layer]->material_id;
+        hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u), dim3(256), 0, stream, gv, fr,
+                           (const tr_tri_record*)ctx->d_records, (const unsigned long long*)ctx->d_vis[layer], planes);
+    }
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_draw_scene(tr_context* ctx, const tr_culling_push_constants* culling, const tr_push_constants* push,
+                        const tr_gbuffer_target* opaque, const tr_gbuffer_target* transmissive, void* stream) {
+    if (!ctx || !culling || !push) return TR_ERR_INVALID_ARGUMENT;
+    if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
+    tr_status st = tr_frustum_culling(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instances, ctx->num_instances,
+                                      culling, ctx->d_instance_counts, stream);
+    if (st != TR_OK) return st;
+    void* draws[TR_NUM_DRAW_BUFFERS] = {ctx->d_draws[0], ctx->d_draws[1], ctx->d_draws[2], ctx->d_draws[3]};
+    st = tr_demultiplex_draws(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instance_counts, ctx->d_draw_counts, draws,
+                              stream);
+    if (st != TR_OK) return st;
+    return tr_rasterize(ctx, ctx->d_draw_counts, draws, push, opaque, transmissive, stream);
 }
 
 tr_status tr_write_cluster_data(tr_context* ctx, const tr_uniforms* u, const float inverse_perspective[16],

@@ -163,6 +163,45 @@ class TransmissionRenderer:
             levels.append(buf[off:off + w * h].reshape(h, w, 4))
         return lay, levels
 
+    # ---- geometry front end (model buffers -> the two TGB-v1 layers)
+    def upload_geometry(self, geometry: dict):
+        """geometry: position (N,3) f32, normal (N,3) f32, uv (N,2) f32, index (M,) u32, primitives / instances
+        record arrays (wire.PRIMITIVE_DTYPE / INSTANCE_DTYPE), e.g. from meshes.ModelBuffers or gltf.load_gltf."""
+        a = {k: np.ascontiguousarray(geometry[k], dtype=dt) for k, dt in
+             (("position", np.float32), ("normal", np.float32), ("uv", np.float32), ("index", np.uint32),
+              ("primitives", wire.PRIMITIVE_DTYPE), ("instances", wire.INSTANCE_DTYPE))}
+        d = wire.GeometryDesc(a["position"].ctypes.data, a["normal"].ctypes.data, a["uv"].ctypes.data, len(a["position"]),
+                              a["index"].ctypes.data, len(a["index"]), a["primitives"].ctypes.data, len(a["primitives"]),
+                              a["instances"].ctypes.data, len(a["instances"]))
+        self._check(self.lib.tr_upload_geometry(self._ctx, C.byref(d), self._stream()), "tr_upload_geometry")
+
+    def new_layer(self, width: int, height: int) -> "GBufferPlanes":
+        dev = self.device
+        return GBufferPlanes(torch.empty((height, width, 4), dtype=torch.float32, device=dev),
+                             torch.empty((height, width, 4), dtype=torch.float32, device=dev),
+                             torch.empty((height, width, 2), dtype=torch.float32, device=dev),
+                             torch.empty((height, width), dtype=torch.int32, device=dev))
+
+    @staticmethod
+    def _target(layer: "GBufferPlanes") -> wire.GBufferTarget:
+        return wire.GBufferTarget(layer.pos_depth.data_ptr(), layer.nrm_scale.data_ptr(), layer.uv.data_ptr(),
+                                  layer.material_id.data_ptr())
+
+    def rasterize(self, draw_counts: torch.Tensor, draws, push: wire.PushConstants, opaque: "GBufferPlanes",
+                  transmissive: "GBufferPlanes"):
+        """The depth pre-passes + colour-pass rasterisation of src/main.rs:1900-2042 for explicit draw buffers."""
+        ptrs = (C.c_void_p * 4)(*[d.data_ptr() for d in draws])
+        to, tt = self._target(opaque), self._target(transmissive)
+        self._check(self.lib.tr_rasterize(self._ctx, draw_counts.data_ptr(), C.byref(ptrs), C.byref(push), C.byref(to),
+                                          C.byref(tt), self._stream()), "tr_rasterize")
+
+    def draw_scene(self, culling: wire.CullingPushConstants, push: wire.PushConstants, opaque: "GBufferPlanes",
+                   transmissive: "GBufferPlanes"):
+        """Culling + demultiplex + rasterisation of the uploaded geometry into the two layers."""
+        to, tt = self._target(opaque), self._target(transmissive)
+        self._check(self.lib.tr_draw_scene(self._ctx, C.byref(culling), C.byref(push), C.byref(to), C.byref(tt),
+                                           self._stream()), "tr_draw_scene")
+
     # ---- GPU culling (src/main.rs:1716-1763, 1811-1838)
     def frustum_culling(self, primitives: torch.Tensor, instances: torch.Tensor, push: wire.CullingPushConstants):
         """primitives / instances: uint8 device tensors holding PrimitiveInfo / Instance records.

@@ -236,6 +236,16 @@ class CullingPushConstants(C.Structure):  # shared-structs/src/lib.rs:270-279
         return out
 
 
+class GeometryDesc(C.Structure):  # include/tr_shade.h tr_geometry_desc
+    _fields_ = [("position", C.c_void_p), ("normal", C.c_void_p), ("uv", C.c_void_p), ("num_vertices", C.c_uint32),
+                ("index", C.c_void_p), ("num_indices", C.c_uint32), ("primitives", C.c_void_p),
+                ("num_primitives", C.c_uint32), ("instances", C.c_void_p), ("num_instances", C.c_uint32)]
+
+
+class GBufferTarget(C.Structure):  # include/tr_shade.h tr_gbuffer_target
+    _fields_ = [("pos_depth", C.c_void_p), ("nrm_scale", C.c_void_p), ("uv", C.c_void_p), ("material_id", C.c_void_p)]
+
+
 class TextureDesc(C.Structure):  # include/tr_shade.h tr_texture_desc
     _fields_ = [
         ("rgba8", C.c_void_p),
