@@ -204,3 +204,25 @@ def test_raster_error_paths(ggx_lut):
     fresh.draw_scene(culling, sc["push"], o, t)
     torch.cuda.synchronize()
     fresh.close()
+
+
+def test_cli_gltf_in_frame_out(tmp_path):
+    """The reference's CLI shape on a glTF file: culling -> rasteriser -> clusters -> opaque -> mips -> transmission
+    -> tonemap -> PNG, all on the GPU."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_demo_gltf
+    from transmission_renderer_amd import cli
+    from transmission_renderer_amd.png import read_png
+    glb, out = str(tmp_path / "demo.glb"), str(tmp_path / "frame.png")
+    make_demo_gltf.main(glb)
+    assert cli.main([glb, "--width", "320", "--height", "180", "--scale", "1.0", "--out", out,
+                     "--hdr-out", str(tmp_path / "hdr.npy")]) == 0
+    img = read_png(out)
+    assert img.shape == (180, 320, 4)
+    hdr = np.load(str(tmp_path / "hdr.npy")).astype(np.float32)
+    covered = hdr[..., :3].sum(axis=2) > 0
+    assert 0.2 < covered.mean() < 0.9 and np.isfinite(hdr).all()
+    assert len(np.unique(img.reshape(-1, 4), axis=0)) > 500          # an actual picture
+    assert cli.main(["NoSuchModel"]) == 2

@@ -1,17 +1,23 @@
-"""glTF-in/frame-out command line of the reference, for the part of the pipeline this repository covers.
+"""glTF-in/frame-out command line of the reference, on the MI355X path.
 
 The reference's CLI (`Opt`, src/main.rs:65-91) is
-    transmission-renderer [--scale f] [--roughness-override f] [--spotlights] ... <gltf_sample_model_name>
-and renders to a window.  Here the frame goes to a file and the scene source is a synthetic TGB-v1 G-buffer
-(`synthetic`): glTF import + rasterisation are SURVEY.md §8f row f3 and not built yet, so any other model name is
-refused rather than approximated.  Everything downstream of the G-buffer is the real path:
-cluster build -> main opaque -> mip chain -> transmissive pass -> tonemap -> PNG.
+    transmission-renderer [--scale f] [--roughness-override f] [--spotlights] [--external-model] <gltf_sample_model_name>
+and renders to a window.  Here the frame goes to a file.  Scene sources:
+    <path>.gltf / <path>.glb   a glTF 2.0 file (what `--external-model` gives the reference; the Khronos sample-model
+                               checkout the reference resolves bare names against is not in this image), placed like
+                               src/main.rs:364-368: translated to (0, 2, 0), scaled by --scale
+    meshes                     the procedural mesh scene (transmission_renderer_amd/meshes.py), same pipeline
+    synthetic                  a ready-made TGB-v1 G-buffer (the benchmark's input), no geometry stage
+Pipeline (every stage on the GPU through libtr_shade.so):
+    [frustum culling -> draw demultiplex -> vertex stage + rasteriser ->] cluster build -> main opaque ->
+    mip chain -> transmissive pass -> tonemap -> PNG
 
-    python -m transmission_renderer_amd.cli synthetic --width 1920 --height 1080 --lights 2 --out frame.png
+    python -m transmission_renderer_amd.cli meshes --width 1920 --height 1080 --out frame.png
 """
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 import time
 
@@ -20,8 +26,8 @@ import numpy as np
 
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="transmission_renderer_amd.cli", description=__doc__.split("\n\n")[0])
-    ap.add_argument("gltf_sample_model_name", help="'synthetic' (glTF import is not built yet)")
-    ap.add_argument("-s", "--scale", type=float, default=1.0, help="model scale (flat model_scale of every fragment)")
+    ap.add_argument("gltf_sample_model_name", help="a .gltf / .glb path, 'meshes' or 'synthetic'")
+    ap.add_argument("-s", "--scale", type=float, default=1.0, help="model scale (src/main.rs:364-368)")
     ap.add_argument("--roughness-override", type=float, default=None)
     ap.add_argument("--spotlights", action="store_true", help="add the reference's two spotlights (src/main.rs:455-476)")
     ap.add_argument("--width", type=int, default=1920)
@@ -31,46 +37,76 @@ def main(argv=None) -> int:
     ap.add_argument("--hdr-out", default=None, help="also save the RGBA16F HDR frame as .npy")
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
-    if args.gltf_sample_model_name != "synthetic":
-        print("only the 'synthetic' scene is available: glTF import / rasterisation (SURVEY.md 8f row f3) is not built",
-              file=sys.stderr)
+    name = args.gltf_sample_model_name
+    is_file = name.lower().endswith((".gltf", ".glb"))
+    if not is_file and name not in ("synthetic", "meshes"):
+        print(f"'{name}': give a .gltf / .glb path, 'meshes' or 'synthetic' (the glTF-Sample-Models checkout the "
+              "reference resolves bare names against is not available here)", file=sys.stderr)
+        return 2
+    if is_file and not os.path.exists(name):
+        print(f"{name}: no such file", file=sys.stderr)
         return 2
 
     import torch
-    from . import synthetic, wire
+    from . import gltf, meshes, synthetic, wire
     from .png import write_png
     from .renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer
 
     w, h = args.width, args.height
     r = TransmissionRenderer(args.device)
-    scene = synthetic.make_scene(w, h, num_point_lights=args.lights, roughness_override=args.roughness_override)
+    scene = synthetic.make_scene(w, h, num_point_lights=args.lights, roughness_override=args.roughness_override,
+                                 with_gbuffer=(name == "synthetic"), textured=(name == "meshes"))
     if args.spotlights:
         scene["lights"] = scene["lights"] + wire.default_lights(spotlights=True)[2:]
-    if args.scale != 1.0:
-        scene["gbuffer"]["nrm_scale"][..., 3] *= np.float32(args.scale)
-        for m in scene["materials"]:   # src/model_loading.rs:317: attenuation distance is pre-multiplied by the scale
-            m.attenuation_distance = m.attenuation_distance * args.scale
+    geometry = None
+    if name == "synthetic":
+        if args.scale != 1.0:
+            scene["gbuffer"]["nrm_scale"][..., 3] *= np.float32(args.scale)
+            for m in scene["materials"]:   # src/model_loading.rs:317: attenuation distance is pre-multiplied by the scale
+                m.attenuation_distance = m.attenuation_distance * args.scale
+    elif name == "meshes":
+        geometry = meshes.make_mesh_scene(extra_instances=True)
+        scene["materials"][2].alpha_clipping_cutoff = 0.75
+        scene["materials"][7].alpha_clipping_cutoff = 0.6
+    else:
+        loaded = gltf.load_gltf(name, base_transform=meshes.Similarity(np.array([0.0, 2.0, 0.0], np.float32), args.scale),
+                                roughness_override=args.roughness_override)
+        geometry = loaded.geometry()
+        scene["materials"] = loaded.materials or [wire.MaterialInfo.default()]
+        scene["textures"] = loaded.textures
     r.upload_ggx_lut()
     r.upload_materials(scene["materials"])
+    if scene.get("textures"):
+        r.upload_textures(scene["textures"])
     r.upload_lights(scene["lights"])
+    if geometry is not None:
+        r.upload_geometry(geometry)
     _, view = wire.default_camera()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     aabbs = r.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
     r.assign_lights_to_clusters(view, wire.view_rotation_inverse(view), aabbs)
-    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    if geometry is None:
+        # the synthetic scene has one layer: it is shaded as opaque geometry first (the backdrop the refraction
+        # sees), then as the transmissive layer in front of it
+        opaque = transmissive = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    else:
+        opaque, transmissive = r.new_layer(w, h), r.new_layer(w, h)
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+        r.draw_scene(culling, scene["push"], opaque, transmissive)
     pyr = OpaquePyramid(w, h, r.device)
     hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
-    # the synthetic scene has one layer: it is shaded as opaque geometry first (the backdrop the refraction sees),
-    # then as the transmissive layer in front of it
-    r.record(g, g, scene["uniforms"], scene["push"], hdr, pyr)
+    r.record(opaque, transmissive, scene["uniforms"], scene["push"], hdr, pyr)
     ldr = r.tonemap(hdr)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     write_png(args.out, ldr.cpu().numpy())
     if args.hdr_out:
         np.save(args.hdr_out, hdr.cpu().numpy())
-    print(f"{w}x{h}, sun + {len(scene['lights'])} lights: clusters + opaque + mips + transmission + tonemap in "
-          f"{dt * 1e3:.2f} ms (first call, includes launch overheads) -> {args.out}")
+    what = "clusters + " + ("" if geometry is None else "culling + rasteriser + ") + "opaque + mips + transmission + tonemap"
+    extra = "" if geometry is None else f", {len(geometry['index']) // 3} triangles in {len(geometry['primitives'])} primitives"
+    print(f"{w}x{h}, sun + {len(scene['lights'])} lights{extra}: {what} in {dt * 1e3:.2f} ms (first call, includes "
+          f"launch overheads) -> {args.out}")
     r.close()
     return 0
 

@@ -143,9 +143,10 @@ class ModelBuffers:
         self._num_vertices = 0
         self._num_indices = 0
 
-    def add_primitive(self, mesh: Mesh, draw_buffer_index: int, instances: Sequence[tuple]) -> int:
+    def add_primitive(self, mesh: Mesh, draw_buffer_index: int, instances: Sequence[tuple], bbox=None) -> int:
         """One PrimitiveInfo + its instances ([(Similarity, material_id), ...], contiguous from first_instance).
-        Bounding sphere from the bounding box, like src/model_loading.rs:146-153."""
+        Bounding sphere from the bounding box (`bbox` = (min, max), default: of the positions), like
+        src/model_loading.rs:146-153."""
         first_index = self._num_indices
         self.index.append(mesh.index.astype(np.uint32) + np.uint32(self._num_vertices))
         self.position.append(mesh.position.astype(f32))
@@ -153,7 +154,9 @@ class ModelBuffers:
         self.uv.append(mesh.uv.astype(f32))
         self._num_vertices += len(mesh.position)
         self._num_indices += len(mesh.index)
-        mn, mx = mesh.position.min(axis=0).astype(f32), mesh.position.max(axis=0).astype(f32)
+        if bbox is None:
+            bbox = (mesh.position.min(axis=0), mesh.position.max(axis=0))
+        mn, mx = np.asarray(bbox[0], f32), np.asarray(bbox[1], f32)
         center = ((mn + mx) / f32(2.0)).astype(f32)
         d = (mn - mx).astype(f32)
         radius = f32(f32(np.sqrt(f32(f32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]))) / f32(2.0))

@@ -51,12 +51,10 @@ def _unfilter(raw: np.ndarray, height: int, stride: int, bpp: int) -> np.ndarray
     return out
 
 
-def read_png(path: str) -> np.ndarray:
-    """Returns an (H, W, C) uint8 array (C = 1, 2, 3 or 4)."""
-    with open(path, "rb") as f:
-        data = f.read()
+def decode_png(data: bytes, what: str = "<bytes>") -> np.ndarray:
+    """Returns an (H, W, C) uint8 array (C = 1, 2, 3 or 4) from the bytes of an 8-bit non-interlaced PNG."""
     if data[:8] != _SIG:
-        raise ValueError(f"{path}: not a PNG")
+        raise ValueError(f"{what}: not a PNG")
     pos = 8
     idat = []
     width = height = ctype = None
@@ -68,7 +66,7 @@ def read_png(path: str) -> np.ndarray:
         if kind == b"IHDR":
             width, height, depth, ctype, _comp, _filt, interlace = struct.unpack(">IIBBBBB", body)
             if depth != 8 or interlace != 0 or ctype not in _CHANNELS:
-                raise ValueError(f"{path}: unsupported PNG (depth {depth}, colour type {ctype}, interlace {interlace})")
+                raise ValueError(f"{what}: unsupported PNG (depth {depth}, colour type {ctype}, interlace {interlace})")
         elif kind == b"IDAT":
             idat.append(body)
         elif kind == b"IEND":
@@ -79,9 +77,12 @@ def read_png(path: str) -> np.ndarray:
     return img.reshape(height, width, ch)
 
 
-def read_png_rgba8(path: str) -> np.ndarray:
-    """(H, W, 4) uint8; RGB gets alpha 255 (src/model_loading.rs:36-52 does the same widening)."""
-    img = read_png(path)
+def read_png(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        return decode_png(f.read(), path)
+
+
+def _to_rgba8(img: np.ndarray) -> np.ndarray:
     h, w, c = img.shape
     if c == 4:
         return np.ascontiguousarray(img)
@@ -94,6 +95,15 @@ def read_png_rgba8(path: str) -> np.ndarray:
         out[..., :3] = img[..., :1]
         out[..., 3] = img[..., 1]
     return out
+
+
+def read_png_rgba8(path: str) -> np.ndarray:
+    """(H, W, 4) uint8; RGB gets alpha 255 (src/model_loading.rs:36-52 does the same widening)."""
+    return _to_rgba8(read_png(path))
+
+
+def read_png_rgba8_bytes(data: bytes) -> np.ndarray:
+    return _to_rgba8(decode_png(data))
 
 
 def write_png(path: str, img: np.ndarray) -> None:
