@@ -36,6 +36,20 @@ __device__ __forceinline__ T* launder(T* p) {
     return p;
 }
 
+// Memory access as (uniform base pointer in scalar registers) + (32-bit byte offset per lane): the addressing form
+// global_load / global_store take directly (saddr + voffset), so an access costs the one or two instructions that
+// form the offset instead of 64-bit pointer arithmetic in vector registers.  Every buffer of the hot kernels is
+// below 4 GiB (checked on the host).  Products of coordinates (< 2^24) use the full-rate 24-bit multiply-add.
+template <class T>
+__device__ __forceinline__ T ld(const void* base, uint32_t byte_offset) {
+    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset);
+}
+template <class T>
+__device__ __forceinline__ void st(void* base, uint32_t byte_offset, T value) {
+    *reinterpret_cast<T*>(static_cast<char*>(base) + byte_offset) = value;
+}
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+
 // ------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }

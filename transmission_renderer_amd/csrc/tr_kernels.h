@@ -322,7 +322,7 @@ __device__ __forceinline__ void pyramid_issue_levels(pyramid_fetch& pf, const ui
                                                      clevels* lv, uint32_t levels, float u, float v, uint32_t l0) {
     const uint32_t l1 = min(l0 + 1u, levels - 1u);
     const uint32_t w0 = lv->width[l0], w1 = lv->width[l1];
-    const uint2* b0 = texels + lv->offset[l0];
+    const uint2* b0 = texels + lv->offset[l0];   // (scalar) level bases
     const uint2* b1 = texels + lv->offset[l1];
     uint32_t bx[2];
     axis_pair(u, v2f{lv->wf[l0], lv->wf[l1]}, v2f{lv->xlim[l0], lv->xlim[l1]}, pf.wx, bx);
@@ -331,14 +331,14 @@ __device__ __forceinline__ void pyramid_issue_levels(pyramid_fetch& pf, const ui
     axis_single(v, lv->hf[l0], wy0, y00, y01);
     axis_single(v, lv->hf[l1], wy1, y10, y11);
     pf.wy = v2f{wy0, wy1};
-    auto ld = [](const uint2* p) {
-        u32x4 t = *reinterpret_cast<const u32x4_a8*>(p);  // one global_load_dwordx4
+    auto ld2 = [](const uint2* level, uint32_t texel) {
+        u32x4 t = ld<u32x4_a8>(level, texel * 8u);  // one global_load_dwordx4, saddr + voffset
         return uint4{t.x, t.y, t.z, t.w};
     };
-    pf.r0[0] = ld(b0 + y00 * w0 + bx[0]);
-    pf.r1[0] = ld(b0 + y01 * w0 + bx[0]);
-    pf.r0[1] = ld(b1 + y10 * w1 + bx[1]);
-    pf.r1[1] = ld(b1 + y11 * w1 + bx[1]);
+    pf.r0[0] = ld2(b0, mad24(y00, w0, bx[0]));
+    pf.r1[0] = ld2(b0, mad24(y01, w0, bx[0]));
+    pf.r0[1] = ld2(b1, mad24(y10, w1, bx[1]));
+    pf.r1[1] = ld2(b1, mad24(y11, w1, bx[1]));
     pf.narrow0 = w0 < 2u;
     pf.narrow1 = w1 < 2u;
 }
@@ -421,8 +421,8 @@ __device__ __forceinline__ void lut_issue(lut_fetch& lf, const uint32_t* __restr
     float fl = floorf(x);
     lf.fx = x - fl;
     uint32_t k = (uint32_t)((int)fl + 1);
-    lf.p0 = pairs[m.lut_row0 + k];
-    lf.p1 = pairs[m.lut_row1 + k];
+    lf.p0 = ld<uint32_t>(pairs, (m.lut_row0 + k) * 4u);
+    lf.p1 = ld<uint32_t>(pairs, (m.lut_row1 + k) * 4u);
 }
 __device__ __forceinline__ v2f lut_resolve(const lut_fetch& lf, float fy) {
     auto b = [](uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); };
@@ -531,12 +531,12 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     // The light count and the first list entry are requested here so that they are back long before the loop.
     const float zs = fmaf(-L->fp.lcc_scale, fast_log2(fmaf(pd.w, L->fp.slice_a, L->fp.slice_b)), L->fp.slice_k);
     const uint32_t cz = (uint32_t)fmaxf(zs, 0.0f);  // v_cvt_u32_f32 saturates, NaN -> 0 (Rust `as u32`)
-    const uint32_t cluster = cz * L->fp.clusters_xy + cluster_xy;
+    const uint32_t cluster = mad24(cz, L->fp.clusters_xy, cluster_xy);   // (cz saturates far below 2^24 * clusters_xy)
     const bool in_range = cluster < L->fp.num_clusters_total;  // out-of-range reads as 0 lights (robust access)
     const uint32_t csafe = in_range ? cluster : 0u;
-    const uint32_t* indices = L->light_indices + (size_t)csafe * TR_MAX_LIGHTS_PER_CLUSTER;  // per-lane reads
-    uint32_t num_lights = L->cluster_counts[csafe];
-    const uint4 list4 = *reinterpret_cast<const uint4*>(indices);  // the first four entries (lists are 512-byte aligned)
+    const uint32_t list_offset = csafe * (TR_MAX_LIGHTS_PER_CLUSTER * 4u);   // byte offset of this lane's list
+    uint32_t num_lights = ld<uint32_t>(L->cluster_counts, csafe * 4u);
+    const uint32_t first_light = ld<uint32_t>(L->light_indices, list_offset);
     num_lights = in_range ? num_lights : 0u;
     if (TR_ABLATE(L, 8u)) num_lights = 0;
 
@@ -590,14 +590,14 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         // punctual lights (lighting.rs:55-92 / 179-217)
         cdlight* lights = as_constant(L2->lights);
         uint32_t i = 0;
-        uint32_t head = list4.x;
+        uint32_t head = first_light;
         uint64_t pending = __ballot(i < num_lights);
         while (pending) {
             const int l0 = __ffsll((unsigned long long)pending) - 1;
             const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)head, l0);
             const uint64_t group = __ballot(i < num_lights && head == h0);
             if ((group >> lane) & 1ull) {  // membership from the mask keeps h0 scalar (see shade_kernel)
-                const uint32_t next = indices[min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u)];  // in flight during the eval
+                const uint32_t next = ld<uint32_t>(L2->light_indices, list_offset + min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u) * 4u);  // in flight during the eval
                 eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px, transmits);
                 ++i;
                 head = next;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         t.px = F->fp.rect_x0 + txi * 64u + lx;
         t.py = F->fp.rect_y0 + tyi * 4u + ly;
         const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
-        const size_t gpix = (size_t)(cy - F->fp.g_origin_y) * F->fp.g_width + (cx - F->fp.g_origin_x);
+        const uint32_t gpix = mad24(cy - F->fp.g_origin_y, F->fp.g_width, cx - F->fp.g_origin_x);
         if (TR_ABLATE(F, 64u)) {  // profiling only: no G-buffer traffic (synthetic per-lane inputs)
             t.mat = (tile >> 5) & 15u;
             t.pd = float4{(float)cx * 1e-3f - 1.5f, 2.0f + (float)cy * 1e-3f, -2.0f, 0.004f};
@@ -812,12 +812,12 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
             t.cluster_x = 5; t.cluster_y_term = 0;
             return;
         }
-        t.mat = F->material_id[gpix];
-        t.pd = F->pos_depth[gpix];
-        t.ns = F->nrm_scale[gpix];
-        if constexpr (TEXTURED) t.uv = F->uv[gpix];
-        t.cluster_x = (uint32_t)F->cluster_x[cx];
-        t.cluster_y_term = F->cluster_y_term[cy];
+        t.mat = ld<uint32_t>(F->material_id, gpix * 4u);
+        t.pd = ld<float4>(F->pos_depth, gpix * 16u);
+        t.ns = ld<float4>(F->nrm_scale, gpix * 16u);
+        if constexpr (TEXTURED) t.uv = ld<float2>(F->uv, gpix * 8u);
+        t.cluster_x = (uint32_t)ld<uint16_t>(F->cluster_x, cx * 2u);
+        t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
     };
 
     uint32_t j = blockIdx.x >> 3;
@@ -886,13 +886,12 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         if ((TRANSMISSIVE ? active : inside) && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
             claunch* W = launder(L);
-            const size_t pix = (size_t)cur.py * W->fp.width + cur.px;
-            OutT* hdr = (OutT*)W->hdr;
-            if constexpr (sizeof(OutT) == 8) hdr[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
-            else hdr[pix] = OutT{out.x, out.y, out.z, 1.0f};
+            const uint32_t pix = mad24(cur.py, W->fp.width, cur.px);
+            if constexpr (sizeof(OutT) == 8) st<uint2>(W->hdr, pix * 8u, pack_rgba16f(out.x, out.y, out.z, 1.0f));
+            else st<OutT>(W->hdr, pix * 16u, OutT{out.x, out.y, out.z, 1.0f});
             if constexpr (!TRANSMISSIVE) {
                 uint2* mip0 = W->mip0;
-                if (mip0) mip0[pix] = pack_rgba16f(out.x, out.y, out.z, 1.0f);
+                if (mip0) st<uint2>(mip0, pix * 8u, pack_rgba16f(out.x, out.y, out.z, 1.0f));
             }
         }
         cur = nxt;

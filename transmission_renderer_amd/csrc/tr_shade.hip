@@ -233,6 +233,10 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     if (rect.x0 < g->origin_x || rect.y0 < g->origin_y || rect.x1 > g->origin_x + g->width ||
         rect.y1 > g->origin_y + g->height)
         return TR_ERR_INVALID_ARGUMENT;  // the tile must be covered by the planes this rank holds
+    // the kernels address every buffer as base + 32-bit byte offset and multiply coordinates with 24-bit operands
+    if ((uint64_t)fw * fh * 16u > 0xFFFFFFFFull || (uint64_t)g->width * g->height * 16u > 0xFFFFFFFFull ||
+        fw >= (1u << 24) || fh >= (1u << 24) || (uint64_t)ctx->num_clusters_total * TR_MAX_LIGHTS_PER_CLUSTER * 4u > 0xFFFFFFFFull)
+        return TR_ERR_UNSUPPORTED;
     std::memset(fp, 0, sizeof(*fp));
     std::memcpy(fp->proj_view, pc->proj_view, sizeof(fp->proj_view));
     std::memcpy(fp->view_position, pc->view_position, sizeof(fp->view_position));
@@ -449,7 +453,7 @@ tr_status tr_pyramid_layout(uint32_t width, uint32_t height, tr_pyramid* out, si
         out->level_offset[l] = (uint32_t)off;
         off += (uint64_t)level_dim(width, l) * level_dim(height, l);
     }
-    if (off > 0xFFFFFFFFull) return TR_ERR_UNSUPPORTED;
+    if ((off + 1u) * 8u > 0xFFFFFFFFull) return TR_ERR_UNSUPPORTED;   // sampled with 32-bit byte offsets
     // + one texel of tail padding: the sampler reads texels in 16-byte pairs and may touch (never use) the 8
     // bytes after the last texel of the last level
     if (out_bytes) *out_bytes = (size_t)(off + 1u) * 8u;
