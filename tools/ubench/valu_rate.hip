@@ -25,6 +25,38 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b) {
                                       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
         if (KIND == 7) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_floor_f32 %4, %4\n v_floor_f32 %5, %5\n v_cvt_u32_f32 %6, %6\n v_cvt_f32_ubyte0 %7, %7"
                                       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) :: "vcc"); }
+        if (KIND == 8) { asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 9) { asm volatile("v_sub_f32 %0, %0, %1\n v_sub_f32 %1, %1, %2\n v_sub_f32 %2, %2, %3\n v_sub_f32 %3, %3, %4\n v_max_f32 %4, %4, %5\n v_max_f32 %5, %5, %6\n v_min_f32 %6, %6, %7\n v_min_f32 %7, %7, %0"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 10) { asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_lt_f32 vcc, %2, %3\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_lt_f32 vcc, %4, %5\n v_cndmask_b32 %4, %4, %5, vcc\n v_cmp_lt_f32 vcc, %6, %7\n v_cndmask_b32 %6, %6, %7, vcc"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) :: "vcc"); }
+        if (KIND == 11) { asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %2, %3, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %3, %4, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %5, %6, %4 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %6, %7, %5 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %6, %7, %0, %6 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %0, %1, %7 op_sel_hi:[1,0,0]"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 12) { asm volatile("v_add_u32 %0, %0, %1\n v_lshlrev_b32 %1, 2, %1\n v_and_b32 %2, %2, %3\n v_mul_u32_u24 %3, %3, %4\n v_mad_u32_u24 %4, %4, %5, %6\n v_add_lshl_u32 %5, %5, %6, 3\n v_min_u32 %6, %6, %7\n v_add_u32 %7, %7, %0"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 13) { asm volatile("v_fma_f32 %0, %8, %0, %1\n v_fma_f32 %1, %8, %1, %2\n v_fma_f32 %2, %9, %2, %3\n v_fma_f32 %3, %9, %3, %4\n v_mul_f32 %4, 0x3b808081, %4\n v_mul_f32 %5, %8, %5\n v_fmac_f32 %6, %9, %7\n v_fmac_f32 %7, %8, %0"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "s"(b)); }
+        if (KIND == 14) { asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %4\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %4, %4, %5, %6\n v_fma_f32 %5, %5, %6, %7\n v_fma_f32 %6, %6, %7, %0\n v_fma_f32 %7, %7, %0, %1"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 15) { asm volatile("v_mul_f32 %0, %0, %1\n v_fmac_f32 %1, %1, %2\n v_mul_f32 %2, %2, %3\n v_fmac_f32 %3, %3, %4\n v_add_f32 %4, %4, %5\n v_mul_f32 %5, %5, %6\n v_add_f32 %6, %6, %7\n v_mul_f32 %7, %7, %0"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 16) { asm volatile("v_fma_f32 %0, %8, %0, %1\n v_fma_f32 %1, %8, %1, %2\n v_fma_f32 %2, %9, %2, %3\n v_fma_f32 %3, %9, %3, %4\n v_fma_f32 %4, %8, %4, %5\n v_fma_f32 %5, %8, %5, %6\n v_fma_f32 %6, %9, %6, %7\n v_fma_f32 %7, %9, %7, %0"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "s"(b)); }
+        if (KIND == 17) { asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_add_f32 %2, %9, %2\n v_add_f32 %3, %9, %3\n v_mul_f32 %4, %8, %4\n v_sub_f32 %5, %8, %5\n v_max_f32 %6, %9, %6\n v_fmac_f32 %7, %9, %0"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "s"(b)); }
+        if (KIND == 18) { asm volatile("v_mul_f32 %0, 0x3b808081, %0\n v_mul_f32 %1, 0x3b808081, %1\n v_add_f32 %2, 0x3b808081, %2\n v_max_f32 %3, 0x34000000, %3\n v_mul_f32 %4, 0x3b808081, %4\n v_max_f32 %5, 0x34000000, %5\n v_add_f32 %6, 0x3b808081, %6\n v_mul_f32 %7, 0x3b808081, %7"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 19) { asm volatile("v_mul_f32 %0, 2.0, %0\n v_add_f32 %1, 1.0, %1\n v_sub_f32 %2, 1.0, %2\n v_max_f32 %3, 0, %3\n v_mul_f32 %4, 0.5, %4\n v_fma_f32 %5, %5, 2.0, 2.0\n v_add_f32 %6, -1.0, %6\n v_mul_f32 %7, 4.0, %7"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 20) { asm volatile("v_fma_f32 %0, -%0, %1, %2\n v_fma_f32 %1, %1, -%2, %3\n v_mul_f32_e64 %2, %2, -%3\n v_fma_f32 %3, %3, %4, -%5\n v_max_f32_e64 %4, -%4, -%5\n v_fma_f32 %5, -%5, %6, 1.0\n v_mul_f32_e64 %6, -%6, %7\n v_fma_f32 %7, |%7|, %0, %1"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
+        if (KIND == 21) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %5, %5, %6, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %0, vcc"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) :: "vcc"); }
+        if (KIND == 22) { asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %4\n v_cmp_lt_f32 vcc, %4, %5\n v_cmp_lt_f32 vcc, %5, %6\n v_cmp_lt_f32 vcc, %6, %7\n v_cmp_lt_f32 vcc, %7, %0"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) :: "vcc"); }
+        if (KIND == 23) { asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_floor_f32 %2, %2\n v_floor_f32 %3, %3\n v_cvt_u32_f32 %4, %4\n v_cvt_f32_u32 %5, %5\n v_cvt_pk_f16_f32 %6, %6, %7\n v_cvt_f32_ubyte0 %7, %7"
+                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); }
     }
     out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
 }
@@ -41,8 +73,13 @@ template <int KIND> void run(const char* name, int blocks, float* d) {
 }
 int main() {
     float* d; hipMalloc(&d, 8192 * 256 * 4);
-    for (int blocks : {1024, 2048}) {
+    for (int blocks : {8192}) {
         run<0>("v_fma_f32", blocks, d); run<1>("v_pk_fma_f32", blocks, d); run<4>("v_mul/add_f32", blocks, d); run<3>("v_max/min_f32", blocks, d);
+        run<14>("v_fma_f32 (3 vgpr srcs)", blocks, d); run<15>("v_mul/fmac/add 2-src vgpr", blocks, d); run<13>("fma/mul with sgpr/literal", blocks, d);
+        run<8>("v_mov_b32", blocks, d); run<9>("v_sub/max/min_f32", blocks, d); run<10>("v_cmp+v_cndmask", blocks, d); run<11>("v_fma_mix_f32", blocks, d); run<12>("int add/shift/and/mul24", blocks, d);
+        run<16>("v_fma_f32 sgpr src", blocks, d); run<17>("VOP2 mul/add/sub/max sgpr src0", blocks, d); run<18>("VOP2 with 32-bit literal", blocks, d);
+        run<19>("inline constants", blocks, d); run<20>("VOP3 neg/abs modifiers", blocks, d); run<21>("v_cndmask_b32", blocks, d); run<22>("v_cmp_lt_f32", blocks, d);
+        run<23>("max3/floor/cvt", blocks, d);
         run<2>("v_rcp_f32", blocks, d); run<6>("sqrt/rsq/exp/log", blocks, d); run<5>("v_cvt_f32_f16", blocks, d); run<7>("cndmask/floor/cvt", blocks, d);
     }
     return 0;

@@ -1,16 +1,15 @@
 // tr_kernels.h — gfx950 (CDNA4, wave64) device code of the transmission/volume PBR shading path.
 //
 // Shape of the work
-//   One thread shades one pixel; a wave is a 64x1 pixel row segment, so every G-buffer plane is
-//   read as one contiguous 1 KiB / 256 B burst per wave and the RGBA16F target is written as one
-//   512 B burst; a 256-thread workgroup is a 64x4 screen tile.  Workgroups are renumbered so that
-//   each XCD (own L2) owns a contiguous band of the screen: the data-dependent taps into the
-//   opaque pyramid then re-use texel rows inside one L2 instead of being fetched by all eight.
+//   One thread shades one pixel; a wave is a 16x4 pixel tile (four 256 B row segments per float4 plane, one 128 B
+//   segment of the RGBA16F target per row), a 256-thread workgroup a 64x4 screen tile.  Workgroups are persistent
+//   and renumbered so that each XCD (own L2) owns a contiguous band of the screen: the data-dependent taps into
+//   the opaque pyramid then re-use texel rows inside one L2 instead of being fetched by all eight.
 //
-// What bounds it (rocprofv3 PMC, profiles/r01): the path is VALU-issue bound, not HBM bound — a
-// gfx950 SIMD retires one wave64 fp32 instruction per 4 cycles unless it is a packed
-// (v_pk_{fma,mul,add}_f32) one.  So the math is arranged to be short and packable, NOT as a
-// transliteration of the reference:
+// What bounds it (rocprofv3 PMC, profiles/r01): VALU issue and latency, not HBM — ~510 vector instructions per
+// pixel against 60 B of traffic.  So the math is arranged to be short, NOT as a transliteration of the reference,
+// and the kernel is kept at 64 VGPRs (8 waves per SIMD), because resident waves are what hides the scalar-load,
+// G-buffer and tap latencies:
 //   * everything that depends only on the material is digested once per upload into `tr_dmat`
 //     and read through the scalar unit: a wave handles one material at a time (waves that
 //     straddle several run a waterfall loop over them), so there is a single code path and the
@@ -19,13 +18,15 @@
 //       |v+l|^2 = 2+2 v.l,  v.h = (1+v.l)/|v+l|,  1-(n.h)^2 = |n x (v+l)|^2/|v+l|^2
 //     (the last form keeps d_ggx well conditioned at low roughness); the mirrored light of
 //     transmission_btdf needs no vector at all (n.l' = -n.l, v.l' = v.l - 2 n.l n.v, and
-//     n x (v+l') = n x (v+l)), so the basic_brdf lobe and the btdf lobe are the two halves of the
-//     same packed instructions;  D*V is one reciprocal per lobe, x^5 three multiplies;
-//   * the two mip levels of the trilinear tap, and the two channels of the GGX LUT, are likewise
-//     the two halves of packed instructions; horizontally adjacent texels come in one 16-byte load;
+//     n x (v+l') = n x (v+l)), so the two lobes share the vector work;  D*V is one reciprocal per lobe,
+//     x^5 three multiplies.  (On gfx950 v_pk_fma_f32 issues at half the rate of v_fma_f32 — tools/ubench —
+//     so packing buys nothing: the build disables packed-fp32 selection.)
+//   * horizontally adjacent texels come in one 16-byte load, filtered as one weighted sum of v_fma_mix_f32;
 //   * the cluster x / y lookups are exact tables (built with the reference's own IEEE division on
 //     the host), the depth slice is one v_log_f32;
-//   * the pyramid / LUT taps are issued before the light loop and consumed after it.
+//   * every buffer is addressed as scalar base + 32-bit byte offset (saddr/voffset loads, 24-bit multiply-adds);
+//   * the pyramid / LUT taps are issued after the light loop (see shade_pixel) and there is no register
+//     prefetch of the next tile: both were worth less than the two extra waves their registers cost.
 // These differ from the reference's op order by a few ulp of fp32 (and are closer to exact
 // arithmetic where the reference is ill-conditioned); parity criteria: tests/test_gpu_parity.py.
 //
@@ -49,7 +50,7 @@ namespace tr {
 #endif
 #define TR_ABLATE(L, bit) (TR_ABLATION && ((L)->fp.ablate & (bit)))
 
-// ---------------------------------------------------------------- digested material (160 B)
+// ---------------------------------------------------------------- digested material (176 B)
 // Index 0 of every pair belongs to the basic_brdf lobe, index 1 to the transmission_btdf lobe.
 struct alignas(16) tr_dmat {
     float diffuse[3];      // diffuse_factor.rgb (base colour)
@@ -73,9 +74,11 @@ struct alignas(16) tr_dmat {
                            // bit2: the material has texture slots (shaded by the per-pixel material path)
     float ior_clamp;       // clamp(2 ior - 2, 0, 1)
     float f0_dielectric;   // ((ior - 1) / (ior + 1))^2
-    uint32_t _pad[5];
+    float bt_a[3];         // k[1] * (1 - f0): the btdf lobe is accumulated as sum(I D'V') and sum(I D'V' p') and
+    float bt_b[3];         // k[1] * (f90 - f0): resolved once per pixel as bt_a * sum1 - bt_b * sum2
+    uint32_t _pad[3];
 };
-static_assert(sizeof(tr_dmat) == 160, "digested material is 160 B");
+static_assert(sizeof(tr_dmat) == 176, "digested material is 176 B");
 
 // Light as the kernels read it: the reference's 48-byte record (shared-structs/src/lib.rs:70-78)
 // with the per-light constants of spotlight_factor (:129-138) digested at upload.
@@ -158,7 +161,7 @@ typedef const TR_CONSTANT tr_launch claunch;
 // per lane (vector registers), digested per pixel from the sampled factors.
 struct lane_dmat {
     float diffuse[3], f90, c_diff[3], eta, f0[3], transmission_factor, df[3], thickness, emission[3], rough_ior;
-    float neg_atten_log2[3], lut_fy, a2[2], oma2[2], k[2];
+    float neg_atten_log2[3], lut_fy, a2[2], oma2[2], k[2], bt_a[3], bt_b[3];
     uint32_t lut_row0, lut_row1, flags;
 };
 __device__ __forceinline__ const lane_dmat* launder(const lane_dmat* p) { return p; }
@@ -167,7 +170,9 @@ __device__ __forceinline__ const lane_dmat* launder(const lane_dmat* p) { return
 // Accumulators of one pixel over its lights.
 struct light_acc {
     f3 d;        // sum I * nol * (1 - max(F))                     (x c_diff/pi at the end)
-    v2f st[3];   // per channel: { sum I * nol * D*V * F ,  sum I * (1 - F') * D_t*V_t }
+    f3 s;        // sum I * nol * D*V * F                          (basic_brdf specular)
+    f3 ta, tb;   // sum I * D'V'/k' and sum I * D'V'/k' * p'       (transmission_btdf: (1 - F') is linear in p', so the
+                 //  lobe is resolved once per pixel: bt_a * ta - bt_b * tb; the per-light work has no scalar operand)
 };
 
 // One light against one pixel: basic_brdf (+ transmission_btdf when TRANSMISSIVE), the two lobes
@@ -210,17 +215,18 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
         // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal
         const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(nol * nol, m.oma2[0], m.a2[0])));
-        float dv = m.k[0] * rcp(f * f * g);
-        dv = g > 0.0f ? dv : 0.0f;
+        // (g > 0 always: n.l, n.v are clamped to EPSILON and the roots are positive, so v_smith's `denom <= 0`
+        //  guard, :125-131, cannot trigger; a NaN propagates like in the reference)
+        const float dv = m.k[0] * rcp(f * f * g);
         const float Fx = fmaf(m.df[0], p, m.f0[0]), Fy = fmaf(m.df[1], p, m.f0[1]), Fz = fmaf(m.df[2], p, m.f0[2]);
         const float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));  // diffuse_brdf :356-360
         const float ws = nol * dv;                                 // specular_brdf :362-375 (weighted by n.l :414-421)
         acc.d.x = fmaf(I.x, wd, acc.d.x);
         acc.d.y = fmaf(I.y, wd, acc.d.y);
         acc.d.z = fmaf(I.z, wd, acc.d.z);
-        acc.st[0].x = fmaf(I.x * ws, Fx, acc.st[0].x);
-        acc.st[1].x = fmaf(I.y * ws, Fy, acc.st[1].x);
-        acc.st[2].x = fmaf(I.z * ws, Fz, acc.st[2].x);
+        acc.s.x = fmaf(I.x * ws, Fx, acc.s.x);
+        acc.s.y = fmaf(I.y * ws, Fy, acc.s.y);
+        acc.s.z = fmaf(I.z * ws, Fz, acc.s.z);
     }
     // ---- lobe 1: transmission_btdf (:200-233): the light mirrored about the surface,
     //      n.l' = -(n.l), v.l' = v.l - 2 (n.l)(n.v); no vector is formed.  For the mirrored light |v+l'|^2
@@ -239,11 +245,14 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
             const float sin2 = c2 * (inv_h * inv_h);
             const float f = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - sin2, sin2) : 1.0f;
             const float g = fmaf(nolm, px.g_nov.y, nov * fast_sqrt(fmaf(nolm * nolm, m.oma2[1], m.a2[1])));
-            float dv = m.k[1] * rcp(f * f * g);
-            dv = g > 0.0f ? dv : 0.0f;                               // not weighted by n.l (:232)
-            acc.st[0].y = fmaf(I.x * dv, 1.0f - fmaf(m.df[0], p, m.f0[0]), acc.st[0].y);
-            acc.st[1].y = fmaf(I.y * dv, 1.0f - fmaf(m.df[1], p, m.f0[1]), acc.st[1].y);
-            acc.st[2].y = fmaf(I.z * dv, 1.0f - fmaf(m.df[2], p, m.f0[2]), acc.st[2].y);
+            const float r = rcp(f * f * g);                          // D'V' / k[1]; not weighted by n.l (:232)
+            const float tx = I.x * r, ty = I.y * r, tz = I.z * r;
+            acc.ta.x += tx;
+            acc.ta.y += ty;
+            acc.ta.z += tz;
+            acc.tb.x = fmaf(tx, p, acc.tb.x);
+            acc.tb.y = fmaf(ty, p, acc.tb.y);
+            acc.tb.z = fmaf(tz, p, acc.tb.z);
         }
     }
 }
@@ -481,6 +490,8 @@ __device__ __forceinline__ void digest_factors(D& d, float metallic, float rough
         const float ds = f0d * spec_colour[k] * specular_factor;
         d.f0[k] = ds + (diff - ds) * metallic;                       // calculate_combined_f0
         d.df[k] = d.f90 - d.f0[k];
+        d.bt_a[k] = d.k[1] * (1.0f - d.f0[k]);
+        d.bt_b[k] = d.k[1] * d.df[k];
     }
     d.rough_ior = rough * ior_clamp;                                 // PerceptualRoughness::apply_ior :157-159
     // GGX LUT row (v = perceptual roughness; bilinear, clamp to edge)
@@ -548,6 +559,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     // transmission_factor == 0 (scalar): lib.rs:157-159 multiplies the whole transmission term by zero, so the
     // refraction taps, the LUT and the btdf lobes are skipped for such materials
     const bool transmits = TRANSMISSIVE && (m->flags & 2u);
+    auto issue_taps = [&]() {
     if (transmits) {
         // refract(-v, n, ior) :248-256 ; unit length by construction (Snell), so no re-normalise
         float eta = m->eta;
@@ -570,12 +582,13 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         if (!TR_ABLATE(L, 2u)) lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, *m, nov_raw);
         else { lf.p0 = lf.p1 = 0x40404040u; lf.fx = nov_raw; }
     }
+    };
 
     // ================= phases 2+3: the sun, then the clustered punctual lights =================
     // Every lane walks its own cluster's list; at each step the lanes whose next light index equals that of the
     // first pending lane evaluate it together, with the light read through the scalar unit.  When the lists
     // agree (the normal case, also across cluster boundaries) that is one pass per light.
-    light_acc acc = {{0.f, 0.f, 0.f}, {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}};
+    light_acc acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto lights_phase = [&]() {
         claunch* L2 = launder(L);
         MatP m2 = launder(m);
@@ -622,9 +635,12 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
             const v2f AB = lut_resolve(lf, m4->lut_fy);
             // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
             const float fb = m4->f90 * AB.y;
-            float tx = fmaf(1.0f - fmaf(m4->f0[0], AB.x, fb), T.x, acc.st[0].y) * m4->diffuse[0];
-            float ty = fmaf(1.0f - fmaf(m4->f0[1], AB.x, fb), T.y, acc.st[1].y) * m4->diffuse[1];
-            float tz = fmaf(1.0f - fmaf(m4->f0[2], AB.x, fb), T.z, acc.st[2].y) * m4->diffuse[2];
+            const float bx = fmaf(-m4->bt_b[0], acc.tb.x, m4->bt_a[0] * acc.ta.x);   // sum over lights of transmission_btdf
+            const float by = fmaf(-m4->bt_b[1], acc.tb.y, m4->bt_a[1] * acc.ta.y);
+            const float bz = fmaf(-m4->bt_b[2], acc.tb.z, m4->bt_a[2] * acc.ta.z);
+            float tx = fmaf(1.0f - fmaf(m4->f0[0], AB.x, fb), T.x, bx) * m4->diffuse[0];
+            float ty = fmaf(1.0f - fmaf(m4->f0[1], AB.x, fb), T.y, by) * m4->diffuse[1];
+            float tz = fmaf(1.0f - fmaf(m4->f0[2], AB.x, fb), T.z, bz) * m4->diffuse[2];
             // lib.rs:157-159: real = tf * transmission; diffuse = lerp(diffuse, real, tf)
             float tf = m4->transmission_factor;
             diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
@@ -632,8 +648,8 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
             diffuse.z = fmaf(fmaf(tf, tz, -diffuse.z), tf, diffuse.z);
         }
 
-        f3 out = {diffuse.x + acc.st[0].x + m4->emission[0], diffuse.y + acc.st[1].x + m4->emission[1],
-                  diffuse.z + acc.st[2].x + m4->emission[2]};
+        f3 out = {diffuse.x + acc.s.x + m4->emission[0], diffuse.y + acc.s.y + m4->emission[1],
+                  diffuse.z + acc.s.z + m4->emission[2]};
         if constexpr (!TRANSMISSIVE) {
             if (L4->fp.debug_clusters != 0u) {  // lib.rs:241-245
                 f3 a = debug_colour_for_id(num_lights), b = debug_colour_for_id(cluster);
@@ -643,7 +659,12 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         return out;
     };
 
+    // Order: lights first, then the refraction taps and their resolve.  Issuing the taps before the light loop
+    // would hide their latency inside the wave, but holds 16 + 6 vector registers across the loop; without them
+    // the kernel fits 64 VGPRs = 8 waves per SIMD, and the other seven waves hide the latency better (measured:
+    // 129 -> 122 us on the 4K frame, profiles/r01).
     lights_phase();
+    issue_taps();
     return finish();
 }
 
@@ -761,8 +782,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
 // b % 8).  The 64x4-pixel tiles of the rect are cut into 8 contiguous bands, one per XCD, and the k
 // blocks of an XCD sweep their band front to back, so at any moment an XCD's L2 serves a compact
 // window of the screen (and of the opaque pyramid behind it).  A wave is a 16x4 pixel tile — few
-// waves straddle a material or cluster border, every plane row segment is still >= one 128 B line —
-// and the G-buffer of the block's next tile is already in flight while the current one is shaded.
+// waves straddle a material or cluster border, every plane row segment is still >= one 128 B line.
 //
 // TEXTURED (chosen by the host when an uploaded material has texture slots): additionally reads the uv plane,
 // forms the quad differences with two lane swizzles (the 16x4 wave tile holds whole 2x2 quads: partner lanes are
@@ -793,12 +813,12 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
     const uint32_t band_start = xcd * per + min(xcd, rem);
     const uint32_t band_len = per + (xcd < rem ? 1u : 0u);
 
-    // Branch-free: out-of-rect lanes read a clamped (valid) pixel and are masked later, and the prefetch
-    // past the end of the band re-reads the last tile.  With no branch around the loads the compiler
-    // can wait for exactly the older tile's loads (s_waitcnt vmcnt(N)) and leave the prefetch in flight.
+    // Out-of-rect lanes read a clamped (valid) pixel and are masked later.  There is no software prefetch of the
+    // next tile: its 13 registers would cost two of the eight resident waves per SIMD, and those waves hide the
+    // G-buffer latency as well as the prefetch did (measured, see shade_pixel).
     auto fetch = [&](uint32_t j, tile_regs& t) {
         claunch* F = launder(L);
-        const uint32_t tile = band_start + min(j, band_len - 1u);
+        const uint32_t tile = band_start + j;
         const uint32_t tyi = tile / F->fp.tiles_x;
         const uint32_t txi = tile - tyi * F->fp.tiles_x;
         t.px = F->fp.rect_x0 + txi * 64u + lx;
@@ -820,12 +840,9 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
     };
 
-    uint32_t j = blockIdx.x >> 3;
-    if (j >= band_len) return;
-    tile_regs cur, nxt;
-    fetch(j, cur);
-    while (j < band_len) {
-        const uint32_t jn = j + stride;
+    for (uint32_t j = blockIdx.x >> 3; j < band_len; j += stride) {
+        tile_regs cur;
+        fetch(j, cur);
         claunch* S = launder(L);
         const bool inside = cur.px < S->fp.rect_x1 && cur.py < S->fp.rect_y1;
         const bool active = inside && cur.mat != TR_NOT_COVERED;
@@ -833,12 +850,10 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         uint64_t todo = __ballot(active);
         cdmat* dmats = as_constant(S->dmats);
         if (TR_ABLATE(S, 32u)) {  // profiling only: pure streaming skeleton
-            fetch(jn, nxt);
             todo = 0;
             out = f3{cur.pd.x + cur.ns.x + (float)cur.mat, cur.pd.y + cur.ns.y + (float)cur.cluster_x, cur.pd.z + cur.ns.z + cur.pd.w + cur.ns.w};
         } else if (todo) {
             // One material at a time through the scalar unit; a wave that straddles k materials loops k times.
-            fetch(jn, nxt);
             quad_derivs qd;
             if constexpr (TEXTURED) {
                 // dFdx = value(x|1) - value(x&~1), dFdy likewise, zero where the partner has no fragment (lanes
@@ -880,8 +895,6 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
                     }
                 }
             }
-        } else {
-            fetch(jn, nxt);
         }
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         if ((TRANSMISSIVE ? active : inside) && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
@@ -894,8 +907,6 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
                 if (mip0) st<uint2>(mip0, pix * 8u, pack_rgba16f(out.x, out.y, out.z, 1.0f));
             }
         }
-        cur = nxt;
-        j = jn;
     }
 }
 
@@ -930,7 +941,7 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
         float coeff = -logf(mi.attenuation_colour[k]) / mi.attenuation_distance;  // :284
         d.neg_atten_log2[k] = has_atten ? (-coeff) * kLog2e : 0.0f;
     }
-    for (int k = 0; k < 5; ++k) d._pad[k] = 0u;
+    for (int k = 0; k < 3; ++k) d._pad[k] = 0u;
     out[i] = d;
 }
 

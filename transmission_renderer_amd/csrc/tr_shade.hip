@@ -21,7 +21,7 @@ using namespace tr;
 struct tr_context {
     int device = 0;
     int32_t last_hip_error = 0;
-    uint32_t blocks_per_xcd = 128;  // (CUs / 8) * 4 resident blocks per CU
+    uint32_t blocks_per_xcd = 1024;  // (CUs / 8) * resident blocks per CU * 4, set at context creation
 
     // materials
     tr_material_info* d_materials_raw = nullptr;
@@ -384,7 +384,8 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
     if (!ctx) return TR_ERR_OUT_OF_MEMORY;
     ctx->device = device_ordinal;
     {
-        // persistent grid: twice the resident blocks per CU (measured best on MI355X: the tail of the sweep is
+        // persistent grid: four times the resident blocks per CU (measured on MI355X with the 8-waves-per-SIMD
+        // kernel: 256 / 512 / 1024 / 2048 blocks per XCD -> 124 / 121 / 117 / 116 us; the tail of the sweep is
         // spread over more, shorter runs), 1/8 of them per XCD
         hipDeviceProp_t prop;
         int resident = 0;
@@ -392,7 +393,7 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
             resident <= 0)
             resident = 4;
         if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount >= 8) {
-            ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * 2u;
+            ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * 4u;
             ctx->num_cus = (uint32_t)prop.multiProcessorCount;
         }
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
