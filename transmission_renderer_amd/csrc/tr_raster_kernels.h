@@ -12,7 +12,7 @@
 // Shape of the work (one layer = two of the four draw buffers):
 //   scan_draws     one workgroup: triangles per draw -> prefix, so triangle t of the layer's draw stream is known
 //   setup          one thread per triangle: vertex stage, clip-space edge functions, bounds, work-item count
-//   scan_items     one workgroup: work items per triangle -> prefix
+//   scan_items     work items per triangle -> prefix (chunk sums, prefix of the sums, per-chunk scan)
 //   raster         persistent waves; a work item is one 8-pixel-tall row of a triangle's bounds, at most 512 pixels
 //                  wide; a wave covers it in 8x8 pixel blocks and resolves visibility with one 64-bit atomicMax of
 //                  (depth bits << 32 | t) per covered pixel: reversed-Z GREATER, and among equal depths the
@@ -206,24 +206,65 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_vie
     item_counts[t] = items;
 }
 
-__global__ __launch_bounds__(1024) void raster_scan_items_kernel(const uint32_t* __restrict__ item_counts,
-                                                                 uint32_t* __restrict__ item_base,
-                                                                 tr_layer_counts* __restrict__ counts) {
+// item_base = exclusive prefix of item_counts over the layer's triangles, in three passes so that millions of
+// triangles scan at memory speed: per-chunk sums -> (single workgroup) prefix of the chunk sums -> per-chunk scan.
+// The triangle count lives on the device, so the grids are sized for the capacity and surplus blocks exit.
+constexpr uint32_t kScanChunk = 4096u;   // 1024 threads x 4
+
+__global__ __launch_bounds__(1024) void raster_scan_items_reduce_kernel(const uint32_t* __restrict__ item_counts,
+                                                                        const tr_layer_counts* __restrict__ counts,
+                                                                        uint32_t* __restrict__ chunk_sums) {
     __shared__ uint32_t lds[17];
     const uint32_t n = counts->num_triangles;
+    const uint32_t first = blockIdx.x * kScanChunk;
+    if (first >= n) return;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t t = first + k * 1024u + threadIdx.x;
+        v += t < n ? item_counts[t] : 0u;
+    }
+    uint32_t total;
+    (void)block_exclusive_scan(v, lds, total);
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void raster_scan_items_chunks_kernel(uint32_t* __restrict__ chunk_sums,
+                                                                        tr_layer_counts* __restrict__ counts) {
+    __shared__ uint32_t lds[17];
+    const uint32_t nchunks = (counts->num_triangles + kScanChunk - 1u) / kScanChunk;
     uint32_t running = 0;
-    for (uint32_t base = 0; base < n; base += 1024u) {
-        const uint32_t t = base + threadIdx.x;
+    for (uint32_t base = 0; base < nchunks; base += 1024u) {
+        const uint32_t c = base + threadIdx.x;
+        const uint32_t v = c < nchunks ? chunk_sums[c] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, lds, total);
+        if (c < nchunks) chunk_sums[c] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) counts->num_items = running;
+}
+
+__global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const uint32_t* __restrict__ item_counts,
+                                                                       const uint32_t* __restrict__ chunk_sums,
+                                                                       const tr_layer_counts* __restrict__ counts,
+                                                                       uint32_t* __restrict__ item_base) {
+    __shared__ uint32_t lds[17];
+    const uint32_t n = counts->num_triangles;
+    const uint32_t first = blockIdx.x * kScanChunk;
+    if (first == 0u && threadIdx.x == 0 && n == 0u) item_base[0] = 0u;
+    if (first >= n) return;
+    uint32_t running = chunk_sums[blockIdx.x];
+#pragma unroll 1
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t t = first + k * 1024u + threadIdx.x;
         const uint32_t v = t < n ? item_counts[t] : 0u;
         uint32_t total;
         const uint32_t ex = block_exclusive_scan(v, lds, total);
         if (t < n) item_base[t] = running + ex;
         running += total;
     }
-    if (threadIdx.x == 0) {
-        item_base[n] = running;
-        counts->num_items = running;
-    }
+    if (first + kScanChunk >= n && threadIdx.x == 0) item_base[n] = running;   // the last chunk closes the prefix
 }
 
 // Barycentrics and depth at a pixel centre (oracle: tri_pixel).  `rec` is wave-uniform in the raster kernel
@@ -268,10 +309,23 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
     const uint32_t waves = gridDim.x * 4u;
     const uint32_t n_items = counts->num_items, n_tris = counts->num_triangles;
     const uint32_t first = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));   // wave-uniform
-    for (uint32_t item = first; item < n_items; item += waves) {
-        const uint32_t t = __builtin_amdgcn_readfirstlane(upper_index(item_base, n_tris, item));
+    // Wave w owns the items w, w + W, w + 2W, ... (W = number of waves: neighbouring rows of a large triangle go to
+    // different waves).  It takes 64 of them at a time: every lane finds the triangle of one item (a binary search
+    // over the prefix array, 64 searches in flight together), then the wave works through the 64 items one by one.
+    for (uint32_t batch = 0; first + (uint64_t)batch * 64u * waves < n_items; ++batch) {
+      const uint64_t my_item64 = first + ((uint64_t)batch * 64u + lane) * waves;
+      const uint32_t my_item = (uint32_t)min(my_item64, (uint64_t)0xFFFFFFFFu);
+      uint32_t my_t = 0u, my_local = 0u;
+      const bool mine = my_item64 < n_items;
+      if (mine) {
+          my_t = upper_index(item_base, n_tris, my_item);
+          my_local = my_item - item_base[my_t];
+      }
+      const uint32_t in_chunk = (uint32_t)__popcll(__ballot(mine));   // items are taken in lane order: a prefix of the lanes
+      for (uint32_t k = 0; k < in_chunk; ++k) {
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)k);
+        const uint32_t local = (uint32_t)__builtin_amdgcn_readlane((int)my_local, (int)k);
         const TR_CONSTANT tr_tri_record& rec = *as_constant(records + t);
-        const uint32_t local = item - item_base[t];
         const uint32_t bx0 = rec.x0 >> 3, by0 = rec.y0 >> 3, bx1 = rec.x1 >> 3;
         const uint32_t groups = ((bx1 - bx0 + 1u) + kItemWidthBlocks - 1u) / kItemWidthBlocks;
         const uint32_t row = local / groups, group = local - row * groups;
@@ -321,6 +375,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             }
             if (hit) atomicMax(&vis[pix], ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)t);
         }
+      }
     }
 }
 

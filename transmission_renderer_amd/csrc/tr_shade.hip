@@ -56,6 +56,7 @@ struct tr_context {
     tr_tri_record* d_records = nullptr;
     uint32_t* d_item_counts = nullptr;
     uint32_t* d_item_base = nullptr;
+    uint32_t* d_chunk_sums = nullptr;
     tr_layer_counts* d_layer_counts = nullptr;
     unsigned long long* d_vis[2] = {nullptr, nullptr};
     size_t vis_pixels = 0;
@@ -301,12 +302,14 @@ void free_geometry(tr_context* ctx) {
     (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_item_counts);
     (void)hipFree(ctx->d_item_base);
+    (void)hipFree(ctx->d_chunk_sums);
     (void)hipFree(ctx->d_layer_counts);
     ctx->d_position = ctx->d_normal = ctx->d_uv = nullptr;
     ctx->d_index = nullptr;
     ctx->d_primitives = nullptr;
     ctx->d_instances = nullptr;
     ctx->d_instance_counts = ctx->d_draw_counts = ctx->d_tri_base = ctx->d_item_counts = ctx->d_item_base = nullptr;
+    ctx->d_chunk_sums = nullptr;
     ctx->d_records = nullptr;
     ctx->d_layer_counts = nullptr;
     ctx->num_vertices = ctx->num_indices = ctx->num_primitives = ctx->num_instances = 0;
@@ -753,6 +756,7 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_records, cap * sizeof(tr_tri_record)));
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_counts, cap * 4u));
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_base, (cap + 1u) * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_chunk_sums, ((cap + kScanChunk - 1u) / kScanChunk + 1u) * 4u));
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_layer_counts, sizeof(tr_layer_counts)));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_position, g->position, nv * 12u, hipMemcpyHostToDevice, stream));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_normal, g->normal, nv * 12u, hipMemcpyHostToDevice, stream));
@@ -822,8 +826,15 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
             hipLaunchKernelGGL(raster_setup_kernel, dim3((cap + 255u) / 256u), dim3(256), 0, stream, gv, fr, da, db,
                                (const uint32_t*)ctx->d_tri_base, (const tr_layer_counts*)ctx->d_layer_counts, 1u,
                                ctx->d_records, ctx->d_item_counts);
-            hipLaunchKernelGGL(raster_scan_items_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)ctx->d_item_counts,
-                               ctx->d_item_base, ctx->d_layer_counts);
+            const uint32_t chunks = (cap + kScanChunk - 1u) / kScanChunk;
+            hipLaunchKernelGGL(raster_scan_items_reduce_kernel, dim3(chunks), dim3(1024), 0, stream,
+                               (const uint32_t*)ctx->d_item_counts, (const tr_layer_counts*)ctx->d_layer_counts,
+                               ctx->d_chunk_sums);
+            hipLaunchKernelGGL(raster_scan_items_chunks_kernel, dim3(1), dim3(1024), 0, stream, ctx->d_chunk_sums,
+                               ctx->d_layer_counts);
+            hipLaunchKernelGGL(raster_scan_items_apply_kernel, dim3(chunks), dim3(1024), 0, stream,
+                               (const uint32_t*)ctx->d_item_counts, (const uint32_t*)ctx->d_chunk_sums,
+                               (const tr_layer_counts*)ctx->d_layer_counts, ctx->d_item_base);
             hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * 8u), dim3(256), 0, stream, gv, fr,
                                (const tr_tri_record*)ctx->d_records, (const uint32_t*)ctx->d_item_base,
                                (const tr_layer_counts*)ctx->d_layer_counts, at,
