@@ -76,7 +76,8 @@ struct alignas(16) tr_dmat {
     float f0_dielectric;   // ((ior - 1) / (ior + 1))^2
     float bt_a[3];         // k[1] * (1 - f0): the btdf lobe is accumulated as sum(I D'V') and sum(I D'V' p') and
     float bt_b[3];         // k[1] * (f90 - f0): resolved once per pixel as bt_a * sum1 - bt_b * sum2
-    uint32_t _pad[3];
+    uint32_t lut_line;     // first entry of this material's GGX LUT line (build_lut_lines_kernel), in entries
+    uint32_t _pad[2];
 };
 static_assert(sizeof(tr_dmat) == 176, "digested material is 176 B");
 
@@ -139,6 +140,7 @@ struct tr_launch {
     const uint32_t* cluster_counts;
     const uint32_t* light_indices;
     const uint32_t* lut_pairs;          // (R,G)[x-1], (R,G)[x] per entry
+    const float4* lut_lines;            // per material: the LUT at the material's roughness, (A,B)[x-1], (A,B)[x] per entry
     const tr_level_table* levels;
     const uint16_t* cluster_x;          // [frame width]  u32(frag_coord.x / cluster_size.x)
     const uint32_t* cluster_y_term;     // [frame height] u32(frag_coord.y / cluster_size.y) * num_clusters.x
@@ -421,6 +423,7 @@ __device__ __forceinline__ f3 pyramid_resolve(pyramid_fetch& pf) {
 struct lut_fetch {
     uint32_t p0, p1;
     float fx;
+    float4 line;   // scalar-material path: both horizontal neighbours of the material's own LUT line
 };
 template <class Mat>
 __device__ __forceinline__ void lut_issue(lut_fetch& lf, const uint32_t* __restrict__ pairs, float lut_wf,
@@ -432,6 +435,20 @@ __device__ __forceinline__ void lut_issue(lut_fetch& lf, const uint32_t* __restr
     uint32_t k = (uint32_t)((int)fl + 1);
     lf.p0 = ld<uint32_t>(pairs, (m.lut_row0 + k) * 4u);
     lf.p1 = ld<uint32_t>(pairs, (m.lut_row1 + k) * 4u);
+}
+// The same tap for a material in scalar registers: its roughness is fixed, so the row interpolation was done once
+// per material (build_lut_lines_kernel) and the pixel only interpolates along n.v: one 16-byte load, four ops.
+__device__ __forceinline__ void lut_line_issue(lut_fetch& lf, const float4* __restrict__ lines, float lut_wf,
+                                               uint32_t line, float nov_raw) {
+    float x = fmaf(nov_raw, lut_wf, -0.5f);
+    x = fminf(fmaxf(x, -1.0f), lut_wf);
+    float fl = floorf(x);
+    lf.fx = x - fl;
+    uint32_t k = (uint32_t)((int)fl + 1);
+    lf.line = ld<float4>(lines, (line + k) * 16u);
+}
+__device__ __forceinline__ v2f lut_line_resolve(const lut_fetch& lf) {
+    return v2f{fmaf(lf.line.z - lf.line.x, lf.fx, lf.line.x), fmaf(lf.line.w - lf.line.y, lf.fx, lf.line.y)};
 }
 __device__ __forceinline__ v2f lut_resolve(const lut_fetch& lf, float fy) {
     auto b = [](uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); };
@@ -579,8 +596,11 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         float lod = L->fp.log2_fb_width * m->rough_ior; // :334-335
         if (!TR_ABLATE(L, 1u)) pyramid_issue<SCALAR_MATERIAL>(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane);
         else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
-        if (!TR_ABLATE(L, 2u)) lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, *m, nov_raw);
-        else { lf.p0 = lf.p1 = 0x40404040u; lf.fx = nov_raw; }
+        if constexpr (SCALAR_MATERIAL) {
+            lut_line_issue(lf, L->lut_lines, (float)L->fp.lut_width, m->lut_line, nov_raw);
+        } else {
+            lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, *m, nov_raw);
+        }
     }
     };
 
@@ -632,7 +652,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
                 T.y *= fast_exp2(m4->neg_atten_log2[1] * len);
                 T.z *= fast_exp2(m4->neg_atten_log2[2] * len);
             }
-            const v2f AB = lut_resolve(lf, m4->lut_fy);
+            v2f AB;
+            if constexpr (SCALAR_MATERIAL) AB = lut_line_resolve(lf);
+            else AB = lut_resolve(lf, m4->lut_fy);
             // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
             const float fb = m4->f90 * AB.y;
             const float bx = fmaf(-m4->bt_b[0], acc.tb.x, m4->bt_a[0] * acc.ta.x);   // sum over lights of transmission_btdf
@@ -941,8 +963,24 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
         float coeff = -logf(mi.attenuation_colour[k]) / mi.attenuation_distance;  // :284
         d.neg_atten_log2[k] = has_atten ? (-coeff) * kLog2e : 0.0f;
     }
-    for (int k = 0; k < 3; ++k) d._pad[k] = 0u;
+    d.lut_line = i * lut_stride;
+    for (int k = 0; k < 2; ++k) d._pad[k] = 0u;
     out[i] = d;
+}
+
+// Per material, the GGX LUT at the material's roughness: entry k = (A, B) of texel clamp(k-1) and of texel clamp(k)
+// after the row interpolation, already divided by 255 (what lut_resolve computes per pixel for the row pair).
+__global__ void build_lut_lines_kernel(const uint32_t* __restrict__ pairs, const tr_dmat* __restrict__ dmats,
+                                       float4* __restrict__ lines, uint32_t stride, uint32_t count) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, mi = blockIdx.y;
+    if (k >= stride || mi >= count) return;
+    const tr_dmat& m = dmats[mi];
+    const uint32_t p0 = pairs[m.lut_row0 + k], p1 = pairs[m.lut_row1 + k];
+    auto b = [](uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); };
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = fmaf(b(p1, c) - b(p0, c), m.lut_fy, b(p0, c)) * (1.0f / 255.0f);
+    lines[(size_t)mi * stride + k] = float4{v[0], v[1], v[2], v[3]};
 }
 
 // GGX LUT -> pair table.  For the unclamped left tap i0 = floor(u*w - 0.5) in [-1, w], entry

@@ -77,6 +77,8 @@ struct tr_context {
     // GGX LUT
     uint32_t* d_lut_rgba8 = nullptr;
     uint32_t* d_lut_pairs = nullptr;
+    float4* d_lut_lines = nullptr;      // per material, see build_lut_lines_kernel
+    size_t lut_lines_entries = 0;
     uint32_t lut_w = 0, lut_h = 0, lut_stride = 0;
     std::vector<uint8_t> stage_lut;
 
@@ -121,6 +123,18 @@ tr_status ensure_digested(tr_context* ctx, hipStream_t stream) {
     uint32_t n = ctx->num_materials;
     hipLaunchKernelGGL(digest_materials_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, ctx->d_materials_raw,
                        ctx->d_dmats, n, ctx->lut_h, ctx->lut_stride);
+    const size_t entries = (size_t)n * ctx->lut_stride;
+    if (entries * 16u > 0xFFFFFFFFull) return TR_ERR_UNSUPPORTED;
+    if (entries > ctx->lut_lines_entries) {
+        TR_HIP(ctx, hipStreamSynchronize(stream));
+        (void)hipFree(ctx->d_lut_lines);
+        ctx->d_lut_lines = nullptr;
+        ctx->lut_lines_entries = 0;
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_lut_lines, entries * sizeof(float4)));
+        ctx->lut_lines_entries = entries;
+    }
+    hipLaunchKernelGGL(build_lut_lines_kernel, dim3((ctx->lut_stride + 255u) / 256u, n), dim3(256), 0, stream,
+                       (const uint32_t*)ctx->d_lut_pairs, (const tr_dmat*)ctx->d_dmats, ctx->d_lut_lines, ctx->lut_stride, n);
     TR_HIP(ctx, hipGetLastError());
     ctx->dmats_dirty = false;
     return TR_OK;
@@ -334,6 +348,7 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.cluster_counts = ctx->d_cluster_counts;
     L.light_indices = ctx->d_light_indices;
     L.lut_pairs = ctx->d_lut_pairs;
+    L.lut_lines = ctx->d_lut_lines;
     L.levels = ctx->d_levels;
     L.cluster_x = ctx->d_cluster_x;
     L.cluster_y_term = ctx->d_cluster_y_term;
@@ -431,6 +446,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_alights);
     (void)hipFree(ctx->d_lut_rgba8);
     (void)hipFree(ctx->d_lut_pairs);
+    (void)hipFree(ctx->d_lut_lines);
     (void)hipFree(ctx->d_levels);
     (void)hipFree(ctx->d_cluster_x);
     (void)hipFree(ctx->d_cluster_y_term);
