@@ -117,6 +117,7 @@ struct tr_frame_params {
     uint32_t g_origin_x, g_origin_y;  // frame position of plane element (0,0)
     uint32_t rect_x0, rect_y0, rect_x1, rect_y1;
     uint32_t tiles_x, tiles_y;   // 64x4 tiles covering the rect
+    uint32_t tiles_x_magic;      // floor(2^32 / tiles_x): tile / tiles_x on the scalar unit (one fix-up step)
     uint32_t lut_width, lut_stride;  // pair-table stride in entries (= lut_width + 2)
     uint32_t lut_height;
     uint32_t pyr_levels;
@@ -841,8 +842,13 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
     auto fetch = [&](uint32_t j, tile_regs& t) {
         claunch* F = launder(L);
         const uint32_t tile = band_start + j;
-        const uint32_t tyi = tile / F->fp.tiles_x;
-        const uint32_t txi = tile - tyi * F->fp.tiles_x;
+        // tile / tiles_x without the vector unit: q = mulhi(tile, floor(2^32 / d)) is the quotient or one less
+        uint32_t tyi = __umulhi(tile, F->fp.tiles_x_magic);
+        uint32_t txi = tile - tyi * F->fp.tiles_x;
+        if (txi >= F->fp.tiles_x) {
+            txi -= F->fp.tiles_x;
+            ++tyi;
+        }
         t.px = F->fp.rect_x0 + txi * 64u + lx;
         t.py = F->fp.rect_y0 + tyi * 4u + ly;
         const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
