@@ -49,6 +49,16 @@ __device__ __forceinline__ void st(void* base, uint32_t byte_offset, T value) {
     *reinterpret_cast<T*>(static_cast<char*>(base) + byte_offset) = value;
 }
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+// The wave's lane mask of a predicate, straight from the compare (HIP's __ballot goes through v_cndmask + v_cmp;
+// the builtin does too unless the predicate is ONE compare, so callers fold their conditions into a key first).
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// A scalar value the optimiser cannot relate to its source: inside `if (per_lane == s)` LLVM's equality propagation
+// substitutes the per-lane value for the scalar `s`, and every table read indexed by it degrades to a per-lane vector
+// load; indexing with opaque(s) instead keeps the reads on the scalar unit.
+__device__ __forceinline__ uint32_t opaque(uint32_t s) {
+    asm volatile("" : "+s"(s));
+    return s;
+}
 
 // ------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }

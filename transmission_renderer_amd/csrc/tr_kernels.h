@@ -369,11 +369,11 @@ __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __
         pyramid_issue_levels(pf, texels, lv, levels, u, v, __builtin_amdgcn_readfirstlane((uint32_t)lf));
     } else {
         const uint32_t mine = (uint32_t)lf;
-        uint64_t todo = __ballot(1);
+        uint64_t todo = ballot(true);
         while (todo) {
             const int first = __ffsll((unsigned long long)todo) - 1;
             const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, first);
-            const uint64_t group = __ballot(mine == l0);
+            const uint64_t group = ballot(mine == l0);
             todo &= ~group;
             if ((group >> lane) & 1ull) pyramid_issue_levels(pf, texels, lv, levels, u, v, l0);
         }
@@ -623,20 +623,21 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
                                      {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, transmits);
         // punctual lights (lighting.rs:55-92 / 179-217)
         cdlight* lights = as_constant(L2->lights);
+        constexpr uint32_t kDone = 0xFFFFFFFFu;   // a lane whose list is exhausted
         uint32_t i = 0;
-        uint32_t head = first_light;
-        uint64_t pending = __ballot(i < num_lights);
+        uint32_t head = num_lights ? first_light : kDone;
+        uint64_t pending = ballot(head != kDone);
         while (pending) {
             const int l0 = __ffsll((unsigned long long)pending) - 1;
             const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)head, l0);
-            const uint64_t group = __ballot(i < num_lights && head == h0);
-            if ((group >> lane) & 1ull) {  // membership from the mask keeps h0 scalar (see shade_kernel)
-                const uint32_t next = ld<uint32_t>(L2->light_indices, list_offset + min(i + 1u, TR_MAX_LIGHTS_PER_CLUSTER - 1u) * 4u);  // in flight during the eval
-                eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0], pos, px, transmits);
+            const uint32_t h0s = opaque(h0);
+            if (head == h0) {
                 ++i;
-                head = next;
+                const uint32_t next = ld<uint32_t>(L2->light_indices, list_offset + min(i, TR_MAX_LIGHTS_PER_CLUSTER - 1u) * 4u);  // in flight during the eval
+                eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0s], pos, px, transmits);
+                head = i < num_lights ? next : kDone;
             }
-            pending = __ballot(i < num_lights);
+            pending = ballot(head != kDone);
         }
     };
     // ================= phase 4: resolve the taps, composite =================
@@ -874,8 +875,9 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         claunch* S = launder(L);
         const bool inside = cur.px < S->fp.rect_x1 && cur.py < S->fp.rect_y1;
         const bool active = inside && cur.mat != TR_NOT_COVERED;
+        const uint32_t key = inside ? cur.mat : TR_NOT_COVERED;   // the material of a lane that has work
         f3 out = {0.f, 0.f, 0.f};  // clear colour of the opaque pass (src/main.rs:1592-1601)
-        uint64_t todo = __ballot(active);
+        uint64_t todo = ballot(key != TR_NOT_COVERED);
         cdmat* dmats = as_constant(S->dmats);
         if (TR_ABLATE(S, 32u)) {  // profiling only: pure streaming skeleton
             todo = 0;
@@ -905,13 +907,10 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
             }
             while (todo) {
                 const int l0 = __ffsll((unsigned long long)todo) - 1;
-                const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)cur.mat, l0);
-                const uint64_t group = __ballot(active && cur.mat == m0);
-                todo &= ~group;
-                // Membership is read back from the ballot mask, not from `mat == m0`: inside `if (mat == m0)`
-                // the optimiser substitutes the per-lane `mat` for the scalar `m0` and the table reads turn
-                // into per-lane vector loads.
-                if ((group >> lane) & 1ull) {
+                const uint32_t mk = (uint32_t)__builtin_amdgcn_readlane((int)key, l0);
+                const uint32_t m0 = opaque(mk);   // tables are indexed with m0, the branch compares mk (see opaque())
+                todo &= ~ballot(key == mk);
+                if (key == mk) {
                     if constexpr (TEXTURED) {
                         if (dmats[m0].flags & 4u)
                             out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane,
