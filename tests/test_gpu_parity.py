@@ -386,3 +386,63 @@ def test_frame_recorded_into_a_hip_graph_replays_bit_exact(renderer, ggx_lut):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(hdr, want_hdr) and torch.equal(ldr2, want_ldr)
+
+
+def test_many_lights_long_and_ragged_lists(renderer, ggx_lut):
+    """160 small lights scattered through the view volume: cluster lists of very different lengths (some hit the
+    128-entry cap), so every wave walks ragged lists through the de-duplicating light loop; both passes."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    w, h = 256, 144
+    scene = synthetic.make_scene(w, h, num_point_lights=0)
+    rng = np.random.default_rng(21)
+    lights = []
+    for k in range(160):
+        pos = (rng.uniform(-2.5, 2.5), rng.uniform(0.5, 4.0), rng.uniform(-4.5, -0.5))
+        col = tuple(rng.uniform(0.1, 1.0, 3))
+        if k % 7 == 0:
+            lights.append(wire.Light.new_spot(pos, col, float(rng.uniform(0.5, 3.0)), (0.0, -1.0, 0.0), 0.3, 0.7))
+        else:
+            lights.append(wire.Light.new_point(pos, col, float(rng.uniform(0.02, 1.5))))
+    lights += [wire.Light.new_point((0.0, 2.0, -2.5), (1, 1, 1), 40.0) for _ in range(100)]   # everywhere: some lists overflow
+    scene["lights"] = lights
+    _, view = wire.default_camera()
+    q = wire.view_rotation_inverse(view)
+    r.upload_materials(scene["materials"])
+    r.upload_lights(lights)
+    aabbs = r.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
+    counts, indices = r.assign_lights_to_clusters(view, q, aabbs)
+    torch.cuda.synchronize()
+    scene["cluster_counts"] = counts.cpu().numpy().view(np.uint32)
+    scene["light_indices"] = indices.cpu().numpy().view(np.uint32)
+    assert scene["cluster_counts"].max() == wire.MAX_LIGHTS_PER_CLUSTER and len(np.unique(scene["cluster_counts"])) >= 10
+    o_aabbs = oracle.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
+    o_counts, o_idx = oracle.assign_lights_to_clusters(lights, o_aabbs, view, q)
+    # the reference's counter keeps counting past the 128 slots of a list (shader/src/lib.rs:634-643 stores only the
+    # first 128); the library clamps the count it hands to the shading passes
+    assert o_counts.max() > wire.MAX_LIGHTS_PER_CLUSTER
+    np.testing.assert_array_equal(scene["cluster_counts"], np.minimum(o_counts, wire.MAX_LIGHTS_PER_CLUSTER))
+    lists = scene["light_indices"].reshape(-1, wire.MAX_LIGHTS_PER_CLUSTER)
+    o_lists = o_idx.reshape(-1, wire.MAX_LIGHTS_PER_CLUSTER)
+    for c in np.nonzero(scene["cluster_counts"])[0][::37]:
+        n = scene["cluster_counts"][c]
+        np.testing.assert_array_equal(lists[c, :n], o_lists[c, :n])
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    b = oracle.SceneBinding(scene, ggx_lut)
+    tex = oracle.new_pyramid(w, h, synthetic.make_opaque_mip0(w, h))
+    oracle.generate_mips(w, h, tex)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.texels.copy_(torch.from_numpy(tex).to(r.device))
+    t32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    o32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
+    r.shade_opaque(g, scene["uniforms"], scene["push"], o32, None)
+    torch.cuda.synchronize()
+    _, want_t = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8, fp64=True)
+    _, want_o, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
+    for got, want, what in ((t32.cpu().numpy(), want_t, "transmission"), (o32.cpu().numpy(), want_o, "opaque")):
+        e = _norm_err(got, want)
+        out = np.abs(e).max(axis=2) > 5e-3       # pixels on a depth-slice boundary take a neighbouring cluster's list
+        assert out.mean() <= 3e-3, (what, out.mean())
+        e = np.where(out[..., None], 0.0, e)
+        assert _rmse(e).max() <= 1e-4, (what, _rmse(e))
