@@ -44,6 +44,12 @@ template <class T>
 __device__ __forceinline__ T ld(const void* base, uint32_t byte_offset) {
     return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset);
 }
+// Streamed-once data (the G-buffer planes): non-temporal, so it does not displace the tables and pyramid texels
+// the same kernel keeps re-reading from L2.
+template <class T>
+__device__ __forceinline__ T ld_stream(const void* base, uint32_t byte_offset) {
+    return __builtin_nontemporal_load(reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset));
+}
 template <class T>
 __device__ __forceinline__ void st(void* base, uint32_t byte_offset, T value) {
     *reinterpret_cast<T*>(static_cast<char*>(base) + byte_offset) = value;
