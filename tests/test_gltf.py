@@ -136,3 +136,37 @@ def test_loader_refuses_what_the_reference_cannot_draw(tmp_path):
     json.dump(doc, open(bad, "w"))
     with pytest.raises(gltf.GltfError):          # the reference asserts on non-uniform scale (:478-487)
         gltf.load_gltf(bad)
+
+
+def test_jpeg_palette_and_grey_images(tmp_path):
+    """Texture containers beyond 8-bit RGB(A) PNG: JPEG and palette PNG decode (RGB widened to RGBA like
+    src/model_loading.rs:36-52); grey images are refused because the reference panics on them (:348-351)."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    import io
+    rng = np.random.default_rng(2)
+    base = (np.linspace(0, 255, 32 * 24 * 3).reshape(24, 32, 3) + rng.integers(0, 20, (24, 32, 3))).clip(0, 255).astype(np.uint8)
+    def encoded(img, fmt, **kw):
+        buf = io.BytesIO()
+        img.save(buf, format=fmt, **kw)
+        return buf.getvalue()
+    jpeg = encoded(Image.fromarray(base), "JPEG", quality=90)
+    pal = encoded(Image.fromarray(base).quantize(16), "PNG")
+    grey = encoded(Image.fromarray(base[..., 0]), "PNG")
+    got = gltf.decode_image_rgba8(jpeg)
+    want = np.asarray(Image.open(io.BytesIO(jpeg)).convert("RGB"))
+    assert got.shape == (24, 32, 4) and (got[..., 3] == 255).all()
+    np.testing.assert_array_equal(got[..., :3], want)
+    assert np.abs(got[..., :3].astype(int) - base.astype(int)).mean() < 6          # it is the picture, lossy
+    got = gltf.decode_image_rgba8(pal)
+    np.testing.assert_array_equal(got[..., :3], np.asarray(Image.open(io.BytesIO(pal)).convert("RGB")))
+    with pytest.raises(gltf.GltfError):
+        gltf.decode_image_rgba8(grey)
+    # through a whole file: a JPEG base colour texture
+    quad = meshes.plane(1.0, 1.0)
+    path = str(tmp_path / "jpeg.glb")
+    gltf.write_gltf(path, [{"mesh": 0}], [[(quad, 0)]],
+                    [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}], [(jpeg, "image/jpeg")])
+    scene = gltf.load_gltf(path)
+    assert scene.materials[0].textures.diffuse == 0 and scene.textures[0][1] is True
+    np.testing.assert_array_equal(scene.textures[0][0][..., :3], want)

@@ -12,7 +12,7 @@ What the reference does per file (src/model_loading.rs:12-333), and this module 
   * images are uploaded once per (image, sRGB?) pair: base colour / emissive / specular colour as sRGB, the rest
     linear, the specular (alpha) texture re-using an sRGB copy when one exists (:166-222).
 The reference leans on the un-vendored `gltf` crate (fork @0324938) for parsing; here the JSON / GLB container, the
-accessors and PNG decoding are read directly.  JPEG images are refused (no decoder in this image): loudly.
+accessors and 8-bit RGB(A) PNG decoding are read directly; JPEG and the other PNG variants go through Pillow.
 
 `write_gltf` is the inverse for test assets (there is no network for the Khronos sample models).
 """
@@ -117,9 +117,45 @@ class Document:
             data = self._read_uri(img["uri"])
         else:
             data, _ = self.view_bytes(img["bufferView"])
-        if data[:8] != b"\x89PNG\r\n\x1a\n":
-            raise GltfError(f"image {index}: only PNG images can be decoded here (JPEG needs a decoder this image lacks)")
-        return read_png_rgba8_bytes(data)      # RGB -> RGBA widening like src/model_loading.rs:36-52
+        return decode_image_rgba8(data, f"image {index}")
+
+
+def decode_image_rgba8(data: bytes, what: str = "image") -> np.ndarray:
+    """Encoded image bytes -> (H, W, 4) uint8, the way `gltf::import` + src/model_loading.rs:36-52, 343-351 treat them:
+    RGB is widened to RGBA (alpha 255), RGBA is kept; anything else (grey, grey+alpha, 16-bit) makes the reference
+    panic ("unsupported format") and is refused here.  8-bit non-interlaced RGB(A) PNGs are decoded in-module;
+    every other container / variant (JPEG, palette or interlaced PNG, ...) goes through Pillow when it is installed."""
+    if data[:8] == b"\x89PNG\r\n\x1a\n":
+        try:
+            from .png import decode_png
+            img = decode_png(data, what)
+        except ValueError:
+            img = None                     # a PNG variant the small decoder does not read
+        if img is not None:
+            if img.shape[2] in (1, 2):
+                raise GltfError(f"{what}: grey / grey+alpha images are an unsupported format in the reference "
+                                "(src/model_loading.rs:348-351 panics)")
+            return read_png_rgba8_bytes(data)
+    try:
+        from PIL import Image
+    except ImportError as e:               # pragma: no cover - Pillow is present in the build image
+        raise GltfError(f"{what}: only 8-bit RGB(A) PNGs can be decoded without Pillow") from e
+    import io
+    with Image.open(io.BytesIO(data)) as im:
+        im.load()
+        if im.mode == "P":
+            im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+        elif im.mode in ("CMYK", "YCbCr"):
+            im = im.convert("RGB")
+        if im.mode == "RGB":
+            rgb = np.asarray(im, dtype=np.uint8)
+            out = np.full(rgb.shape[:2] + (4,), 255, dtype=np.uint8)
+            out[..., :3] = rgb
+            return out
+        if im.mode == "RGBA":
+            return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+        raise GltfError(f"{what}: image mode {im.mode} is an unsupported format in the reference "
+                        "(src/model_loading.rs:348-351 panics on anything but 8-bit RGB / RGBA)")
 
 
 def _node_similarity(node: dict) -> Similarity:
@@ -317,7 +353,8 @@ def write_gltf(path: str, nodes: list, meshes_: list, materials: list, images: l
                binary: bool = True, index_type=np.uint16) -> None:
     """Writes a .glb (or .gltf with embedded data URIs).
     nodes: glTF node dicts (TRS / children / mesh);  meshes_: [[(Mesh, material index or None), ...], ...];
-    materials: glTF material dicts;  images: [(H, W, 3|4) uint8 arrays];  textures: [image index] (default: 1:1)."""
+    materials: glTF material dicts;  images: [(H, W, 3|4) uint8 arrays, written as PNG, or (encoded bytes, mime type)];
+    textures: [image index] (default: 1:1)."""
     blob = bytearray()
     views, accessors = [], []
 
@@ -349,12 +386,16 @@ def write_gltf(path: str, nodes: list, meshes_: list, materials: list, images: l
         jmeshes.append({"primitives": jp})
     jimages = []
     for img in images:
-        data = _png_bytes(img)
+        mime = "image/png"
+        if isinstance(img, tuple):          # (encoded bytes, mime type): stored as they are
+            data, mime = img
+        else:
+            data = _png_bytes(img)
         while len(blob) % 4:
             blob.append(0)
         views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)})
         blob.extend(data)
-        jimages.append({"bufferView": len(views) - 1, "mimeType": "image/png"})
+        jimages.append({"bufferView": len(views) - 1, "mimeType": mime})
     used = sorted({e for m in materials for e in m.get("extensions", {})} |
                   {"KHR_texture_transform" for m in materials
                    if "KHR_texture_transform" in m.get("pbrMetallicRoughness", {}).get("baseColorTexture", {}).get("extensions", {})})
