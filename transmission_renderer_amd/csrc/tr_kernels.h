@@ -1187,17 +1187,14 @@ __device__ __forceinline__ uint32_t linear_to_srgb8(float x) {   // the sRGB tar
     return (uint32_t)fmaf(e, 255.0f, 0.5f);
 }
 
-__global__ __launch_bounds__(256) void tonemap_kernel(const uint2* __restrict__ hdr, uint32_t* __restrict__ out,
-                                                      uint32_t n, const tr_tonemap_params p, int bgra) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint2 q = hdr[i];
-    const float r = h2f_lo(q.x), g = h2f_hi(q.x), b = h2f_lo(q.y);
+// fragment_tonemap (shader/src/lib.rs:683-697, shader/src/tonemapping.rs:8-27) + the sRGB encode of the swapchain
+// format.  Two pixels per thread (16-byte loads, 8-byte stores); the two divisions of the operator are v_rcp_f32.
+__device__ __forceinline__ uint32_t tonemap_pixel(uint32_t lo, uint32_t hi, const tr_tonemap_params& p, float e1, int bgra) {
+    const float r = h2f_lo(lo), g = h2f_hi(lo), b = h2f_lo(hi);
     const float mx = fmaxf(r, fmaxf(g, b));
-    const float inv = 1.0f / mx;                       // color / max  (0/0 = NaN for black: reference behaviour)
+    const float inv = rcp(mx);                         // color / max  (0/0 = NaN for black: reference behaviour)
     const float z = fast_pow(mx, p.a);
-    const float tm = z / fmaf(fast_pow(z, p.d), p.b, p.c);   // tonemap_inner
-    const float e1 = p.saturation / p.cross_saturation;
+    const float tm = z * rcp(fmaf(fast_pow(z, p.d), p.b, p.c));   // tonemap_inner
     const float t = fast_pow(tm, p.crosstalk);
     float c[3] = {r * inv, g * inv, b * inv};
 #pragma unroll
@@ -1208,7 +1205,21 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const uint2* __restrict__ 
         c[k] = fmaxf(fminf(x * tm, 1.0f), 0.0f);       // .min(ONE).max(ZERO): NaN -> 1 (v_min/v_max return the number)
     }
     const uint32_t R = linear_to_srgb8(c[0]), G = linear_to_srgb8(c[1]), B = linear_to_srgb8(c[2]);
-    out[i] = bgra ? (B | (G << 8) | (R << 16) | 0xFF000000u) : (R | (G << 8) | (B << 16) | 0xFF000000u);
+    return bgra ? (B | (G << 8) | (R << 16) | 0xFF000000u) : (R | (G << 8) | (B << 16) | 0xFF000000u);
+}
+
+__global__ __launch_bounds__(256) void tonemap_kernel(const uint2* __restrict__ hdr, uint32_t* __restrict__ out,
+                                                      uint32_t n, const tr_tonemap_params p, int bgra) {
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 2u;
+    if (i >= n) return;
+    const float e1 = p.saturation / p.cross_saturation;
+    if (i + 1u < n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(hdr + i);          // pixels i, i + 1 (the target is 16-byte aligned)
+        *reinterpret_cast<uint2*>(out + i) = uint2{tonemap_pixel(q.x, q.y, p, e1, bgra), tonemap_pixel(q.z, q.w, p, e1, bgra)};
+    } else {
+        const uint2 q = hdr[i];
+        out[i] = tonemap_pixel(q.x, q.y, p, e1, bgra);
+    }
 }
 
 }  // namespace tr

@@ -1104,7 +1104,8 @@ tr_status tr_tonemap(tr_context* ctx, const void* hdr, uint32_t width, uint32_t 
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t n = width * height;
-    hipLaunchKernelGGL(tonemap_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint2*)hdr,
+    if (((uintptr_t)hdr & 15u) || ((uintptr_t)out_rgba8 & 7u)) return TR_ERR_INVALID_ARGUMENT;   // 2 pixels per thread
+    hipLaunchKernelGGL(tonemap_kernel, dim3((n + 511u) / 512u), dim3(256), 0, stream, (const uint2*)hdr,
                        (uint32_t*)out_rgba8, n, *params, (int)bgra);
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
