@@ -440,6 +440,38 @@ tr_status tr_bake_lottes_params(const tr_lottes_params* params, tr_tonemap_param
 tr_status tr_tonemap(tr_context* ctx, const void* hdr_rgba16f, uint32_t width, uint32_t height,
                      const tr_tonemap_params* params, void* out_rgba8, int32_t bgra, void* stream);
 
+/* ------------------------------------------------------------------ one frame */
+
+/*
+ * Everything `record()` (src/main.rs:1551-2263) enqueues per frame for this path, in its order, as ONE call on one
+ * stream: zero counters + frustum culling (:1660-1763) -> light assignment (:1765-1798) -> draw demultiplex
+ * (:1811-1838) -> depth pre-passes + rasterisation into the two layers (:1900-2042) -> main opaque colour pass
+ * (:1969-2001) -> opaque mip chain (:2046-2064) -> transmissive pass (:2066-2124) -> tonemap (:2126-2180).
+ * Uses the context's uploaded geometry, materials, textures, lights and GGX LUT.  Every pointer in the descriptor
+ * is a device pointer owned by the caller unless marked host; nothing is allocated per frame.
+ */
+typedef struct tr_frame_desc {
+    const tr_push_constants* push;                 /* host */
+    const tr_uniforms* uniforms;                   /* host */
+    const tr_culling_push_constants* culling;      /* host */
+    const float* view_matrix;                      /* host, 16 floats column-major (AssignLightsPushConstants) */
+    const float* view_rotation;                    /* host, quaternion xyzw = camera_rotation.inverse() */
+    const void* cluster_aabbs;                     /* from tr_write_cluster_data (start-up / resize) */
+    uint32_t num_clusters;
+    uint32_t _reserved;
+    void* cluster_light_counts;                    /* out: num_clusters u32; bound as the passes' tables */
+    void* light_indices;                           /* out: num_clusters * 128 u32 */
+    tr_gbuffer_target opaque_layer;                /* work: whole-frame TGB-v1 planes */
+    tr_gbuffer_target transmissive_layer;
+    tr_pyramid pyramid;                            /* work: opaque_sampled_hdr_framebuffer */
+    void* hdr;                                     /* out: the HDR colour target, whole frame */
+    tr_format hdr_format;
+    int32_t bgra;                                  /* byte order of ldr_out (see tr_tonemap) */
+    const tr_tonemap_params* tonemap;              /* host; may be NULL together with ldr_out: no tonemap */
+    void* ldr_out;                                 /* out: width*height RGBA8 (sRGB encoded), or NULL */
+} tr_frame_desc;
+tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* frame, void* stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

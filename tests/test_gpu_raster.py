@@ -226,3 +226,38 @@ def test_cli_gltf_in_frame_out(tmp_path):
     assert 0.2 < covered.mean() < 0.9 and np.isfinite(hdr).all()
     assert len(np.unique(img.reshape(-1, 4), axis=0)) > 500          # an actual picture
     assert cli.main(["NoSuchModel"]) == 2
+
+
+def test_record_frame_equals_the_stepwise_sequence(renderer, ggx_lut):
+    """tr_record_frame (one native call per frame) reproduces, bit for bit, the frame the individual entry points
+    give when called in the reference's order; a second frame from another camera re-uses every buffer."""
+    from transmission_renderer_amd.renderer import OpaquePyramid
+    r = renderer
+    w, h = 320, 180
+    geo = meshes.make_mesh_scene()
+    for k, view in enumerate((wire.default_camera()[1], wire.look_at_rh((3.5, 2.0, -6.0), (0.0, 1.2, -3.0), (0.0, 1.0, 0.0)))):
+        sc = _scene(w, h, view)
+        sc["lights"] = synthetic.make_lights(2) + [wire.Light.new_point((0.5, 1.5, -2.5), (0.2, 0.9, 0.4), 0.3)]
+        q = wire.view_rotation_inverse(view)
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+        r.upload_materials(sc["materials"])
+        r.upload_textures(sc["textures"])
+        r.upload_lights(sc["lights"])
+        r.upload_geometry(geo)
+        aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+        if k == 0:
+            work = r.new_frame_buffers(w, h)
+        hdr, ldr = r.record_frame(sc["uniforms"], sc["push"], culling, view, q, aabbs, work)
+        torch.cuda.synchronize()
+        got_hdr, got_ldr = hdr.clone(), ldr.clone()
+        # the same frame, one entry point at a time
+        r.assign_lights_to_clusters(view, q, aabbs)
+        o, t = r.new_layer(w, h), r.new_layer(w, h)
+        r.draw_scene(culling, sc["push"], o, t)
+        pyr = OpaquePyramid(w, h, r.device)
+        hdr2 = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+        r.record(o, t, sc["uniforms"], sc["push"], hdr2, pyr)
+        ldr2 = r.tonemap(hdr2)
+        torch.cuda.synchronize()
+        assert torch.equal(got_hdr.view(torch.int16), hdr2.view(torch.int16)) and torch.equal(got_ldr, ldr2)
+        assert (got_hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2

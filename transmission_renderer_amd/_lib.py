@@ -20,7 +20,7 @@ SYMBOLS = (
     "tr_upload_ggx_lut", "tr_upload_textures", "tr_texture_get_layout", "tr_download_texture", "tr_frustum_culling", "tr_demultiplex_draws",
     "tr_upload_geometry", "tr_rasterize", "tr_draw_scene",
     "tr_write_cluster_data", "tr_assign_lights_to_clusters", "tr_shade_opaque",
-    "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap",
+    "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap", "tr_record_frame",
 )
 
 _lib = None
@@ -108,6 +108,8 @@ def load() -> C.CDLL:
     lib.tr_bake_lottes_params.argtypes = [C.POINTER(wire.LottesParams), C.POINTER(wire.TonemapParams)]
     lib.tr_tonemap.restype = i32
     lib.tr_tonemap.argtypes = [vp, vp, u32, u32, C.POINTER(wire.TonemapParams), vp, i32, vp]
+    lib.tr_record_frame.restype = i32
+    lib.tr_record_frame.argtypes = [vp, C.POINTER(wire.FrameDesc), vp]
     if lib.tr_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.tr_abi_version()} != 1")
     _lib = lib

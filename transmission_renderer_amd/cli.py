@@ -85,19 +85,20 @@ def main(argv=None) -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     aabbs = r.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
-    r.assign_lights_to_clusters(view, wire.view_rotation_inverse(view), aabbs)
     if geometry is None:
         # the synthetic scene has one layer: it is shaded as opaque geometry first (the backdrop the refraction
         # sees), then as the transmissive layer in front of it
+        r.assign_lights_to_clusters(view, wire.view_rotation_inverse(view), aabbs)
         opaque = transmissive = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+        pyr = OpaquePyramid(w, h, r.device)
+        hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+        r.record(opaque, transmissive, scene["uniforms"], scene["push"], hdr, pyr)
+        ldr = r.tonemap(hdr)
     else:
-        opaque, transmissive = r.new_layer(w, h), r.new_layer(w, h)
+        # one native call per frame: culling, light assignment, demultiplex, rasteriser, opaque, mips, transmissive, tonemap
         culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
-        r.draw_scene(culling, scene["push"], opaque, transmissive)
-    pyr = OpaquePyramid(w, h, r.device)
-    hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
-    r.record(opaque, transmissive, scene["uniforms"], scene["push"], hdr, pyr)
-    ldr = r.tonemap(hdr)
+        work = r.new_frame_buffers(w, h)
+        hdr, ldr = r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs, work)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     write_png(args.out, ldr.cpu().numpy())

@@ -1111,4 +1111,52 @@ tr_status tr_tonemap(tr_context* ctx, const void* hdr, uint32_t width, uint32_t 
     return TR_OK;
 }
 
+tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream) {
+    if (!ctx || !f || !f->push || !f->uniforms || !f->culling || !f->view_matrix || !f->view_rotation ||
+        !f->cluster_aabbs || !f->cluster_light_counts || !f->light_indices || !f->hdr || !f->pyramid.texels ||
+        f->num_clusters == 0 || ((f->tonemap == nullptr) != (f->ldr_out == nullptr)))
+        return TR_ERR_INVALID_ARGUMENT;
+    if (f->ldr_out && f->hdr_format != TR_FORMAT_RGBA16F) return TR_ERR_INVALID_ARGUMENT;   // the tonemap reads RGBA16F
+    const uint32_t w = f->push->framebuffer_size[0], h = f->push->framebuffer_size[1];
+    if (f->pyramid.width != w || f->pyramid.height != h) return TR_ERR_INVALID_ARGUMENT;
+    if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
+    // "frustum culling compute shader" + "demultiplex draws compute shader" + the draws
+    tr_status st = tr_frustum_culling(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instances, ctx->num_instances,
+                                      f->culling, ctx->d_instance_counts, stream);
+    if (st != TR_OK) return st;
+    st = tr_assign_lights_to_clusters(ctx, f->view_matrix, f->view_rotation, f->cluster_aabbs, f->num_clusters,
+                                      f->cluster_light_counts, f->light_indices, stream);
+    if (st != TR_OK) return st;
+    st = tr_set_cluster_tables(ctx, f->cluster_light_counts, f->light_indices, f->num_clusters);
+    if (st != TR_OK) return st;
+    void* draws[TR_NUM_DRAW_BUFFERS] = {ctx->d_draws[0], ctx->d_draws[1], ctx->d_draws[2], ctx->d_draws[3]};
+    st = tr_demultiplex_draws(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instance_counts, ctx->d_draw_counts, draws,
+                              stream);
+    if (st != TR_OK) return st;
+    st = tr_rasterize(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream);
+    if (st != TR_OK) return st;
+    // "main opaque" -> "opaque framebuffer mipchain" -> "opaque transmissive objects"
+    tr_gbuffer layers[2];
+    const tr_gbuffer_target* targets[2] = {&f->opaque_layer, &f->transmissive_layer};
+    for (int k = 0; k < 2; ++k) {
+        layers[k].pos_depth = targets[k]->pos_depth;
+        layers[k].nrm_scale = targets[k]->nrm_scale;
+        layers[k].uv = targets[k]->uv;
+        layers[k].material_id = targets[k]->material_id;
+        layers[k].width = w;
+        layers[k].height = h;
+        layers[k].origin_x = layers[k].origin_y = 0;
+    }
+    const tr_rect whole = {0u, 0u, w, h};
+    st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
+    if (st != TR_OK) return st;
+    st = tr_generate_mips(ctx, &f->pyramid, stream);
+    if (st != TR_OK) return st;
+    st = tr_shade_transmission(ctx, &layers[1], f->uniforms, f->push, &f->pyramid, f->hdr, f->hdr_format, whole, stream);
+    if (st != TR_OK) return st;
+    // "tonemapping"
+    if (f->ldr_out) st = tr_tonemap(ctx, f->hdr, w, h, f->tonemap, f->ldr_out, f->bgra, stream);
+    return st;
+}
+
 }  // extern "C"

@@ -325,6 +325,39 @@ class TransmissionRenderer:
                                         self._stream()), "tr_tonemap")
         return out
 
+    def record_frame(self, uniforms: wire.Uniforms, push: wire.PushConstants, culling: wire.CullingPushConstants,
+                     view_matrix: np.ndarray, view_rotation: np.ndarray, aabbs: torch.Tensor, work: dict, tonemap=True):
+        """One frame of the uploaded scene through tr_record_frame (the native recorder: culling, light assignment,
+        demultiplex, rasteriser, opaque, mips, transmissive, tonemap).  `work` = new_frame_buffers(); returns
+        (hdr, ldr or None)."""
+        vm = (C.c_float * 16)(*[float(x) for x in np.asarray(view_matrix, dtype=np.float32).reshape(-1)])
+        q = (C.c_float * 4)(*[float(x) for x in np.asarray(view_rotation, dtype=np.float32).reshape(-1)])
+        params = self.baked_tonemap_params() if tonemap else None
+        self._keep["clusters"] = (work["counts"], work["indices"])
+        d = wire.FrameDesc()
+        d.push, d.uniforms, d.culling = C.pointer(push), C.pointer(uniforms), C.pointer(culling)
+        d.view_matrix, d.view_rotation = C.cast(vm, C.POINTER(C.c_float)), C.cast(q, C.POINTER(C.c_float))
+        d.cluster_aabbs, d.num_clusters = aabbs.data_ptr(), int(aabbs.shape[0])
+        d.cluster_light_counts, d.light_indices = work["counts"].data_ptr(), work["indices"].data_ptr()
+        d.opaque_layer, d.transmissive_layer = self._target(work["opaque"]), self._target(work["transmissive"])
+        d.pyramid = work["pyramid"].desc
+        d.hdr, d.hdr_format = work["hdr"].data_ptr(), self._fmt(work["hdr"])
+        d.bgra = 0
+        if tonemap:
+            d.tonemap, d.ldr_out = C.pointer(params), work["ldr"].data_ptr()
+        self._check(self.lib.tr_record_frame(self._ctx, C.byref(d), self._stream()), "tr_record_frame")
+        return work["hdr"], (work["ldr"] if tonemap else None)
+
+    def new_frame_buffers(self, width: int, height: int, num_clusters: int = wire.NUM_CLUSTERS) -> dict:
+        """The per-frame device buffers tr_record_frame works in (allocated once, reused every frame)."""
+        dev = self.device
+        return {"opaque": self.new_layer(width, height), "transmissive": self.new_layer(width, height),
+                "pyramid": OpaquePyramid(width, height, dev),
+                "hdr": torch.zeros((height, width, 4), dtype=torch.float16, device=dev),
+                "ldr": torch.zeros((height, width, 4), dtype=torch.uint8, device=dev),
+                "counts": torch.zeros(num_clusters, dtype=torch.int32, device=dev),
+                "indices": torch.zeros(num_clusters * wire.MAX_LIGHTS_PER_CLUSTER, dtype=torch.int32, device=dev)}
+
     def record(self, opaque: GBufferPlanes, transmissive: GBufferPlanes, uniforms: wire.Uniforms,
                push: wire.PushConstants, hdr: torch.Tensor, pyramid: OpaquePyramid, rect=None):
         """The hot-path slice of `record()` in the reference's order (src/main.rs:1969-2124)."""

@@ -246,6 +246,16 @@ class GBufferTarget(C.Structure):  # include/tr_shade.h tr_gbuffer_target
     _fields_ = [("pos_depth", C.c_void_p), ("nrm_scale", C.c_void_p), ("uv", C.c_void_p), ("material_id", C.c_void_p)]
 
 
+class FrameDesc(C.Structure):  # include/tr_shade.h tr_frame_desc
+    _fields_ = [("push", C.POINTER(PushConstants)), ("uniforms", C.POINTER(Uniforms)),
+                ("culling", C.POINTER(CullingPushConstants)), ("view_matrix", C.POINTER(C.c_float)),
+                ("view_rotation", C.POINTER(C.c_float)), ("cluster_aabbs", C.c_void_p), ("num_clusters", C.c_uint32),
+                ("_reserved", C.c_uint32), ("cluster_light_counts", C.c_void_p), ("light_indices", C.c_void_p),
+                ("opaque_layer", GBufferTarget), ("transmissive_layer", GBufferTarget), ("pyramid", Pyramid),
+                ("hdr", C.c_void_p), ("hdr_format", C.c_int32), ("bgra", C.c_int32),
+                ("tonemap", C.POINTER(TonemapParams)), ("ldr_out", C.c_void_p)]
+
+
 class TextureDesc(C.Structure):  # include/tr_shade.h tr_texture_desc
     _fields_ = [
         ("rgba8", C.c_void_p),
