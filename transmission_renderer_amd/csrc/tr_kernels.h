@@ -951,8 +951,17 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         if ((TRANSMISSIVE ? active : inside) && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
             claunch* W = launder(L);
             const uint32_t pix = mad24(cur.py, W->fp.width, cur.px);
-            if constexpr (sizeof(OutT) == 8) st<uint2>(W->hdr, pix * 8u, pack_rgba16f(out.x, out.y, out.z, 1.0f));
-            else st<OutT>(W->hdr, pix * 16u, OutT{out.x, out.y, out.z, 1.0f});
+            if constexpr (sizeof(OutT) == 8) {
+                const uint2 o = pack_rgba16f(out.x, out.y, out.z, 1.0f);
+                if constexpr (TRANSMISSIVE) {   // the last writer of the frame: streamed out past L2 (the opaque pass's
+                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));   // targets are re-read at once: cached)
+                    __builtin_nontemporal_store(u2v{o.x, o.y}, reinterpret_cast<u2v*>(static_cast<char*>(W->hdr) + pix * 8u));
+                } else {
+                    st<uint2>(W->hdr, pix * 8u, o);
+                }
+            } else {
+                st<OutT>(W->hdr, pix * 16u, OutT{out.x, out.y, out.z, 1.0f});
+            }
             if constexpr (!TRANSMISSIVE) {
                 uint2* mip0 = W->mip0;
                 if (mip0) st<uint2>(mip0, pix * 8u, pack_rgba16f(out.x, out.y, out.z, 1.0f));
