@@ -738,41 +738,63 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     const int32_t id_thickness = TRANSMISSIVE ? mi->textures.thickness : -1;
     const int32_t id_specular = mi->textures.specular, id_spec_colour = mi->textures.specular_colour;
 
-    texture_fetch f_diffuse, f_mr, f_normal, f_emissive, f_transmission, f_thickness, f_specular, f_spec_colour;
-    if (id_diffuse != -1) texture_issue(f_diffuse, arena, tex + id_diffuse, uv.x, uv.y, qd.uv);
-    if (id_mr != -1) texture_issue(f_mr, arena, tex + id_mr, uv.x, uv.y, qd.uv);
-    if (id_normal != -1) texture_issue(f_normal, arena, tex + id_normal, uv.x, uv.y, qd.uv);
-    if (id_emissive != -1) texture_issue(f_emissive, arena, tex + id_emissive, uv.x, uv.y, qd.uv);
-    if (id_transmission != -1) texture_issue(f_transmission, arena, tex + id_transmission, uv.x, uv.y, qd.uv);
-    if (id_thickness != -1) texture_issue(f_thickness, arena, tex + id_thickness, uv.x, uv.y, qd.uv);
-    if (id_specular != -1) texture_issue(f_specular, arena, tex + id_specular, uv.x, uv.y, qd.uv);
-    if (id_spec_colour != -1) texture_issue(f_spec_colour, arena, tex + id_spec_colour, uv.x, uv.y, qd.uv);
+    // Sampling geometry (LOD, level pair, wrapped tap coordinates, weights) depends on the texture's size only, and a
+    // material's textures usually share one size: it is computed once, for the first bound slot, and every slot of
+    // that size only issues its eight taps (scalar chain base + the shared per-lane offsets).  A slot of another size
+    // is sampled on its own afterwards.  All the conditions are scalar (ids and sizes come from the material record).
+    const int32_t ids[8] = {id_diffuse, id_mr, id_normal, id_emissive, id_transmission, id_thickness, id_specular, id_spec_colour};
+    int32_t first = -1;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) first = ids[k] != -1 ? ids[k] : first;
+    tex_geom g0;
+    uint32_t w0 = 0u, h0 = 0u;
+    if (first != -1) {
+        w0 = tex[first].width;
+        h0 = tex[first].height;
+        tex_geom_compute(g0, tex + first, uv.x, uv.y, qd.uv);
+    }
+    bool shared[8];
+    tex_taps taps[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        shared[k] = ids[k] != -1 && tex[ids[k]].width == w0 && tex[ids[k]].height == h0;
+        if (shared[k]) texture_issue_shared(taps[k], arena, tex + ids[k], g0);
+    }
+    // channel c of slot k (call only when the slot is bound)
+    auto sample = [&](auto slot, auto channel) -> float {
+        constexpr int k = decltype(slot)::value, c = decltype(channel)::value;
+        const bool srgb = tex[ids[k]].srgb != 0u;
+        if (shared[k]) return texture_resolve_shared<c>(taps[k], g0, srgb, lds_srgb);
+        tex_geom g1;
+        tex_taps t1;
+        tex_geom_compute(g1, tex + ids[k], uv.x, uv.y, qd.uv);
+        texture_issue_shared(t1, arena, tex + ids[k], g1);
+        return texture_resolve_shared<c>(t1, g1, srgb, lds_srgb);
+    };
+#define TR_SAMPLE(slot, channel) sample(std::integral_constant<int, slot>{}, std::integral_constant<int, channel>{})
 
     lane_dmat lm;
     // diffuse = diffuse_factor * sample (lib.rs:65-69)
     float dr = mi->diffuse_factor[0], dg = mi->diffuse_factor[1], db = mi->diffuse_factor[2];
     if (id_diffuse != -1) {
-        const bool srgb = tex[id_diffuse].srgb != 0u;
-        dr *= texture_resolve_channel<0>(f_diffuse, srgb, lds_srgb);
-        dg *= texture_resolve_channel<1>(f_diffuse, srgb, lds_srgb);
-        db *= texture_resolve_channel<2>(f_diffuse, srgb, lds_srgb);
+        dr *= TR_SAMPLE(0, 0);
+        dg *= TR_SAMPLE(0, 1);
+        db *= TR_SAMPLE(0, 2);
     }
     // get_material_params (lighting.rs:261-301)
     float metallic = mi->metallic_factor, rough = mi->roughness_factor;
     if (id_mr != -1) {
-        const bool srgb = tex[id_mr].srgb != 0u;
-        metallic *= texture_resolve_channel<2>(f_mr, srgb, lds_srgb);   // "These two are switched!"
-        rough *= texture_resolve_channel<1>(f_mr, srgb, lds_srgb);
+        metallic *= TR_SAMPLE(1, 2);   // "These two are switched!"
+        rough *= TR_SAMPLE(1, 1);
     }
     float scx = mi->specular_colour_factor[0], scy = mi->specular_colour_factor[1], scz = mi->specular_colour_factor[2];
     if (id_spec_colour != -1) {
-        const bool srgb = tex[id_spec_colour].srgb != 0u;
-        scx *= texture_resolve_channel<0>(f_spec_colour, srgb, lds_srgb);
-        scy *= texture_resolve_channel<1>(f_spec_colour, srgb, lds_srgb);
-        scz *= texture_resolve_channel<2>(f_spec_colour, srgb, lds_srgb);
+        scx *= TR_SAMPLE(7, 0);
+        scy *= TR_SAMPLE(7, 1);
+        scz *= TR_SAMPLE(7, 2);
     }
     float specular_factor = mi->specular_factor;
-    if (id_specular != -1) specular_factor *= texture_resolve_channel<3>(f_specular, tex[id_specular].srgb != 0u, lds_srgb);
+    if (id_specular != -1) specular_factor *= TR_SAMPLE(6, 3);
     digest_factors(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
                    L->fp.lut_height, L->fp.lut_stride);
     // get_emission (lighting.rs:303-313)
@@ -780,16 +802,14 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     lm.emission[1] = mi->emissive_factor[1];
     lm.emission[2] = mi->emissive_factor[2];
     if (id_emissive != -1) {
-        const bool srgb = tex[id_emissive].srgb != 0u;
-        lm.emission[0] *= texture_resolve_channel<0>(f_emissive, srgb, lds_srgb);
-        lm.emission[1] *= texture_resolve_channel<1>(f_emissive, srgb, lds_srgb);
-        lm.emission[2] *= texture_resolve_channel<2>(f_emissive, srgb, lds_srgb);
+        lm.emission[0] *= TR_SAMPLE(3, 0);
+        lm.emission[1] *= TR_SAMPLE(3, 1);
+        lm.emission[2] *= TR_SAMPLE(3, 2);
     }
     lm.transmission_factor = mi->transmission_factor;               // lib.rs:71-77
-    if (id_transmission != -1)
-        lm.transmission_factor *= texture_resolve_channel<0>(f_transmission, tex[id_transmission].srgb != 0u, lds_srgb);
+    if (id_transmission != -1) lm.transmission_factor *= TR_SAMPLE(4, 0);
     lm.thickness = mi->thickness_factor;                            // lib.rs:120-124
-    if (id_thickness != -1) lm.thickness *= texture_resolve_channel<1>(f_thickness, tex[id_thickness].srgb != 0u, lds_srgb);
+    if (id_thickness != -1) lm.thickness *= TR_SAMPLE(5, 1);
     lm.eta = dm->eta;
     lm.neg_atten_log2[0] = dm->neg_atten_log2[0];
     lm.neg_atten_log2[1] = dm->neg_atten_log2[1];
@@ -800,11 +820,10 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     if (id_normal != -1) {
         const float inv_n = rsq(dot3(ns.x, ns.y, ns.z, ns.x, ns.y, ns.z));
         const f3 n = {ns.x * inv_n, ns.y * inv_n, ns.z * inv_n};
-        const bool srgb = tex[id_normal].srgb != 0u;
         // map_normal * 255/127 - 128/127 (the compiled shader folds 255/127 into one multiply)
-        const float mx = fmaf(texture_resolve_channel<0>(f_normal, srgb, lds_srgb), 255.0f / 127.0f, -128.0f / 127.0f);
-        const float my = fmaf(texture_resolve_channel<1>(f_normal, srgb, lds_srgb), 255.0f / 127.0f, -128.0f / 127.0f);
-        const float mz = fmaf(texture_resolve_channel<2>(f_normal, srgb, lds_srgb), 255.0f / 127.0f, -128.0f / 127.0f);
+        const float mx = fmaf(TR_SAMPLE(2, 0), 255.0f / 127.0f, -128.0f / 127.0f);
+        const float my = fmaf(TR_SAMPLE(2, 1), 255.0f / 127.0f, -128.0f / 127.0f);
+        const float mz = fmaf(TR_SAMPLE(2, 2), 255.0f / 127.0f, -128.0f / 127.0f);
         auto cross = [](f3 a, f3 b) { return f3{fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y))}; };
         const f3 dp2perp = cross(qd.dp_dy, n), dp1perp = cross(n, qd.dp_dx);
         const f3 t = {fmaf(dp2perp.x, qd.uv.dudx, dp1perp.x * qd.uv.dudy), fmaf(dp2perp.y, qd.uv.dudx, dp1perp.y * qd.uv.dudy),
@@ -817,6 +836,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         ns.y = fmaf(n.y, mz, fmaf(b.y, by_, t.y * tx));
         ns.z = fmaf(n.z, mz, fmaf(b.z, by_, t.z * tx));             // shade_pixel normalises
     }
+#undef TR_SAMPLE
     return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd, ns, lane, cl);
 }
 

@@ -172,4 +172,85 @@ __device__ __forceinline__ float texture_resolve_channel(const texture_fetch& f,
     return (srgb && K < 3) ? r : r * (1.0f / 255.0f);
 }
 
+// ---- the same sampler with the geometry factored out: materials usually bind several textures of one size, and
+// everything up to the tap addresses (LOD, level pair, wrapped tap coordinates, weights) depends on the size only.
+struct tex_geom {
+    uint32_t o[2][4];      // byte offsets of the taps t00, t10, t01, t11 from the chain's first texel, per level
+    float fx[2], fy[2], frac;
+};
+struct tex_taps {
+    uint32_t t[2][4];
+};
+
+__device__ __forceinline__ void tex_geom_level(tex_geom& g, int lv, uint32_t rel, uint32_t w, uint32_t h, float uu, float vv) {
+    const float x = fmaf(uu, (float)w, -0.5f), y = fmaf(vv, (float)h, -0.5f);
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    g.fx[lv] = x - fx0;
+    g.fy[lv] = y - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 += x0 < 0 ? (int)w : 0;
+    y0 += y0 < 0 ? (int)h : 0;
+    x1 -= x1 >= (int)w ? (int)w : 0;
+    y1 -= y1 >= (int)h ? (int)h : 0;
+    const uint32_t ux0 = min((uint32_t)x0, w - 1u), uy0 = min((uint32_t)y0, h - 1u);
+    const uint32_t ux1 = min((uint32_t)x1, w - 1u), uy1 = min((uint32_t)y1, h - 1u);
+    const uint32_t r0 = mad24(uy0, w, rel), r1 = mad24(uy1, w, rel);
+    g.o[lv][0] = (r0 + ux0) * 4u;
+    g.o[lv][1] = (r0 + ux1) * 4u;
+    g.o[lv][2] = (r1 + ux0) * 4u;
+    g.o[lv][3] = (r1 + ux1) * 4u;
+}
+
+__device__ __forceinline__ void tex_geom_compute(tex_geom& g, cdtex* t, float u, float v, const uv_derivs& d) {
+    const float wf = t->wf, hf = t->hf;
+    const float mxx = d.dudx * wf, mxy = d.dvdx * hf, myx = d.dudy * wf, myy = d.dvdy * hf;
+    const float rho2 = fmaxf(fmaf(mxx, mxx, mxy * mxy), fmaf(myx, myx, myy * myy));
+    const float lambda = 0.5f * fast_log2(rho2);
+    const float l = fminf(fmaxf(lambda, 0.0f), t->max_lod);
+    const float lf = floorf(l);
+    g.frac = l - lf;
+    const uint32_t l0 = (uint32_t)lf;
+    const uint32_t l1 = min(l0 + 1u, t->levels - 1u);
+    const u32x2_a4 o = *reinterpret_cast<const TR_CONSTANT u32x2_a4*>(t->offset + l0);
+    const uint32_t base = t->offset[0];                 // (scalar) the same for every texture of this size: relative
+    const uint32_t w = t->width, h = t->height;
+    const float uu = u - floorf(u), vv = v - floorf(v);
+    tex_geom_level(g, 0, o.x - base, max(w >> l0, 1u), max(h >> l0, 1u), uu, vv);
+    tex_geom_level(g, 1, o.y - base, max(w >> l1, 1u), max(h >> l1, 1u), uu, vv);
+}
+
+__device__ __forceinline__ void texture_issue_shared(tex_taps& f, const uint32_t* __restrict__ arena, cdtex* t, const tex_geom& g) {
+    const uint32_t* chain = arena + t->offset[0];       // scalar base: the taps are saddr + voffset loads
+#pragma unroll
+    for (int lv = 0; lv < 2; ++lv)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f.t[lv][k] = ld<uint32_t>(chain, g.o[lv][k]);
+}
+
+template <int K>
+__device__ __forceinline__ float texture_resolve_shared(const tex_taps& f, const tex_geom& g, bool srgb,
+                                                        const float* __restrict__ lds_srgb) {
+    float lv[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        float a, b, c, d;
+        if (srgb && K < 3) {
+            a = lds_srgb[(f.t[l][0] >> (8 * K)) & 0xFFu];
+            b = lds_srgb[(f.t[l][1] >> (8 * K)) & 0xFFu];
+            c = lds_srgb[(f.t[l][2] >> (8 * K)) & 0xFFu];
+            d = lds_srgb[(f.t[l][3] >> (8 * K)) & 0xFFu];
+        } else {
+            a = (float)((f.t[l][0] >> (8 * K)) & 0xFFu);
+            b = (float)((f.t[l][1] >> (8 * K)) & 0xFFu);
+            c = (float)((f.t[l][2] >> (8 * K)) & 0xFFu);
+            d = (float)((f.t[l][3] >> (8 * K)) & 0xFFu);
+        }
+        const float top = fmaf(b - a, g.fx[l], a), bot = fmaf(d - c, g.fx[l], c);
+        lv[l] = fmaf(bot - top, g.fy[l], top);
+    }
+    const float r = fmaf(lv[1] - lv[0], g.frac, lv[0]);
+    return (srgb && K < 3) ? r : r * (1.0f / 255.0f);
+}
+
 }  // namespace tr
