@@ -163,11 +163,23 @@ typedef const TR_CONSTANT tr_launch claunch;
 // The material as the per-pixel code reads it when it has texture slots: the same fields as tr_dmat, but
 // per lane (vector registers), digested per pixel from the sampled factors.
 struct lane_dmat {
-    float diffuse[3], f90, c_diff[3], eta, f0[3], transmission_factor, df[3], thickness, emission[3], rough_ior;
-    float neg_atten_log2[3], lut_fy, a2[2], oma2[2], k[2], bt_a[3], bt_b[3];
-    uint32_t lut_row0, lut_row1, flags;
+    float diffuse[3], f90, eta, f0[3], transmission_factor, df[3], thickness, emission[3], rough_ior;
+    float neg_atten_log2[3], a2[2], oma2[2], k[2];
+    float metallic, rough;   // what the end of the pixel derives c_diff, the btdf coefficients and the LUT row from
+    uint32_t flags;          // (kept instead of those values: they are needed only after the light loop)
 };
 __device__ __forceinline__ const lane_dmat* launder(const lane_dmat* p) { return p; }
+
+// Values read only after the light loop: from the table for a scalar material, derived on the spot for a per-lane one.
+__device__ __forceinline__ float mat_c_diff(const TR_CONSTANT tr_dmat* m, int k) { return m->c_diff[k]; }
+__device__ __forceinline__ float mat_bt_a(const TR_CONSTANT tr_dmat* m, int k) { return m->bt_a[k]; }
+__device__ __forceinline__ float mat_bt_b(const TR_CONSTANT tr_dmat* m, int k) { return m->bt_b[k]; }
+__device__ __forceinline__ float mat_c_diff(const lane_dmat* m, int k) {
+    const float diff = m->diffuse[k];
+    return (diff + (0.0f - diff) * m->metallic) * kFrac1Pi;          // lerp(diffuse, 0, metallic) / pi
+}
+__device__ __forceinline__ float mat_bt_a(const lane_dmat* m, int k) { return m->k[1] * (1.0f - m->f0[k]); }
+__device__ __forceinline__ float mat_bt_b(const lane_dmat* m, int k) { return m->k[1] * m->df[k]; }
 
 // ------------------------------------------------------------------------ one light
 // Accumulators of one pixel over its lights.
@@ -423,19 +435,18 @@ __device__ __forceinline__ f3 pyramid_resolve(pyramid_fetch& pf) {
 // horizontal neighbours of a row in one dword.  R and G ride in the halves of packed ops.
 struct lut_fetch {
     uint32_t p0, p1;
-    float fx;
+    float fx, fy;
     float4 line;   // scalar-material path: both horizontal neighbours of the material's own LUT line
 };
-template <class Mat>
 __device__ __forceinline__ void lut_issue(lut_fetch& lf, const uint32_t* __restrict__ pairs, float lut_wf,
-                                          Mat& m, float nov_raw) {
+                                          uint32_t row0, uint32_t row1, float nov_raw) {
     float x = fmaf(nov_raw, lut_wf, -0.5f);
     x = fminf(fmaxf(x, -1.0f), lut_wf);
     float fl = floorf(x);
     lf.fx = x - fl;
     uint32_t k = (uint32_t)((int)fl + 1);
-    lf.p0 = ld<uint32_t>(pairs, (m.lut_row0 + k) * 4u);
-    lf.p1 = ld<uint32_t>(pairs, (m.lut_row1 + k) * 4u);
+    lf.p0 = ld<uint32_t>(pairs, (row0 + k) * 4u);
+    lf.p1 = ld<uint32_t>(pairs, (row1 + k) * 4u);
 }
 // The same tap for a material in scalar registers: its roughness is fixed, so the row interpolation was done once
 // per material (build_lut_lines_kernel) and the pixel only interpolates along n.v: one 16-byte load, four ops.
@@ -485,7 +496,21 @@ __device__ __forceinline__ f3 debug_colour_for_id(uint32_t id) {
 // base colour): run once per material at upload for materials without textures (digest_materials_kernel, into
 // scalar-read tr_dmat) and once per pixel for textured ones (into lane_dmat).  Same fp32 operations as the
 // reference where a value is a pure function of its inputs (glam-pbr/src/lib.rs:141-161, 182-198, 425-435).
-template <class D>
+// GGX LUT row pair and weight for a roughness (v = perceptual roughness; bilinear, clamp to edge)
+__device__ __forceinline__ void lut_rows(float rough, uint32_t lut_height, uint32_t lut_stride, float& fy, uint32_t& row0,
+                                         uint32_t& row1) {
+#pragma clang fp contract(off)
+    const float fh = (float)lut_height;
+    float y = rough * fh - 0.5f;
+    y = fminf(fmaxf(y, -1.0f), fh);
+    const float fl = floorf(y);
+    fy = y - fl;
+    const int a = (int)fl, mx = (int)lut_height - 1;
+    row0 = (uint32_t)min(max(a, 0), mx) * lut_stride;
+    row1 = (uint32_t)min(max(a + 1, 0), mx) * lut_stride;
+}
+
+template <bool FULL, class D>
 __device__ __forceinline__ void digest_factors(D& d, float metallic, float rough, float ior_clamp, float f0d,
                                                float specular_factor, float scx, float scy, float scz, float dx,
                                                float dy, float dz, uint32_t lut_height, uint32_t lut_stride) {
@@ -503,24 +528,18 @@ __device__ __forceinline__ void digest_factors(D& d, float metallic, float rough
     for (int k = 0; k < 3; ++k) {
         const float diff = diffuse[k];
         d.diffuse[k] = diff;
-        const float cd = diff + (0.0f - diff) * metallic;            // c_diff = lerp(diffuse, 0, metallic)
-        d.c_diff[k] = cd * kFrac1Pi;
         const float ds = f0d * spec_colour[k] * specular_factor;
         d.f0[k] = ds + (diff - ds) * metallic;                       // calculate_combined_f0
         d.df[k] = d.f90 - d.f0[k];
-        d.bt_a[k] = d.k[1] * (1.0f - d.f0[k]);
-        d.bt_b[k] = d.k[1] * d.df[k];
+        if constexpr (FULL) {
+            const float cd = diff + (0.0f - diff) * metallic;        // c_diff = lerp(diffuse, 0, metallic)
+            d.c_diff[k] = cd * kFrac1Pi;
+            d.bt_a[k] = d.k[1] * (1.0f - d.f0[k]);
+            d.bt_b[k] = d.k[1] * d.df[k];
+        }
     }
     d.rough_ior = rough * ior_clamp;                                 // PerceptualRoughness::apply_ior :157-159
-    // GGX LUT row (v = perceptual roughness; bilinear, clamp to edge)
-    const float fh = (float)lut_height;
-    float y = rough * fh - 0.5f;
-    y = fminf(fmaxf(y, -1.0f), fh);
-    const float fl = floorf(y);
-    d.lut_fy = y - fl;
-    const int a = (int)fl, mx = (int)lut_height - 1;
-    d.lut_row0 = (uint32_t)min(max(a, 0), mx) * lut_stride;
-    d.lut_row1 = (uint32_t)min(max(a + 1, 0), mx) * lut_stride;
+    if constexpr (FULL) lut_rows(rough, lut_height, lut_stride, d.lut_fy, d.lut_row0, d.lut_row1);
 }
 
 // ------------------------------------------------------------------------ cluster lookup
@@ -616,8 +635,10 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
         if constexpr (SCALAR_MATERIAL) {
             lut_line_issue(lf, L->lut_lines, (float)L->fp.lut_width, m->lut_line, nov_raw);
-        } else {
-            lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, *m, nov_raw);
+        } else {   // per-pixel roughness: the row pair is found here, not carried through the light loop
+            uint32_t row0, row1;
+            lut_rows(m->rough, L->fp.lut_height, L->fp.lut_stride, lf.fy, row0, row1);
+            lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, row0, row1, nov_raw);
         }
     }
     };
@@ -663,7 +684,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     auto finish = [&]() -> f3 {
         claunch* L4 = launder(L);
         MatP m4 = launder(m);
-        f3 diffuse = {acc.d.x * m4->c_diff[0], acc.d.y * m4->c_diff[1], acc.d.z * m4->c_diff[2]};
+        f3 diffuse = {acc.d.x * mat_c_diff(m4, 0), acc.d.y * mat_c_diff(m4, 1), acc.d.z * mat_c_diff(m4, 2)};
 
         if (transmits) {
             // ---- ibl_volume_refraction, part 2 (:337-353)
@@ -675,12 +696,12 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
             }
             v2f AB;
             if constexpr (SCALAR_MATERIAL) AB = lut_line_resolve(lf);
-            else AB = lut_resolve(lf, m4->lut_fy);
+            else AB = lut_resolve(lf, lf.fy);
             // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
             const float fb = m4->f90 * AB.y;
-            const float bx = fmaf(-m4->bt_b[0], acc.tb.x, m4->bt_a[0] * acc.ta.x);   // sum over lights of transmission_btdf
-            const float by = fmaf(-m4->bt_b[1], acc.tb.y, m4->bt_a[1] * acc.ta.y);
-            const float bz = fmaf(-m4->bt_b[2], acc.tb.z, m4->bt_a[2] * acc.ta.z);
+            const float bx = fmaf(-mat_bt_b(m4, 0), acc.tb.x, mat_bt_a(m4, 0) * acc.ta.x);   // sum over lights of transmission_btdf
+            const float by = fmaf(-mat_bt_b(m4, 1), acc.tb.y, mat_bt_a(m4, 1) * acc.ta.y);
+            const float bz = fmaf(-mat_bt_b(m4, 2), acc.tb.z, mat_bt_a(m4, 2) * acc.ta.z);
             float tx = fmaf(1.0f - fmaf(m4->f0[0], AB.x, fb), T.x, bx) * m4->diffuse[0];
             float ty = fmaf(1.0f - fmaf(m4->f0[1], AB.x, fb), T.y, by) * m4->diffuse[1];
             float tz = fmaf(1.0f - fmaf(m4->f0[2], AB.x, fb), T.z, bz) * m4->diffuse[2];
@@ -753,13 +774,16 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         h0 = tex[first].height;
         tex_geom_compute(g0, tex + first, uv.x, uv.y, qd.uv);
     }
+    // Two groups, so that at most four slots' taps are live at a time: first the slots the material digest needs
+    // (base colour, metallic-roughness, specular, specular colour), then normal, emissive, transmission, thickness.
     bool shared[8];
     tex_taps taps[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        shared[k] = ids[k] != -1 && tex[ids[k]].width == w0 && tex[ids[k]].height == h0;
-        if (shared[k]) texture_issue_shared(taps[k], arena, tex + ids[k], g0);
-    }
+    for (int k = 0; k < 8; ++k) shared[k] = ids[k] != -1 && tex[ids[k]].width == w0 && tex[ids[k]].height == h0;
+    if (shared[0]) texture_issue_shared(taps[0], arena, tex + ids[0], g0);
+    if (shared[1]) texture_issue_shared(taps[1], arena, tex + ids[1], g0);
+    if (shared[6]) texture_issue_shared(taps[6], arena, tex + ids[6], g0);
+    if (shared[7]) texture_issue_shared(taps[7], arena, tex + ids[7], g0);
     // channel c of slot k (call only when the slot is bound)
     auto sample = [&](auto slot, auto channel) -> float {
         constexpr int k = decltype(slot)::value, c = decltype(channel)::value;
@@ -795,8 +819,14 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     }
     float specular_factor = mi->specular_factor;
     if (id_specular != -1) specular_factor *= TR_SAMPLE(6, 3);
-    digest_factors(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
-                   L->fp.lut_height, L->fp.lut_stride);
+    digest_factors<false>(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
+                          L->fp.lut_height, L->fp.lut_stride);
+    lm.metallic = metallic;
+    lm.rough = rough;
+    if (shared[2]) texture_issue_shared(taps[2], arena, tex + ids[2], g0);
+    if (shared[3]) texture_issue_shared(taps[3], arena, tex + ids[3], g0);
+    if (shared[4]) texture_issue_shared(taps[4], arena, tex + ids[4], g0);
+    if (shared[5]) texture_issue_shared(taps[5], arena, tex + ids[5], g0);
     // get_emission (lighting.rs:303-313)
     lm.emission[0] = mi->emissive_factor[0];
     lm.emission[1] = mi->emissive_factor[1];
@@ -1005,7 +1035,7 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
     const float root = (ior - 1.0f) / (ior + 1.0f);
     d.f0_dielectric = root * root;                                   // to_dielectric_f0 :190-195
     d.ior_clamp = fminf(fmaxf(ior * 2.0f - 2.0f, 0.0f), 1.0f);
-    digest_factors(d, mi.metallic_factor, mi.roughness_factor, d.ior_clamp, d.f0_dielectric, mi.specular_factor,
+    digest_factors<true>(d, mi.metallic_factor, mi.roughness_factor, d.ior_clamp, d.f0_dielectric, mi.specular_factor,
                    mi.specular_colour_factor[0], mi.specular_colour_factor[1], mi.specular_colour_factor[2],
                    mi.diffuse_factor[0], mi.diffuse_factor[1], mi.diffuse_factor[2], lut_height, lut_stride);
     for (int k = 0; k < 3; ++k) d.emission[k] = mi.emissive_factor[k];
