@@ -353,7 +353,8 @@ typedef struct tr_geometry_desc {
 } tr_geometry_desc;
 tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* geometry_host, void* stream);
 
-/* One writable TGB-v1 layer covering the whole frame (push->framebuffer_size): device pointers. */
+/* One writable TGB-v1 layer covering the whole frame (push->framebuffer_size): device pointers.  Where a pixel has no
+ * fragment only material_id (= TR_NOT_COVERED) is written; the other planes keep whatever they held. */
 typedef struct tr_gbuffer_target {
     void* pos_depth;    /* float4 */
     void* nrm_scale;    /* float4 */

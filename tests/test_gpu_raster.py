@@ -63,8 +63,9 @@ def _compare(got, want, alpha_materials=(), max_rim_pixels=0):
     """Bit-exact, except that up to `max_rim_pixels` pixels may differ where either side shows an alpha-clipped
     material (the pixel then shows whatever is behind the cut-out on the other side)."""
     differ = got["material_id"] != want["material_id"]
+    covered = want["material_id"] != wire.NOT_COVERED        # without a fragment only the id plane is defined
     for k in ("pos_depth", "nrm_scale", "uv"):
-        differ |= (got[k].view(np.uint32) != want[k].view(np.uint32)).any(axis=2)
+        differ |= (got[k].view(np.uint32) != want[k].view(np.uint32)).any(axis=2) & covered
     if not differ.any():
         return 0
     ys, xs = np.nonzero(differ)

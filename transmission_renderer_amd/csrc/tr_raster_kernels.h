@@ -397,10 +397,7 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_v
     if (px >= f.width || py >= f.height) return;
     const size_t pix = (size_t)py * f.width + px;
     const unsigned long long key = vis[pix];
-    if (key == 0ull) {
-        out.pos_depth[pix] = float4{0.f, 0.f, 0.f, 0.f};
-        out.nrm_scale[pix] = float4{0.f, 0.f, 0.f, 0.f};
-        out.uv[pix] = float2{0.f, 0.f};
+    if (key == 0ull) {   // no fragment: only the id plane is defined there (the shading passes look at nothing else)
         out.material_id[pix] = TR_NOT_COVERED;
         return;
     }
