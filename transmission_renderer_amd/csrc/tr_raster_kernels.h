@@ -51,7 +51,7 @@ struct tr_layer_counts {      // written by scan_draws / scan_items, read by the
     uint32_t num_items;
 };
 
-constexpr uint32_t kItemWidthBlocks = 64u;   // a work item spans at most 64 8x8 blocks horizontally
+constexpr uint32_t kItemWidthBlocks = 8u;    // a work item spans at most 8 8x8 blocks horizontally (short items balance)
 
 // ------------------------------------------------------------------------ block-wide exclusive scan
 // 1024 threads; returns the exclusive prefix of `v` over the block and the block total (in every thread).
@@ -269,10 +269,10 @@ __global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const uin
 
 // Barycentrics and depth at a pixel centre (oracle: tri_pixel).  `rec` is wave-uniform in the raster kernel
 // (scalar registers) and per lane in the resolve.
+// The three edge functions at a pixel centre and the top-left-rule inside test.
 template <class Rec>
-__device__ __forceinline__ bool tri_pixel(const Rec& rec, float pxc, float pyc, float lambda[3], float& depth) {
+__device__ __forceinline__ bool tri_edges(const Rec& rec, float pxc, float pyc, float fv[3]) {
 #pragma clang fp contract(off)
-    float fv[3];
     bool inside = true;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -280,6 +280,13 @@ __device__ __forceinline__ bool tri_pixel(const Rec& rec, float pxc, float pyc, 
         const bool tie = rec.A[i] > 0.0f || (rec.A[i] == 0.0f && rec.B[i] > 0.0f);
         inside &= fv[i] > 0.0f || (fv[i] == 0.0f && tie);
     }
+    return inside;
+}
+
+// Barycentrics and depth from the edge values; true if the fragment survives clipping and the depth range.
+template <class Rec>
+__device__ __forceinline__ bool tri_depth(const Rec& rec, const float fv[3], float lambda[3], float& depth) {
+#pragma clang fp contract(off)
     const float sum = (fv[0] + fv[1]) + fv[2];
     const float inv = 1.0f / sum;
 #pragma unroll
@@ -287,7 +294,14 @@ __device__ __forceinline__ bool tri_pixel(const Rec& rec, float pxc, float pyc, 
     const float zc = (lambda[0] * rec.z[0] + lambda[1] * rec.z[1]) + lambda[2] * rec.z[2];
     const float wc = (lambda[0] * rec.w[0] + lambda[1] * rec.w[1]) + lambda[2] * rec.w[2];
     depth = zc / wc;
-    return inside && sum > 0.0f && wc > 0.0f && zc <= wc && depth > 0.0f;
+    return sum > 0.0f && wc > 0.0f && zc <= wc && depth > 0.0f;
+}
+
+template <class Rec>
+__device__ __forceinline__ bool tri_pixel(const Rec& rec, float pxc, float pyc, float lambda[3], float& depth) {
+    float fv[3];
+    const bool inside = tri_edges(rec, pxc, pyc, fv);
+    return tri_depth(rec, fv, lambda, depth) && inside;
 }
 
 struct tr_alpha_tables {        // what the alpha-clip kill reads (depth_pre_pass_alpha_clip, shader/src/lib.rs:269-292)
@@ -335,9 +349,11 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
         const bool alpha_clip = (rec.flags & 1u) != 0u;
         for (uint32_t bx = bstart; bx <= bend; ++bx) {
             const uint32_t px = bx * 8u + (lane & 7u);
-            float lam[3], depth;
-            bool hit = tri_pixel(rec, (float)px + 0.5f, (float)py + 0.5f, lam, depth);
+            float fv[3], lam[3], depth;
+            bool hit = tri_edges(rec, (float)px + 0.5f, (float)py + 0.5f, fv);
             hit = hit && px >= rec.x0 && px <= rec.x1 && py >= rec.y0 && py <= rec.y1;
+            if (ballot(hit) == 0ull) continue;   // the block misses the triangle (half of a large triangle's box does)
+            hit = tri_depth(rec, fv, lam, depth) && hit;
             const size_t pix = (size_t)py * f.width + px;
             if (hit && behind) hit = depth > __uint_as_float((uint32_t)(behind[pix] >> 32));   // nearer than the opaque surface
             if (hit && alpha_clip) {
