@@ -428,6 +428,97 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* gbuffer, cons
                                 const tr_push_constants* push, const tr_pyramid* pyramid,
                                 void* hdr_inout, tr_format format, tr_rect rect, void* stream);
 
+/* ------------------------------------------------- the glam-pbr shading API */
+/*
+ * glam-pbr's public functions (glam-pbr/src/lib.rs), batched: element i of the output is the reference function
+ * applied to element i of the input.  They are pure per-sample functions in the reference (by-value Copy structs,
+ * no errors, NaN propagates); here the arrays live in HBM (device pointers, tightly packed, 4-byte aligned), one
+ * thread evaluates one element on `stream`, and the arithmetic is the passes' own device code (same digest, same
+ * light evaluation, same samplers), so a caller that keeps its own G-buffer gets the values the passes produce.
+ * Direction vectors (`normal`, `view`, `light`) are unit vectors, as the reference's only caller passes them
+ * (shader/src/lib.rs:79-80, shader/src/lighting.rs:229; `Normal` / `View` / `Light` wrap them without normalising).
+ */
+
+/* `MaterialParams` (:172-179; `PerceptualRoughness` and `IndexOfRefraction` are f32 newtypes). 40 B. */
+typedef struct tr_material_params {
+    float diffuse_colour[3];
+    float metallic;
+    float perceptual_roughness;
+    float index_of_refraction;
+    float specular_colour[3];
+    float specular_factor;
+} tr_material_params;
+
+/* `BasicBrdfParams` (:163-169). 88 B. */
+typedef struct tr_basic_brdf_params {
+    float normal[3];
+    float light[3];              /* direction to the light */
+    float light_intensity[3];
+    float view[3];
+    tr_material_params material_params;
+} tr_basic_brdf_params;
+
+/* `BrdfResult` (:438-441). 24 B. */
+typedef struct tr_brdf_result {
+    float diffuse[3];
+    float specular[3];
+} tr_brdf_result;
+
+/* The arguments of `transmission_btdf(material_params, normal, view, light)` (:200-205). 76 B. */
+typedef struct tr_transmission_btdf_params {
+    tr_material_params material_params;
+    float normal[3];
+    float view[3];
+    float light[3];
+} tr_transmission_btdf_params;
+
+/* `IblVolumeRefractionParams` (:235-246). 168 B. */
+typedef struct tr_ibl_volume_refraction_params {
+    tr_material_params material_params;
+    uint32_t framebuffer_size_x;
+    float normal[3];
+    float view[3];
+    float proj_view_matrix[16];  /* column-major */
+    float position[3];
+    float thickness;
+    float model_scale;
+    float attenuation_distance;  /* +INF = no attenuation */
+    float attenuation_colour[3];
+} tr_ibl_volume_refraction_params;
+
+/* What `light_direction_and_attenuation` returns (:12-23): (direction, distance, attenuation). 20 B. */
+typedef struct tr_light_direction {
+    float direction[3];
+    float distance;
+    float attenuation;
+} tr_light_direction;
+
+/* basic_brdf (:377-423): params_dev = tr_basic_brdf_params[count], results_dev = tr_brdf_result[count]. */
+tr_status tr_basic_brdf(tr_context* ctx, const void* params_dev, uint32_t count, void* results_dev, void* stream);
+/* transmission_btdf (:200-233): params_dev = tr_transmission_btdf_params[count], rgb_dev = float[count][3]. */
+tr_status tr_transmission_btdf(tr_context* ctx, const void* params_dev, uint32_t count, void* rgb_dev, void* stream);
+/* ibl_volume_refraction (:292-354) with the two closures the reference's caller passes (shader/src/lib.rs:126-138):
+ * framebuffer_sampler = the opaque pyramid through clamp_sampler (trilinear, `framebuffer` below),
+ * ggx_lut_sampler = the GGX LUT given to tr_upload_ggx_lut (bilinear, clamp).
+ * params_dev = tr_ibl_volume_refraction_params[count], rgb_dev = float[count][3]. */
+tr_status tr_ibl_volume_refraction(tr_context* ctx, const void* params_dev, uint32_t count, const tr_pyramid* framebuffer,
+                                   void* rgb_dev, void* stream);
+/* light_direction_and_attenuation (:12-23): two float[count][3] arrays in, tr_light_direction[count] out. */
+tr_status tr_light_direction_and_attenuation(tr_context* ctx, const void* fragment_position_dev,
+                                             const void* light_position_dev, uint32_t count, void* out_dev, void* stream);
+/* d_ggx (:101-109), v_smith_ggx_correlated (:114-133): float[count] arrays; `roughness` is the ACTUAL roughness. */
+tr_status tr_d_ggx(tr_context* ctx, const void* normal_dot_halfway_dev, const void* roughness_dev, uint32_t count,
+                   void* out_dev, void* stream);
+tr_status tr_v_smith_ggx_correlated(tr_context* ctx, const void* normal_dot_view_dev, const void* normal_dot_light_dev,
+                                    const void* roughness_dev, uint32_t count, void* out_dev, void* stream);
+/* fresnel_schlick (:137-139): view_dot_halfway float[count], f0 / f90 / out float[count][3]. */
+tr_status tr_fresnel_schlick(tr_context* ctx, const void* view_dot_halfway_dev, const void* f0_dev, const void* f90_dev,
+                             uint32_t count, void* out_dev, void* stream);
+/* compute_f0 (:454-465; exported by glam-pbr, unused by the renderer): metallic, ior float[count], diffuse_colour and
+ * out float[count][3]. */
+tr_status tr_compute_f0(tr_context* ctx, const void* metallic_dev, const void* index_of_refraction_dev,
+                        const void* diffuse_colour_dev, uint32_t count, void* out_dev, void* stream);
+
 /* ------------------------------------------------------------------ tonemap */
 
 /* Host only: Lottes' curve constants from the un-baked parameters (what colstodian's
@@ -482,6 +573,12 @@ tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* frame, void* str
 #else
 #define TR_STATIC_ASSERT(c, m) _Static_assert(c, m)
 #endif
+TR_STATIC_ASSERT(sizeof(tr_material_params) == 40, "MaterialParams is 10 floats");
+TR_STATIC_ASSERT(sizeof(tr_basic_brdf_params) == 88, "BasicBrdfParams is 22 floats");
+TR_STATIC_ASSERT(sizeof(tr_brdf_result) == 24, "BrdfResult is 6 floats");
+TR_STATIC_ASSERT(sizeof(tr_transmission_btdf_params) == 76, "transmission_btdf arguments are 19 floats");
+TR_STATIC_ASSERT(sizeof(tr_ibl_volume_refraction_params) == 168, "IblVolumeRefractionParams is 42 words");
+TR_STATIC_ASSERT(sizeof(tr_light_direction) == 20, "(Vec3, f32, f32)");
 TR_STATIC_ASSERT(sizeof(tr_push_constants) == 96, "PushConstants is 96 B");
 TR_STATIC_ASSERT(offsetof(tr_push_constants, view_position) == 64, "view_position @64");
 TR_STATIC_ASSERT(offsetof(tr_push_constants, framebuffer_size) == 80, "framebuffer_size @80");

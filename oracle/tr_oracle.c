@@ -1411,3 +1411,84 @@ void o_tonemap_frame(const uint16_t* hdr, uint32_t n, const tr_tonemap_params* p
         if (out_rgba8) out_rgba8[i * 4 + 3] = 255;
     }
 }
+
+/* ------------------------------------------------------------------ batch forms of the glam-pbr API */
+static o_material_params mp_of(const tr_material_params* m) {
+    o_material_params o;
+    o.diffuse_colour = f3(m->diffuse_colour);
+    o.metallic = m->metallic;
+    o.perceptual_roughness = m->perceptual_roughness;
+    o.index_of_refraction = m->index_of_refraction;
+    o.specular_colour = f3(m->specular_colour);
+    o.specular_factor = m->specular_factor;
+    return o;
+}
+static void put3(double* out, o_vec3 v) { out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+
+void o_basic_brdf_batch(const tr_basic_brdf_params* p, uint32_t n, double* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        o_brdf_result r = o_basic_brdf(f3(p[i].normal), f3(p[i].light), f3(p[i].light_intensity), f3(p[i].view),
+                                       mp_of(&p[i].material_params));
+        put3(out + 6 * (size_t)i, r.diffuse);
+        put3(out + 6 * (size_t)i + 3, r.specular);
+    }
+}
+
+void o_transmission_btdf_batch(const tr_transmission_btdf_params* p, uint32_t n, double* out) {
+    for (uint32_t i = 0; i < n; ++i)
+        put3(out + 3 * (size_t)i, o_transmission_btdf(mp_of(&p[i].material_params), f3(p[i].normal), f3(p[i].view), f3(p[i].light)));
+}
+
+typedef struct { const uint8_t* rgba8; uint32_t w, h; } lut_image_t;
+static o_vec2 lut_image_cb(void* user, real nov, real roughness) {
+    const lut_image_t* l = (const lut_image_t*)user;
+    return o_sample_lut(l->rgba8, l->w, l->h, nov, roughness);
+}
+
+void o_ibl_volume_refraction_batch(const tr_ibl_volume_refraction_params* p, uint32_t n, const o_pyramid* framebuffer,
+                                   const uint8_t* ggx_lut_rgba8, uint32_t lut_width, uint32_t lut_height, double* out) {
+    fb_user_t fbu = {framebuffer};
+    lut_image_t lu = {ggx_lut_rgba8, lut_width, lut_height};
+    for (uint32_t i = 0; i < n; ++i) {
+        o_ibl_volume_refraction_params q;
+        q.material_params = mp_of(&p[i].material_params);
+        q.framebuffer_size_x = p[i].framebuffer_size_x;
+        q.normal = f3(p[i].normal);
+        q.view = f3(p[i].view);
+        for (int k = 0; k < 16; ++k) q.proj_view_matrix[k] = p[i].proj_view_matrix[k];
+        q.position = f3(p[i].position);
+        q.thickness = p[i].thickness;
+        q.model_scale = p[i].model_scale;
+        q.attenuation_distance = p[i].attenuation_distance;
+        q.attenuation_colour = f3(p[i].attenuation_colour);
+        put3(out + 3 * (size_t)i, o_ibl_volume_refraction(&q, fb_sampler_cb, &fbu, lut_image_cb, &lu));
+    }
+}
+
+void o_light_direction_and_attenuation_batch(const float* fp, const float* lp, uint32_t n, double* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        o_vec3 d;
+        real dist, att;
+        o_light_direction_and_attenuation(f3(fp + 3 * (size_t)i), f3(lp + 3 * (size_t)i), &d, &dist, &att);
+        put3(out + 5 * (size_t)i, d);
+        out[5 * (size_t)i + 3] = dist;
+        out[5 * (size_t)i + 4] = att;
+    }
+}
+
+void o_d_ggx_batch(const float* noh, const float* roughness, uint32_t n, double* out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = o_d_ggx(noh[i], roughness[i]);
+}
+
+void o_v_smith_ggx_correlated_batch(const float* nov, const float* nol, const float* roughness, uint32_t n, double* out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = o_v_smith_ggx_correlated(nov[i], nol[i], roughness[i]);
+}
+
+void o_fresnel_schlick_batch(const float* voh, const float* f0, const float* f90, uint32_t n, double* out) {
+    for (uint32_t i = 0; i < n; ++i)
+        put3(out + 3 * (size_t)i, o_fresnel_schlick(voh[i], f3(f0 + 3 * (size_t)i), f3(f90 + 3 * (size_t)i)));
+}
+
+void o_compute_f0_batch(const float* metallic, const float* ior, const float* diffuse, uint32_t n, double* out) {
+    for (uint32_t i = 0; i < n; ++i) put3(out + 3 * (size_t)i, o_compute_f0(metallic[i], ior[i], f3(diffuse + 3 * (size_t)i)));
+}

@@ -229,6 +229,19 @@ int  o_alpha_clip_kills(const o_scene* s, uint32_t material_id, o_vec2 uv, o_vec
 void o_rasterize(const o_scene* s, const o_geometry* geo, const tr_draw_command* const draws[4],
                  const uint32_t draw_counts[4], uint32_t width, uint32_t height, o_layer opaque, o_layer transmissive);
 
+/* ---- batch forms of the glam-pbr API: the checker of tr_basic_brdf & co (include/tr_shade.h).  Float records in,
+ * `double` out, so libtr_oracle.so (fp32 arithmetic) and libtr_oracle64.so (fp64) share the signatures. ---- */
+void o_basic_brdf_batch(const tr_basic_brdf_params* p, uint32_t n, double* out6);
+void o_transmission_btdf_batch(const tr_transmission_btdf_params* p, uint32_t n, double* out3);
+void o_ibl_volume_refraction_batch(const tr_ibl_volume_refraction_params* p, uint32_t n, const o_pyramid* framebuffer,
+                                   const uint8_t* ggx_lut_rgba8, uint32_t lut_width, uint32_t lut_height, double* out3);
+void o_light_direction_and_attenuation_batch(const float* fragment_position3, const float* light_position3, uint32_t n,
+                                             double* out5);
+void o_d_ggx_batch(const float* noh, const float* roughness, uint32_t n, double* out);
+void o_v_smith_ggx_correlated_batch(const float* nov, const float* nol, const float* roughness, uint32_t n, double* out);
+void o_fresnel_schlick_batch(const float* voh, const float* f0_3, const float* f90_3, uint32_t n, double* out3);
+void o_compute_f0_batch(const float* metallic, const float* ior, const float* diffuse3, uint32_t n, double* out3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,8 @@ SYMBOLS = (
     "tr_upload_geometry", "tr_rasterize", "tr_draw_scene",
     "tr_write_cluster_data", "tr_assign_lights_to_clusters", "tr_shade_opaque",
     "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap", "tr_record_frame",
+    "tr_basic_brdf", "tr_transmission_btdf", "tr_ibl_volume_refraction", "tr_light_direction_and_attenuation", "tr_d_ggx",
+    "tr_v_smith_ggx_correlated", "tr_fresnel_schlick", "tr_compute_f0",
 )
 
 _lib = None
@@ -110,6 +112,13 @@ def load() -> C.CDLL:
     lib.tr_tonemap.argtypes = [vp, vp, u32, u32, C.POINTER(wire.TonemapParams), vp, i32, vp]
     lib.tr_record_frame.restype = i32
     lib.tr_record_frame.argtypes = [vp, C.POINTER(wire.FrameDesc), vp]
+    for name, nptr in (("tr_basic_brdf", 1), ("tr_transmission_btdf", 1), ("tr_light_direction_and_attenuation", 2),
+                       ("tr_d_ggx", 2), ("tr_v_smith_ggx_correlated", 3), ("tr_fresnel_schlick", 3), ("tr_compute_f0", 3)):
+        fn = getattr(lib, name)   # (ctx, <nptr input arrays>, count, out, stream)
+        fn.restype = i32
+        fn.argtypes = [vp] + [vp] * nptr + [u32, vp, vp]
+    lib.tr_ibl_volume_refraction.restype = i32
+    lib.tr_ibl_volume_refraction.argtypes = [vp, vp, u32, C.POINTER(wire.Pyramid), vp, vp]
     if lib.tr_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.tr_abi_version()} != 1")
     _lib = lib

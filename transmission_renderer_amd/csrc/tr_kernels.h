@@ -665,6 +665,8 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         uint32_t i = 0;
         uint32_t head = num_lights ? cl.l0 : kDone;
         uint64_t pending = ballot(head != kDone);
+        // (wave-uniform: with at most two lights per list — l0, l1 — the loop has no memory access at all)
+        const bool long_lists = ballot(num_lights > 2u) != 0ull;
         while (pending) {
             const int l0 = __ffsll((unsigned long long)pending) - 1;
             const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)head, l0);
@@ -672,7 +674,11 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
             if (head == h0) {
                 ++i;
                 uint32_t next = cl.l1;
-                if (i >= 2u)   // longer lists: the entry is in flight during the evaluation
+#ifdef TR_AB_TAIL_ALWAYS   // experiments only (tools/ab_kernel.py)
+                if (i >= 2u)
+#else
+                if (long_lists && i >= 2u)   // longer lists: the entry is in flight during the evaluation
+#endif
                     next = ld<uint32_t>(L2->light_indices, cl.list_offset + min(i, TR_MAX_LIGHTS_PER_CLUSTER - 1u) * 4u);
                 eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0s], pos, px, transmits);
                 head = i < num_lights ? next : kDone;

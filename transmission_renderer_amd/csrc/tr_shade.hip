@@ -8,6 +8,7 @@
 #include "tr_cluster_kernels.h"
 #include "tr_geometry_kernels.h"
 #include "tr_raster_kernels.h"
+#include "tr_glam_pbr_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1064,6 +1065,117 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
             else hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, L);
         }
     }
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+// ------------------------------------------------------------------------ the glam-pbr shading API (batched)
+namespace {
+// 2^24 elements per launch keeps every 32-bit byte offset of the 168-byte records below 4 GiB.
+constexpr uint32_t kMaxBatch = 1u << 24;
+inline bool batch_args_ok(const tr_context* ctx, uint32_t count, std::initializer_list<const void*> arrays) {
+    if (!ctx || count > kMaxBatch) return false;
+    for (const void* a : arrays)
+        if (!a || ((uintptr_t)a & 3u)) return false;
+    return true;
+}
+inline uint32_t batch_grid(uint32_t count) { return (count + 255u) / 256u; }
+}  // namespace
+
+tr_status tr_basic_brdf(tr_context* ctx, const void* params, uint32_t count, void* results, void* stream_) {
+    if (!batch_args_ok(ctx, count, {params, results})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(basic_brdf_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_,
+                       (const tr_basic_brdf_params*)params, count, (tr_brdf_result*)results);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_transmission_btdf(tr_context* ctx, const void* params, uint32_t count, void* rgb, void* stream_) {
+    if (!batch_args_ok(ctx, count, {params, rgb})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(transmission_btdf_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_,
+                       (const tr_transmission_btdf_params*)params, count, (float*)rgb);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_ibl_volume_refraction(tr_context* ctx, const void* params, uint32_t count, const tr_pyramid* p, void* rgb,
+                                   void* stream_) {
+    if (!batch_args_ok(ctx, count, {params, rgb}) || !p || !p->texels || p->levels == 0 || p->levels > TR_MAX_MIP_LEVELS)
+        return TR_ERR_INVALID_ARGUMENT;
+    if (!ctx->d_lut_pairs || ctx->lut_h == 0) return TR_ERR_TABLES_MISSING;   // the ggx_lut_sampler closure
+    if (count == 0) return TR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    tr_status st = ensure_levels(ctx, p, stream);
+    if (st != TR_OK) return st;
+    tr_ibl_tables t;
+    t.pyramid = (const uint2*)p->texels;
+    t.levels = ctx->d_levels;
+    t.pyr_levels = p->levels;
+    t.lut_pairs = ctx->d_lut_pairs;
+    t.lut_width = ctx->lut_w;
+    t.lut_height = ctx->lut_h;
+    t.lut_stride = ctx->lut_stride;
+    hipLaunchKernelGGL(ibl_volume_refraction_kernel, dim3(batch_grid(count)), dim3(256), 0, stream,
+                       (const tr_ibl_volume_refraction_params*)params, count, t, (float*)rgb);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_light_direction_and_attenuation(tr_context* ctx, const void* fragment_position, const void* light_position,
+                                             uint32_t count, void* out, void* stream_) {
+    if (!batch_args_ok(ctx, count, {fragment_position, light_position, out})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(light_direction_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_,
+                       (const float*)fragment_position, (const float*)light_position, count, (float*)out);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_d_ggx(tr_context* ctx, const void* noh, const void* roughness, uint32_t count, void* out, void* stream_) {
+    if (!batch_args_ok(ctx, count, {noh, roughness, out})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(d_ggx_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_, (const float*)noh,
+                       (const float*)roughness, count, (float*)out);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_v_smith_ggx_correlated(tr_context* ctx, const void* nov, const void* nol, const void* roughness, uint32_t count,
+                                    void* out, void* stream_) {
+    if (!batch_args_ok(ctx, count, {nov, nol, roughness, out})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(v_smith_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_, (const float*)nov,
+                       (const float*)nol, (const float*)roughness, count, (float*)out);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_fresnel_schlick(tr_context* ctx, const void* voh, const void* f0, const void* f90, uint32_t count, void* out,
+                             void* stream_) {
+    if (!batch_args_ok(ctx, count, {voh, f0, f90, out})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(fresnel_schlick_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_, (const float*)voh,
+                       (const float*)f0, (const float*)f90, count, (float*)out);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_compute_f0(tr_context* ctx, const void* metallic, const void* ior, const void* diffuse, uint32_t count,
+                        void* out, void* stream_) {
+    if (!batch_args_ok(ctx, count, {metallic, ior, diffuse, out})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(compute_f0_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_, (const float*)metallic,
+                       (const float*)ior, (const float*)diffuse, count, (float*)out);
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }

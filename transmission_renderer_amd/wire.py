@@ -211,6 +211,24 @@ PRIMITIVE_DTYPE = np.dtype([("packed_bounding_sphere", np.float32, 4), ("draw_bu
 DRAW_COMMAND_DTYPE = np.dtype([("index_count", np.uint32), ("instance_count", np.uint32), ("first_index", np.uint32),
                                ("vertex_offset", np.int32), ("first_instance", np.uint32)])
 assert INSTANCE_DTYPE.itemsize == 48 and PRIMITIVE_DTYPE.itemsize == 32 and DRAW_COMMAND_DTYPE.itemsize == 20
+
+# ---- the glam-pbr API's records (include/tr_shade.h; glam-pbr/src/lib.rs:163-179, 200-205, 235-246, 438-441)
+MATERIAL_PARAMS_DTYPE = np.dtype([("diffuse_colour", np.float32, 3), ("metallic", np.float32),
+                                  ("perceptual_roughness", np.float32), ("index_of_refraction", np.float32),
+                                  ("specular_colour", np.float32, 3), ("specular_factor", np.float32)])
+BASIC_BRDF_PARAMS_DTYPE = np.dtype([("normal", np.float32, 3), ("light", np.float32, 3), ("light_intensity", np.float32, 3),
+                                    ("view", np.float32, 3), ("material_params", MATERIAL_PARAMS_DTYPE)])
+BRDF_RESULT_DTYPE = np.dtype([("diffuse", np.float32, 3), ("specular", np.float32, 3)])
+TRANSMISSION_BTDF_PARAMS_DTYPE = np.dtype([("material_params", MATERIAL_PARAMS_DTYPE), ("normal", np.float32, 3),
+                                           ("view", np.float32, 3), ("light", np.float32, 3)])
+IBL_VOLUME_REFRACTION_PARAMS_DTYPE = np.dtype([
+    ("material_params", MATERIAL_PARAMS_DTYPE), ("framebuffer_size_x", np.uint32), ("normal", np.float32, 3),
+    ("view", np.float32, 3), ("proj_view_matrix", np.float32, 16), ("position", np.float32, 3), ("thickness", np.float32),
+    ("model_scale", np.float32), ("attenuation_distance", np.float32), ("attenuation_colour", np.float32, 3)])
+LIGHT_DIRECTION_DTYPE = np.dtype([("direction", np.float32, 3), ("distance", np.float32), ("attenuation", np.float32)])
+assert (MATERIAL_PARAMS_DTYPE.itemsize, BASIC_BRDF_PARAMS_DTYPE.itemsize, BRDF_RESULT_DTYPE.itemsize,
+        TRANSMISSION_BTDF_PARAMS_DTYPE.itemsize, IBL_VOLUME_REFRACTION_PARAMS_DTYPE.itemsize,
+        LIGHT_DIRECTION_DTYPE.itemsize) == (40, 88, 24, 76, 168, 20)
 NUM_DRAW_BUFFERS = 4
 
 
