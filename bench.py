@@ -154,19 +154,29 @@ def main():
     def step():
         r.shade_transmission(g, uniforms, push, pyr, hdr, rect)
 
+    # Untimed warm-up: W steps — and before them, as many as it takes to have kept the GPU busy for 50 ms: its clocks
+    # ramp over the first ~10 ms of load (measured: the first ~70 back-to-back 4K launches run 10-15 % slow), and the
+    # metric is steady-state throughput.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.05:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # Timed region: exactly K launches back to back, bracketed by the barrier + synchronize pairs (wall clock -> value)
+    # and by ONE pair of HIP events on the launch stream (-> the kernel's average launch duration for the roofline).
+    # No per-launch events here: each record is a barrier packet between two launches and costs them ~5 us apiece.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
-        starts[i].record()      # HIP events on the stream the kernel is launched on
         step()
-        ends[i].record()
+    ev1.record()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -176,6 +186,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    avg_launch_ms = ev0.elapsed_time(ev1) / args.steps
+    # Second pass, outside the timed region: per-launch events for the frame-time percentiles of the metric.
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    for i in range(args.steps):
+        starts[i].record()
+        step()
+        ends[i].record()
+    torch.cuda.synchronize()
     kernel_ms = np.array([s.elapsed_time(e) for s, e in zip(starts, ends)], dtype=np.float64)
 
     composite_ms = None
@@ -197,7 +216,7 @@ def main():
     pixels_total = pixels_rank * world
     ms_per_step = elapsed / args.steps * 1e3
     value = pixels_total * args.steps / elapsed / 1e6
-    avg_kernel_s = float(kernel_ms.mean()) * 1e-3
+    avg_kernel_s = avg_launch_ms * 1e-3
     achieved = pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL / avg_kernel_s / 1e9
 
     if rank == 0:

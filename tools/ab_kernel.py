@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of kernel variants on ONE box: python tools/ab_kernel.py [--lights N] [--rounds R] lib_a.so lib_b.so ...
 Each variant is timed in its own child process (the library is loaded once per process), variants interleaved over
-R rounds; prints the per-variant median of the per-launch HIP-event times of the 4K transmissive pass.
+R rounds; prints the per-variant median of the average launch time over back-to-back batches of the 4K transmissive
+pass at steady-state clocks.
 Experiments only: the product always loads transmission_renderer_amd/libtr_shade.so."""
 import json, os, statistics, subprocess, sys
 
@@ -22,15 +23,33 @@ g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
 pyr = OpaquePyramid(w, h, r.device)
 pyr.level(0).copy_(torch.from_numpy(synthetic.make_opaque_mip0(w, h)).to(r.device)); r.generate_mips(pyr)
 hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
-for _ in range(20): r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr)
-torch.cuda.synchronize()
+# steady state: the GPU's clocks ramp over the first ~10 ms of continuous load (a launch + sync per step never gets
+# there: 4K launches then take ~130 us instead of ~100), so warm up for 100 ms and time back-to-back batches
+import time
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.1:
+    for _ in range(16): r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr)
+    torch.cuda.synchronize()
 ts = []
-for _ in range(int(os.environ.get("TR_AB_STEPS", "200"))):
+batch = 50
+for _ in range(int(os.environ.get("TR_AB_STEPS", "400")) // batch):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr); b.record(); b.synchronize()
-    ts.append(a.elapsed_time(b) * 1e3)
+    a.record()
+    for _ in range(batch): r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr)
+    b.record(); b.synchronize()
+    ts.append(a.elapsed_time(b) * 1e3 / batch)
 ts.sort()
-print(json.dumps({"p50": ts[len(ts) // 2], "p10": ts[len(ts) // 10], "min": ts[0]}))
+res = {"p50": ts[len(ts) // 2], "p10": ts[0], "min": ts[0]}
+try:   # -DTR_TIMING=1 builds: per-wave wait cycles (100 MHz s_memtime ticks) of one launch
+    fn = r.lib.tr_debug_read_timing
+    buf = (C.c_ulonglong * 8)()
+    fn(buf)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr); torch.cuda.synchronize()
+    fn(buf)
+    res["timing"] = list(buf)
+except AttributeError:
+    pass
+print(json.dumps(res))
 '''
 
 
@@ -50,7 +69,14 @@ def main():
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
             if not line:
                 print(lib, "FAILED", out.stderr[-400:]); continue
+            if os.environ.get("TR_TIMING_DUMP"): print(out.stderr[-3000:])
             res[lib].append(json.loads(line[-1]))
+            if "timing" in res[lib][-1]:
+                w0, w1, w2, total, tiles, waves = res[lib][-1]["timing"][:6]
+                longest, waves = waves >> 32, waves & 0xFFFFFFFF
+                print(f"  {os.path.basename(lib)}: per tile and wave (s_memtime ticks): planes wait {w0 / tiles:.1f}, cluster lists {w1 / tiles:.1f}, "
+                      f"taps+LUT {w2 / tiles:.1f}, whole tile {total / tiles:.1f}; {tiles / waves:.2f} tiles per wave, {waves} waves, longest-lived wave {longest} ticks, mean {total / waves:.0f}; "
+                      f"most loaded XCD {res[lib][-1]['timing'][6] / 1000:.3f} of the mean; shader clock while the waves ran {total / max(res[lib][-1]['timing'][7], 1) * 100:.0f} MHz")
     for lib, rs in res.items():
         if rs:
             print(f"{os.path.basename(lib):40s} p50 {statistics.median(r['p50'] for r in rs):7.1f} us  p10 {statistics.median(r['p10'] for r in rs):7.1f}  min {min(r['min'] for r in rs):7.1f}   ({[round(r['p50'], 1) for r in rs]})")

@@ -49,6 +49,36 @@ namespace tr {
 #define TR_ABLATION 0
 #endif
 #define TR_ABLATE(L, bit) (TR_ABLATION && ((L)->fp.ablate & (bit)))
+// Profiling builds (-DTR_TIMING=1, tools/ab_kernel.py): every wave adds the cycles it spent waiting for (0) the G-buffer
+// planes, (1) the cluster lists, (2) the refraction taps + LUT, and (3) its total loop time, (4) tiles, into
+// tr_timing_counters (read back with tr_debug_read_timing).  The waits are forced at the measuring points.
+#ifndef TR_TIMING
+#define TR_TIMING 0
+#endif
+#if TR_TIMING
+__device__ unsigned long long tr_timing_counters[8][1024];   // spread over 1024 slots: same-address atomics serialise
+__device__ __forceinline__ unsigned long long tr_now() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ void tr_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+struct tr_timer { unsigned long long wait[3]; };
+#define TR_TIMER_PARAM , tr_timer& timer
+#define TR_TIMER_ARG , timer
+#else
+#define TR_TIMER_PARAM
+#define TR_TIMER_ARG
+#endif
+
+// Issue priority rises through the phases of a tile (TR_PRIO): among the waves of a SIMD the one nearest to the end of
+// its tile wins the arbitration, finishes, and has its next tile's loads in flight while the others compute — without
+// it the round-robin arbitration keeps waves that started together in lockstep (all wait, then all compute).
+#ifndef TR_PRIO
+#define TR_PRIO 1
+#endif
+template <int P>
+__device__ __forceinline__ void tile_phase() {
+#if TR_PRIO
+    __builtin_amdgcn_s_setprio(P);
+#endif
+}
 
 // ---------------------------------------------------------------- digested material (176 B)
 // Index 0 of every pair belongs to the basic_brdf lobe, index 1 to the transmission_btdf lobe.
@@ -157,6 +187,7 @@ struct tr_launch {
     const struct tr_dtex* textures;
     const uint32_t* tex_arena;          // RGBA8 texels of every chain
     const float* srgb_to_linear;        // 256 entries
+    uint32_t* tile_counters;            // per XCD kSubCounters tile counters + one count of finished waves, 256 bytes apart
 };
 typedef const TR_CONSTANT tr_launch claunch;
 
@@ -580,7 +611,7 @@ __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, 
 // normal mapping.
 template <bool TRANSMISSIVE, class MatP>
 __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 ns, uint32_t lane,
-                                          const cluster_list& cl) {
+                                          const cluster_list& cl TR_TIMER_PARAM) {
     constexpr bool SCALAR_MATERIAL = std::is_same<MatP, cdmat*>::value;
     // ================= phase 1: frame of the pixel, cluster list request, refraction taps =================
     L = launder(L);
@@ -660,6 +691,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
             eval_light<TRANSMISSIVE>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
                                      {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, transmits);
         // punctual lights (lighting.rs:55-92 / 179-217)
+        tile_phase<1>();
         cdlight* lights = as_constant(L2->lights);
         constexpr uint32_t kDone = 0xFFFFFFFFu;   // a lane whose list is exhausted
         uint32_t i = 0;
@@ -734,7 +766,17 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     // the kernel fits 64 VGPRs = 8 waves per SIMD, and the other seven waves hide the latency better (measured:
     // 129 -> 122 us on the 4K frame, profiles/r01).
     lights_phase();
+    tile_phase<2>();
+#if TR_TIMING
+    tr_drain();
+    const unsigned long long t_taps = tr_now();
+#endif
     issue_taps();
+#if TR_TIMING
+    tr_drain();
+    timer.wait[2] += tr_now() - t_taps;
+#endif
+    tile_phase<3>();
     return finish();
 }
 
@@ -753,7 +795,7 @@ struct quad_derivs {
 template <bool TRANSMISSIVE>
 __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material, cdmat* dm, float4 pd, float4 ns,
                                                    float2 uv, const quad_derivs& qd, uint32_t lane,
-                                                   const cluster_list& cl, const float* __restrict__ lds_srgb) {
+                                                   const cluster_list& cl, const float* __restrict__ lds_srgb TR_TIMER_PARAM) {
     L = launder(L);
     dm = launder(dm);
     const TR_CONSTANT tr_material_info* mi = as_constant(L->materials) + material;
@@ -873,7 +915,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         ns.z = fmaf(n.z, mz, fmaf(b.z, by_, t.z * tx));             // shade_pixel normalises
     }
 #undef TR_SAMPLE
-    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd, ns, lane, cl);
+    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd, ns, lane, cl TR_TIMER_ARG);
 }
 
 // ------------------------------------------------------------------------ the shading kernel
@@ -887,6 +929,31 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
 // forms the quad differences with two lane swizzles (the 16x4 wave tile holds whole 2x2 quads: partner lanes are
 // lane^1 and lane^16; the host guarantees an even rect origin) before the wave splits by material, and sends
 // materials flagged as textured through shade_pixel_textured.  The sRGB decode table sits in LDS.
+constexpr uint32_t kTileCounterStride = 64u;   // words: every counter in a cache line (and L2 channel) of its own
+#ifndef TR_SUB_COUNTERS
+#define TR_SUB_COUNTERS 16
+#endif
+constexpr uint32_t kSubCounters = TR_SUB_COUNTERS;         // tile counters per XCD: same-address atomics complete 11-14 ns apart
+                                               // (tools/ubench/scalar_atomic.hip), a 4K band has 16 200 tiles
+constexpr uint32_t kDoneGroups = 16u;
+constexpr uint32_t kXcdCounterWords = (kSubCounters + kDoneGroups + 1u) * kTileCounterStride;
+constexpr uint32_t kTileCounterWords = 8u * kXcdCounterWords;
+#ifndef TR_COUNTER_SCOPE
+#define TR_COUNTER_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+#ifndef TR_DYNAMIC_TILES
+#define TR_DYNAMIC_TILES 0
+#endif
+#ifndef TR_LOAD_BEFORE_STORE
+#define TR_LOAD_BEFORE_STORE 0
+#endif
+#ifndef TR_WAVE_BLOCKS
+#define TR_WAVE_BLOCKS 1
+#endif
+#ifndef TR_NT_STORE
+#define TR_NT_STORE 1
+#endif
+constexpr uint32_t kGridRounds = TR_DYNAMIC_TILES ? 1u : 8u;   // blocks in the grid per resident block
 struct tile_regs {
     float4 pd, ns;
     float2 uv;                                        // TEXTURED only
@@ -895,6 +962,7 @@ struct tile_regs {
 
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, bool TEXTURED = false>
 __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_value) {
+    const uint32_t block_waves = blockDim.x >> 6;   // 4, or 1 (TR_WAVE_BLOCKS: one wave per workgroup)
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
     __shared__ float lds_srgb[TEXTURED ? 256 : 1];
@@ -903,11 +971,10 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t lx = wave * 16u + (lane & 15u), ly = lane >> 4;  // position inside the 64x4 block tile
+    const uint32_t lx = lane & 15u, ly = lane >> 4;                 // position inside the wave's 16x4 tile
 
     const uint32_t ntiles = L->fp.tiles_x * L->fp.tiles_y;
-    const uint32_t xcd = blockIdx.x & 7u, stride = gridDim.x >> 3;
+    const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = ntiles >> 3, rem = ntiles & 7u;
     const uint32_t band_start = xcd * per + min(xcd, rem);
     const uint32_t band_len = per + (xcd < rem ? 1u : 0u);
@@ -915,9 +982,10 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
     // Out-of-rect lanes read a clamped (valid) pixel and are masked later.  There is no software prefetch of the
     // next tile: its 13 registers cost two of the eight resident waves per SIMD, and even scheduled so that nothing
     // younger is waited for during the light evaluation it measured slower (121 vs 113 us).
+    // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
     auto fetch = [&](uint32_t j, tile_regs& t) {
         claunch* F = launder(L);
-        const uint32_t tile = band_start + j;
+        const uint32_t tile = band_start + (j >> 2);
         // tile / tiles_x without the vector unit: q = mulhi(tile, floor(2^32 / d)) is the quotient or one less
         uint32_t tyi = __umulhi(tile, F->fp.tiles_x_magic);
         uint32_t txi = tile - tyi * F->fp.tiles_x;
@@ -925,7 +993,8 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
             txi -= F->fp.tiles_x;
             ++tyi;
         }
-        t.px = F->fp.rect_x0 + txi * 64u + lx;
+        txi = txi * 4u + (j & 3u);
+        t.px = F->fp.rect_x0 + txi * 16u + lx;
         t.py = F->fp.rect_y0 + tyi * 4u + ly;
         const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
         const uint32_t gpix = mad24(cy - F->fp.g_origin_y, F->fp.g_width, cx - F->fp.g_origin_x);
@@ -948,22 +1017,106 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
         t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
     };
 
-    for (uint32_t j = blockIdx.x >> 3; j < band_len; j += stride) {
-        tile_regs cur;
+#if TR_TIMING
+    tr_timer timer = {{0ull, 0ull, 0ull}};
+    unsigned long long tiles_done = 0;
+    const unsigned long long t_loop = tr_now();
+    const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
+#endif
+    // Which tile next.  Default: static — the wave in slot w of its XCD takes the 16x4 tiles w, w + W, w + 2W, ... of the
+    // band (W = waves of the XCD in the grid; the four waves of a block cover one 64x4 block tile side by side, so
+    // their plane rows are 1 KB contiguous and their stores 512 B).  TR_DYNAMIC_TILES=1: tiles are handed out from
+    // per-XCD counters when a wave is free — kSubCounters of them, because same-address atomics complete 11-14 ns
+    // apart (tools/ubench/scalar_atomic.hip) and a 4K band has 16 200 tiles; counter s hands out the tiles s, s + 64,
+    // ...; a wave starts on the counter of its slot and moves on when that is exhausted; the last wave of the XCD to
+    // finish re-arms the counters.  It balances the waves (static: the longest-lived wave of the 4K frame runs 36 %
+    // longer than the mean) but measured slower (135 vs 100 us): a tile then takes 16.6k instead of 11.7k cycles,
+    // the waves of a block no longer touching neighbouring memory at the same time.
+    const uint32_t wave_tiles = band_len * 4u;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * block_waves + (threadIdx.x >> 6));
+#if TR_DYNAMIC_TILES
+    // mode 1: every wave takes 16x4 tiles on its own; mode 2: the block's first wave takes a 64x4 block tile for the four
+    // waves (shared through LDS behind the block's barrier), which keeps them on neighbouring memory at the same time
+    constexpr bool kBlockUnits = TR_DYNAMIC_TILES == 2;
+    __shared__ uint32_t shared_unit[2];
+    uint32_t parity = 0u;
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t units = kBlockUnits ? band_len : wave_tiles;
+    const bool grabber = !kBlockUnits || wave_in_block == 0u;
+    uint32_t* const counters = L->tile_counters + xcd * kXcdCounterWords;
+    uint32_t sub = (kBlockUnits ? (blockIdx.x >> 3) : slot) & (kSubCounters - 1u);
+    uint32_t moves = 0u;   // counters found exhausted so far (they stay exhausted)
+    auto grab = [&]() -> uint32_t {
+        uint32_t v = 0u;
+        if (lane == 0u)
+            v = __hip_atomic_fetch_add(counters + sub * kTileCounterStride, 1u, __ATOMIC_RELAXED, TR_COUNTER_SCOPE);
+        return v;   // (lane 0)
+    };
+    // the unit of a counter value, or, once every counter is exhausted, a value >= units
+    auto resolve = [&](uint32_t request) -> uint32_t {
+        uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane(request) * kSubCounters + sub;
+        while (u >= units && ++moves < kSubCounters) {
+            sub = (sub + 1u) & (kSubCounters - 1u);
+            u = (uint32_t)__builtin_amdgcn_readfirstlane(grab()) * kSubCounters + sub;
+        }
+        return u;
+    };
+    auto share = [&](uint32_t u) -> uint32_t {
+        if constexpr (kBlockUnits) {
+            if (grabber && lane == 0u) shared_unit[parity] = u;
+            __syncthreads();   // (two slots: the next write of this one is behind the next barrier)
+            u = __builtin_amdgcn_readfirstlane(shared_unit[parity]);
+            parity ^= 1u;
+        }
+        return u;
+    };
+    auto tile_of = [&](uint32_t u) -> uint32_t { return u >= units ? 0xFFFFFFFFu : (kBlockUnits ? u * 4u + wave_in_block : u); };
+    uint32_t j = tile_of(share(grabber ? resolve(grab()) : 0u));
+#else
+    uint32_t j = slot;
+#endif
+    tile_regs cur;
+#if TR_LOAD_BEFORE_STORE
+    if (j < wave_tiles) fetch(j, cur);
+#endif
+    while (j < wave_tiles) {
+        tile_phase<0>();
+#if !TR_LOAD_BEFORE_STORE
         fetch(j, cur);
+#endif
+#if TR_DYNAMIC_TILES
+        uint32_t request = 0u;
+        if (grabber) request = grab();   // (travels with the tile's plane loads)
+#endif
+#if TR_TIMING
+        const unsigned long long t_fetch = tr_now();
+        tr_drain();
+        timer.wait[0] += tr_now() - t_fetch;
+        ++tiles_done;
+#endif
         claunch* S = launder(L);
         const bool inside = cur.px < S->fp.rect_x1 && cur.py < S->fp.rect_y1;
         const bool active = inside && cur.mat != TR_NOT_COVERED;
         const uint32_t key = inside ? cur.mat : TR_NOT_COVERED;   // the material of a lane that has work
         f3 out = {0.f, 0.f, 0.f};  // clear colour of the opaque pass (src/main.rs:1592-1601)
         uint64_t todo = ballot(key != TR_NOT_COVERED);
+#if TR_DYNAMIC_TILES
+        request = __builtin_amdgcn_readfirstlane(request);   // (older than the plane loads: it is here) into a scalar register
+#endif
         cdmat* dmats = as_constant(S->dmats);
         if (TR_ABLATE(S, 32u)) {  // profiling only: pure streaming skeleton
             todo = 0;
             out = f3{cur.pd.x + cur.ns.x + (float)cur.mat, cur.pd.y + cur.ns.y + (float)cur.cluster_x, cur.pd.z + cur.ns.z + cur.pd.w + cur.ns.w};
         } else if (todo) {
             // the light lists of all 64 pixels are requested at once, before the wave splits by material
+#if TR_TIMING
+            const unsigned long long t_cluster = tr_now();
+#endif
             const cluster_list cl = cluster_lookup(S, cur.pd.w, cur.cluster_x + cur.cluster_y_term);
+#if TR_TIMING
+            tr_drain();
+            timer.wait[1] += tr_now() - t_cluster;
+#endif
             // One material at a time through the scalar unit; a wave that straddles k materials loops k times.
             quad_derivs qd;
             if constexpr (TEXTURED) {
@@ -994,22 +1147,33 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
                 if (key == mk) {
                     if constexpr (TEXTURED) {
                         if (dmats[m0].flags & 4u)
-                            out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb);
+                            out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb TR_TIMER_ARG);
                         else
-                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cl);
+                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
                     } else {
-                        out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cl);
+                        out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
                     }
                 }
             }
         }
+        // The next tile's plane loads are issued BEFORE this tile's store: memory operations complete in order, so a
+        // load behind the store could not be waited for without waiting for the store's acknowledgement as well.
+        const uint32_t out_px = cur.px, out_py = cur.py;
+#if TR_DYNAMIC_TILES
+        j = tile_of(share(grabber ? resolve(request) : 0u));
+#else
+        j += (gridDim.x >> 3) * block_waves;
+#endif
+#if TR_LOAD_BEFORE_STORE
+        if (j < wave_tiles) fetch(j, cur);
+#endif
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         if ((TRANSMISSIVE ? active : inside) && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
             claunch* W = launder(L);
-            const uint32_t pix = mad24(cur.py, W->fp.width, cur.px);
+            const uint32_t pix = mad24(out_py, W->fp.width, out_px);
             if constexpr (sizeof(OutT) == 8) {
                 const uint2 o = pack_rgba16f(out.x, out.y, out.z, 1.0f);
-                if constexpr (TRANSMISSIVE) {   // the last writer of the frame: streamed out past L2 (the opaque pass's
+                if constexpr (TRANSMISSIVE && TR_NT_STORE) {   // the last writer of the frame: streamed out past L2 (the opaque pass's
                     typedef uint32_t u2v __attribute__((ext_vector_type(2)));   // targets are re-read at once: cached)
                     __builtin_nontemporal_store(u2v{o.x, o.y}, reinterpret_cast<u2v*>(static_cast<char*>(W->hdr) + pix * 8u));
                 } else {
@@ -1024,6 +1188,40 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
             }
         }
     }
+#if TR_DYNAMIC_TILES
+    // Re-arming the counters for the next launch: the last participant (block, or wave in mode 1) of the XCD to leave
+    // its loop zeroes them.  "Last" is found in two levels — 16 groups, then one count of finished groups — because
+    // everybody finishes at the same moment and same-address atomics complete 12 ns apart.
+    if constexpr (kBlockUnits) __syncthreads();
+    if (grabber && lane == 0u) {
+        const uint32_t participants = kBlockUnits ? (gridDim.x >> 3) : (gridDim.x >> 3) * block_waves;
+        const uint32_t me = kBlockUnits ? (blockIdx.x >> 3) : slot;
+        const uint32_t group = me & (kDoneGroups - 1u);
+        const uint32_t group_size = (participants - group + kDoneGroups - 1u) / kDoneGroups;
+        uint32_t* const done = counters + kSubCounters * kTileCounterStride;
+        if (__hip_atomic_fetch_add(done + group * kTileCounterStride, 1u, __ATOMIC_RELAXED, TR_COUNTER_SCOPE) == group_size - 1u) {
+            const uint32_t groups = participants < kDoneGroups ? participants : kDoneGroups;
+            uint32_t* const top = done + kDoneGroups * kTileCounterStride;
+            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, TR_COUNTER_SCOPE) == groups - 1u) {
+                // every other participant of this XCD has left its loop: nobody reads the counters again in this launch
+                for (uint32_t s = 0; s < kSubCounters + kDoneGroups + 1u; ++s)
+                    __hip_atomic_store(counters + s * kTileCounterStride, 0u, __ATOMIC_RELAXED, TR_COUNTER_SCOPE);
+            }
+        }
+    }
+#endif
+#if TR_TIMING
+    if (lane == 0) {
+        atomicAdd(&tr_timing_counters[0][blockIdx.x & 1023u], timer.wait[0]);
+        atomicAdd(&tr_timing_counters[1][blockIdx.x & 1023u], timer.wait[1]);
+        atomicAdd(&tr_timing_counters[2][blockIdx.x & 1023u], timer.wait[2]);
+        atomicAdd(&tr_timing_counters[3][blockIdx.x & 1023u], tr_now() - t_loop);
+        atomicAdd(&tr_timing_counters[4][blockIdx.x & 1023u], tiles_done);
+        atomicAdd(&tr_timing_counters[5][blockIdx.x & 1023u], 1ull);
+        atomicMax(&tr_timing_counters[6][blockIdx.x & 1023u], tr_now() - t_loop);
+        atomicAdd(&tr_timing_counters[7][blockIdx.x & 1023u], __builtin_amdgcn_s_memrealtime() - t_real);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------ material digestion

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -22,7 +23,7 @@ using namespace tr;
 struct tr_context {
     int device = 0;
     int32_t last_hip_error = 0;
-    uint32_t blocks_per_xcd = 1024;  // (CUs / 8) * resident blocks per CU * 4, set at context creation
+    uint32_t blocks_per_xcd = 1024;  // (CUs / 8) * resident blocks per CU * kGridRounds, set at context creation
 
     // materials
     tr_material_info* d_materials_raw = nullptr;
@@ -85,6 +86,7 @@ struct tr_context {
 
     // pyramid level table
     tr_level_table* d_levels = nullptr;
+    uint32_t* d_tile_counters = nullptr;   // shade_kernel's per-XCD tile counters (kTileCounterWords, zero between launches)
     tr_level_table h_levels{};
     uint32_t h_levels_count = 0;
 
@@ -296,7 +298,11 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
 // Persistent grid: 8 XCDs x k blocks, k chosen so that every CU holds its 4 resident 256-thread blocks.
 uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles) {
     const uint32_t per_xcd = (ntiles + 7u) / 8u;
-    uint32_t k = ctx->blocks_per_xcd < per_xcd ? ctx->blocks_per_xcd : per_xcd;
+    uint32_t bpx = ctx->blocks_per_xcd;
+#if TR_ABLATION || TR_TIMING
+    if (const char* e = std::getenv("TR_GRID_QUARTERS")) bpx = bpx / kGridRounds * (uint32_t)std::atoi(e) / 4u;   // profiling builds only: quarters of the resident blocks
+#endif
+    uint32_t k = bpx < per_xcd ? bpx : per_xcd;
     if (k == 0) k = 1;
     return 8u * k;
 }
@@ -352,6 +358,7 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.lut_pairs = ctx->d_lut_pairs;
     L.lut_lines = ctx->d_lut_lines;
     L.levels = ctx->d_levels;
+    L.tile_counters = ctx->d_tile_counters;
     L.cluster_x = ctx->d_cluster_x;
     L.cluster_y_term = ctx->d_cluster_y_term;
     L.pos_depth = (const float4*)g->pos_depth;
@@ -404,23 +411,27 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
     if (!ctx) return TR_ERR_OUT_OF_MEMORY;
     ctx->device = device_ordinal;
     {
-        // persistent grid: four times the resident blocks per CU (measured on MI355X with the 8-waves-per-SIMD
-        // kernel: 256 / 512 / 1024 / 2048 blocks per XCD -> 124 / 121 / 117 / 116 us; the tail of the sweep is
-        // spread over more, shorter runs), 1/8 of them per XCD
+        // persistent grid: kGridRounds (4) times the resident blocks per CU with the static tile order (measured on
+        // MI355X, 8 waves per SIMD: 1 / 2 / 4 / 6 / 8 / 32 rounds -> 117 / 115 / 112 / 111 / 111 / 117 us in the
+        // profiling build: the uneven ends of the waves' runs are spread over more, shorter runs), 1/8 of them per XCD
         hipDeviceProp_t prop;
         int resident = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, shade_kernel<true, uint2>, 256, 0) != hipSuccess ||
             resident <= 0)
             resident = 4;
         if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount >= 8) {
-            ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * 4u;
+            ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * kGridRounds;
             ctx->num_cus = (uint32_t)prop.multiProcessorCount;
         }
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
     }
     if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_colour_tables, sizeof(tr_colour_tables)) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_colour_tables, sizeof(tr_colour_tables)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_tile_counters, kTileCounterWords * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(ctx->d_tile_counters, 0, kTileCounterWords * sizeof(uint32_t)) != hipSuccess) {
         (void)hipFree(ctx->d_levels);
+        (void)hipFree(ctx->d_colour_tables);
+        (void)hipFree(ctx->d_tile_counters);
         delete ctx;
         return TR_ERR_OUT_OF_MEMORY;
     }
@@ -430,6 +441,7 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         if (hipMemcpy(ctx->d_colour_tables, &tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(ctx->d_levels);
             (void)hipFree(ctx->d_colour_tables);
+            (void)hipFree(ctx->d_tile_counters);
             delete ctx;
             return TR_ERR_NO_DEVICE;
         }
@@ -450,6 +462,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_lut_pairs);
     (void)hipFree(ctx->d_lut_lines);
     (void)hipFree(ctx->d_levels);
+    (void)hipFree(ctx->d_tile_counters);
     (void)hipFree(ctx->d_cluster_x);
     (void)hipFree(ctx->d_cluster_y_term);
     (void)hipFree(ctx->d_tex_arena);
@@ -950,7 +963,9 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     st = check_textured_launch(ctx, g, fp);
     if (st != TR_OK) return st;
     fp.pyr_levels = 1;
-    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y)), block(256);
+    // untextured kernels can run as one-wave workgroups (TR_WAVE_BLOCKS): same waves, four times the blocks
+    const bool wave_blocks = TR_WAVE_BLOCKS && !ctx->any_textured;
+    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * (wave_blocks ? 4u : 1u)), block(wave_blocks ? 64 : 256);
     {
         tr_launch L;
         fill_launch(L, ctx, fp, g);
@@ -1050,7 +1065,9 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     st = check_textured_launch(ctx, g, fp);
     if (st != TR_OK) return st;
     fp.pyr_levels = p->levels;
-    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y)), block(256);
+    // untextured kernels can run as one-wave workgroups (TR_WAVE_BLOCKS): same waves, four times the blocks
+    const bool wave_blocks = TR_WAVE_BLOCKS && !ctx->any_textured;
+    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * (wave_blocks ? 4u : 1u)), block(wave_blocks ? 64 : 256);
     {
         tr_launch L;
         fill_launch(L, ctx, fp, g);
@@ -1179,6 +1196,41 @@ tr_status tr_compute_f0(tr_context* ctx, const void* metallic, const void* ior, 
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
+
+#if TR_TIMING
+// profiling builds only (not declared in include/tr_shade.h): reads and clears the kernels' wait-cycle counters
+extern "C" int32_t tr_debug_read_timing(unsigned long long out[8]) {
+    static unsigned long long host[8][1024];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tr_timing_counters), sizeof(host)) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) {
+        out[k] = 0;
+        for (int i = 0; i < 1024; ++i) out[k] += host[k][i];
+    }
+    unsigned long long longest = 0;   // the longest-lived wave
+    for (int i = 0; i < 1024; ++i) longest = std::max(longest, host[6][i]);
+    out[5] = out[5] | (longest << 32);
+    if (std::getenv("TR_TIMING_DUMP")) {   // per XCD: longest-lived wave, mean loop time, tiles
+        for (int x = 0; x < 8; ++x) {
+            unsigned long long mx = 0, sum = 0, waves = 0, tiles = 0;
+            for (int i = x; i < 1024; i += 8) {
+                mx = std::max(mx, host[6][i]);
+                sum += host[3][i];
+                waves += host[5][i];
+                tiles += host[4][i];
+            }
+            std::fprintf(stderr, "xcd %d: longest wave %llu, mean %llu, waves %llu, tiles %llu; per block slot (loop ticks/tiles):", x, mx, waves ? sum / waves : 0, waves, tiles);
+            for (int i = x; i < 1024; i += 8 * 8) std::fprintf(stderr, " %llu/%llu", host[5][i] ? host[3][i] / host[5][i] : 0, host[5][i] ? host[4][i] / host[5][i] : 0);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    unsigned long long per_xcd[8] = {0};   // busy ticks per XCD (block b runs on XCD b % 8)
+    for (int i = 0; i < 1024; ++i) per_xcd[i & 7] += host[3][i];
+    out[6] = *std::max_element(per_xcd, per_xcd + 8) * 1000ull / (out[3] / 8ull + 1ull);   // most loaded XCD, per mille of the mean
+    // out[7]: sum of the waves' loop times in 100 MHz ticks
+    std::memset(host, 0, sizeof(host));
+    return hipMemcpyToSymbol(HIP_SYMBOL(tr_timing_counters), host, sizeof(host)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 tr_status tr_lottes_defaults(tr_lottes_params* out) {
     if (!out) return TR_ERR_INVALID_ARGUMENT;
