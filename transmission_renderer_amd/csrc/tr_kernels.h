@@ -919,11 +919,12 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
 }
 
 // ------------------------------------------------------------------------ the shading kernel
-// Persistent workgroups: grid = 8 * k blocks of 256 threads (k per XCD; hardware block b runs on XCD
-// b % 8).  The 64x4-pixel tiles of the rect are cut into 8 contiguous bands, one per XCD, and the k
-// blocks of an XCD sweep their band front to back, so at any moment an XCD's L2 serves a compact
-// window of the screen (and of the opaque pyramid behind it).  A wave is a 16x4 pixel tile — few
-// waves straddle a material or cluster border, every plane row segment is still >= one 128 B line.
+// Grid: 8 * k workgroups, k per XCD (hardware workgroup b runs on XCD b % 8), of one wave each (TR_WAVE_BLOCKS),
+// kGridRounds times what is resident.  The 64x4-pixel block tiles of the rect are cut into 8
+// contiguous bands, one per XCD; the wave in slot w of its XCD takes the 16x4 quarters w, w + W, ... of the band, so an
+// XCD sweeps its band front to back and its L2 serves a compact window of the screen (and of the opaque pyramid behind
+// it).  A wave is a 16x4 pixel tile — few waves straddle a material or cluster border, every plane row segment is
+// still >= one 128 B line.
 //
 // TEXTURED (chosen by the host when an uploaded material has texture slots): additionally reads the uv plane,
 // forms the quad differences with two lane swizzles (the 16x4 wave tile holds whole 2x2 quads: partner lanes are
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const tr_launch launch_by_va
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
     __shared__ float lds_srgb[TEXTURED ? 256 : 1];
     if constexpr (TEXTURED) {
-        lds_srgb[threadIdx.x] = L->srgb_to_linear[threadIdx.x];
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) lds_srgb[i] = L->srgb_to_linear[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;

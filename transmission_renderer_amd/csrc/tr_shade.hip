@@ -963,8 +963,8 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     st = check_textured_launch(ctx, g, fp);
     if (st != TR_OK) return st;
     fp.pyr_levels = 1;
-    // untextured kernels can run as one-wave workgroups (TR_WAVE_BLOCKS): same waves, four times the blocks
-    const bool wave_blocks = TR_WAVE_BLOCKS && !ctx->any_textured;
+    // one-wave workgroups (TR_WAVE_BLOCKS): same waves, four times the blocks
+    const bool wave_blocks = TR_WAVE_BLOCKS != 0;
     const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * (wave_blocks ? 4u : 1u)), block(wave_blocks ? 64 : 256);
     {
         tr_launch L;
@@ -1065,8 +1065,8 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     st = check_textured_launch(ctx, g, fp);
     if (st != TR_OK) return st;
     fp.pyr_levels = p->levels;
-    // untextured kernels can run as one-wave workgroups (TR_WAVE_BLOCKS): same waves, four times the blocks
-    const bool wave_blocks = TR_WAVE_BLOCKS && !ctx->any_textured;
+    // one-wave workgroups (TR_WAVE_BLOCKS): same waves, four times the blocks
+    const bool wave_blocks = TR_WAVE_BLOCKS != 0;
     const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * (wave_blocks ? 4u : 1u)), block(wave_blocks ? 64 : 256);
     {
         tr_launch L;
