@@ -73,6 +73,9 @@ struct tr_timer { unsigned long long wait[3]; };
 #ifndef TR_PRIO
 #define TR_PRIO 1
 #endif
+#ifndef TR_UNIFORM_CLUSTERS
+#define TR_UNIFORM_CLUSTERS 1
+#endif
 template <int P>
 __device__ __forceinline__ void tile_phase() {
 #if TR_PRIO
@@ -581,6 +584,8 @@ struct cluster_list {
     uint32_t num_lights;
     uint32_t list_offset;   // byte offset of the list in light_indices
     uint32_t l0, l1;        // its first two entries: lists of up to two lights need no load inside the light loop
+    bool uniform;           // (scalar) every pixel of the tile is in one cluster: its list is walked on the scalar unit
+    uint32_t s_cluster;     // (scalar) that cluster, or 0xFFFFFFFF when it is out of range (no lights)
 };
 
 // shader/src/lib.rs:88-98: x / y from exact tables (cluster_xy), the depth slice of
@@ -593,6 +598,20 @@ __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, 
     const bool in_range = c.cluster < L->fp.num_clusters_total;  // out-of-range reads as 0 lights (robust access)
     const uint32_t csafe = in_range ? c.cluster : 0u;
     c.list_offset = csafe * (TR_MAX_LIGHTS_PER_CLUSTER * 4u);
+#if TR_UNIFORM_CLUSTERS
+    // The usual tile lies in one cluster (they are 240 pixels wide at 4K and 1/16 of the log-depth range deep): then
+    // nothing is fetched here, the light loop reads count and list through the scalar unit.
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cluster);
+    c.uniform = ballot(c.cluster != c0) == 0ull;
+    c.s_cluster = c0 < L->fp.num_clusters_total ? c0 : 0xFFFFFFFFu;
+    if (c.uniform) {
+        c.num_lights = c.l0 = c.l1 = 0u;
+        return c;
+    }
+#else
+    c.uniform = false;
+    c.s_cluster = 0u;
+#endif
     const uint32_t n = ld<uint32_t>(L->cluster_counts, csafe * 4u);
     const uint2 first = ld<uint2>(L->light_indices, c.list_offset);   // (lists are 512-byte aligned)
     c.l0 = first.x;
@@ -635,6 +654,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     px.nov = nov;
 
     const uint32_t num_lights = cl.num_lights;
+    uint32_t uniform_lights = 0u;   // (scalar) the count when the tile's cluster is uniform
 
     // ---- ibl_volume_refraction, part 1 (glam-pbr/src/lib.rs:292-337): where the refracted ray leaves
     //      the volume, projected to the screen; the taps are in flight while the lights are evaluated.
@@ -693,6 +713,15 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         // punctual lights (lighting.rs:55-92 / 179-217)
         tile_phase<1>();
         cdlight* lights = as_constant(L2->lights);
+        if (cl.uniform) {   // one cluster for the whole tile: count, list and lights all through the scalar unit
+            const uint32_t sc = opaque(cl.s_cluster);
+            uint32_t n = 0u;
+            if (sc != 0xFFFFFFFFu && !TR_ABLATE(L2, 8u)) n = min(as_constant(L2->cluster_counts)[sc], TR_MAX_LIGHTS_PER_CLUSTER);
+            const TR_CONSTANT uint32_t* list = as_constant(L2->light_indices) + (size_t)(sc == 0xFFFFFFFFu ? 0u : sc) * TR_MAX_LIGHTS_PER_CLUSTER;
+            for (uint32_t i = 0; i < n; ++i) eval_punctual<TRANSMISSIVE>(acc, *m2, lights[list[i]], pos, px, transmits);
+            uniform_lights = n;
+            return;
+        }
         constexpr uint32_t kDone = 0xFFFFFFFFu;   // a lane whose list is exhausted
         uint32_t i = 0;
         uint32_t head = num_lights ? cl.l0 : kDone;
@@ -754,7 +783,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
                   diffuse.z + acc.s.z + m4->emission[2]};
         if constexpr (!TRANSMISSIVE) {
             if (L4->fp.debug_clusters != 0u) {  // lib.rs:241-245
-                f3 a = debug_colour_for_id(num_lights), b = debug_colour_for_id(cl.cluster);
+                f3 a = debug_colour_for_id(cl.uniform ? uniform_lights : num_lights), b = debug_colour_for_id(cl.cluster);
                 out = {fmaf(b.x - 0.5f, 0.025f, a.x), fmaf(b.y - 0.5f, 0.025f, a.y), fmaf(b.z - 0.5f, 0.025f, a.z)};
             }
         }
