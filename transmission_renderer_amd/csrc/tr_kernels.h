@@ -78,8 +78,14 @@ struct tr_timer { unsigned long long wait[3]; };
 #endif
 template <int P>
 __device__ __forceinline__ void tile_phase() {
-#if TR_PRIO
+#if TR_PRIO == 1
     __builtin_amdgcn_s_setprio(P);
+#elif TR_PRIO == 2   // experiments (all measured equal or slower): memory-issuing phases first, compute phases low
+    __builtin_amdgcn_s_setprio(P == 0 ? 3 : P == 1 ? 0 : P == 2 ? 3 : 1);
+#elif TR_PRIO == 3   // two levels
+    __builtin_amdgcn_s_setprio(P >= 2 ? 1 : 0);
+#elif TR_PRIO == 4   // only the last phase raised
+    __builtin_amdgcn_s_setprio(P == 3 ? 3 : 0);
 #endif
 }
 
