@@ -1,0 +1,44 @@
+"""Whole-frame rate of the glTF-in/frame-out pipeline at steady-state clocks (run on the GPU box): tr_record_frame
+(culling, light assignment, demultiplex, rasteriser, opaque, mips, transmissive, tonemap) back to back.
+    python tools/gpu_bench_frame.py [scene.glb | meshes] [width height]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from transmission_renderer_amd import gltf, meshes, synthetic, wire
+from transmission_renderer_amd.renderer import TransmissionRenderer
+
+name = sys.argv[1] if len(sys.argv) > 1 else "meshes"
+w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160)
+r = TransmissionRenderer(0)
+scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False, textured=(name == "meshes"))
+if name == "meshes":
+    geometry = meshes.make_mesh_scene(extra_instances=True)
+    scene["materials"][2].alpha_clipping_cutoff = 0.75
+    scene["materials"][7].alpha_clipping_cutoff = 0.6
+else:
+    loaded = gltf.load_gltf(name, base_transform=meshes.Similarity(np.array([0.0, 2.0, 0.0], np.float32), 1.0))
+    geometry = loaded.geometry()
+    scene["materials"] = loaded.materials or [wire.MaterialInfo.default()]
+    scene["textures"] = loaded.textures
+r.upload_ggx_lut(); r.upload_materials(scene["materials"])
+if scene.get("textures"): r.upload_textures(scene["textures"])
+r.upload_lights(scene["lights"]); r.upload_geometry(geometry)
+_, view = wire.default_camera()
+aabbs = r.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
+culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+work = r.new_frame_buffers(w, h)
+frame = lambda: r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs, work)
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.2:
+    for _ in range(4): frame()
+    torch.cuda.synchronize()
+ts = []
+for _ in range(8):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20): frame()
+    b.record(); b.synchronize(); ts.append(a.elapsed_time(b) / 20)
+ts.sort()
+t = ts[len(ts) // 2]
+print(f"{name} {w}x{h}, {len(geometry['index']) // 3} triangles: {t * 1e3:.1f} us per frame ({1e3 / t:.0f} frames/s), "
+      f"culling -> rasteriser -> opaque -> mips -> transmissive -> tonemap, one tr_record_frame call per frame")
