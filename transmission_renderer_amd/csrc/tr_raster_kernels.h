@@ -82,7 +82,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 }
 
 // tri_base[d] = number of triangles before draw d of the layer's stream (first buffer's draws, then the second's)
-__global__ __launch_bounds__(1024) void raster_scan_draws_kernel(const tr_draw_command* __restrict__ draws_a,
+__device__ __forceinline__ void raster_scan_draws_body(const tr_draw_command* __restrict__ draws_a,
                                                                  const tr_draw_command* __restrict__ draws_b,
                                                                  const uint32_t* __restrict__ draw_counts, uint32_t buffer_a,
                                                                  uint32_t capacity_draws, uint32_t capacity_triangles,
@@ -139,7 +139,7 @@ __device__ __forceinline__ void vertex_stage(const tr_geometry_view& g, const tr
     mat4_mul_point(pv, world[0], world[1], world[2], clip);
 }
 
-__global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_view g, const tr_raster_frame f,
+__device__ __forceinline__ void raster_setup_body(const tr_geometry_view g, const tr_raster_frame f,
                                                            const tr_draw_command* __restrict__ draws_a,
                                                            const tr_draw_command* __restrict__ draws_b,
                                                            const uint32_t* __restrict__ tri_base,
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_vie
 // The triangle count lives on the device, so the grids are sized for the capacity and surplus blocks exit.
 constexpr uint32_t kScanChunk = 4096u;   // 1024 threads x 4
 
-__global__ __launch_bounds__(1024) void raster_scan_items_reduce_kernel(const uint32_t* __restrict__ item_counts,
+__device__ __forceinline__ void raster_scan_items_reduce_body(const uint32_t* __restrict__ item_counts,
                                                                         const tr_layer_counts* __restrict__ counts,
                                                                         uint32_t* __restrict__ chunk_sums) {
     __shared__ uint32_t lds[17];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(1024) void raster_scan_items_reduce_kernel(const ui
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void raster_scan_items_chunks_kernel(uint32_t* __restrict__ chunk_sums,
+__device__ __forceinline__ void raster_scan_items_chunks_body(uint32_t* __restrict__ chunk_sums,
                                                                         tr_layer_counts* __restrict__ counts) {
     __shared__ uint32_t lds[17];
     const uint32_t nchunks = (counts->num_triangles + kScanChunk - 1u) / kScanChunk;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(1024) void raster_scan_items_chunks_kernel(uint32_t
     if (threadIdx.x == 0) counts->num_items = running;
 }
 
-__global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const uint32_t* __restrict__ item_counts,
+__device__ __forceinline__ void raster_scan_items_apply_body(const uint32_t* __restrict__ item_counts,
                                                                        const uint32_t* __restrict__ chunk_sums,
                                                                        const tr_layer_counts* __restrict__ counts,
                                                                        uint32_t* __restrict__ item_base) {
@@ -404,7 +404,7 @@ struct tr_layer_planes {
 
 // One thread per pixel: the winning triangle's attributes at the pixel centre (vertex_instanced_with_scale outputs,
 // perspective-correct), or "no fragment".
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f,
+__device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, const tr_raster_frame f,
                                                              const tr_tri_record* __restrict__ records,
                                                              const unsigned long long* __restrict__ vis,
                                                              const tr_layer_planes out) {
@@ -437,6 +437,61 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_v
                                 inst.translation_and_scale[3]};
     out.uv[pix] = float2{mix(T[0][0], T[1][0], T[2][0]), mix(T[0][1], T[1][1], T[2][1])};
     out.material_id[pix] = inst.material_id;
+}
+
+
+// ---- both layers per launch ----------------------------------------------------------------------------------------
+// The front end of a layer (scan of the draw stream, vertex stage + setup, the three scan passes over the work items)
+// is five small launches, each bound by launch latency at scene sizes like the demos'; the two layers are
+// independent until the transmissive layer's coverage test reads the opaque depth, so each of the five runs once
+// with the layer in blockIdx.y (the resolve: blockIdx.z), on work buffers of its own.
+struct tr_layer_work {
+    const tr_draw_command* draws_a;
+    const tr_draw_command* draws_b;
+    uint32_t buffer_a, capacity_triangles;     // capacity 0: the layer cannot have triangles, its front end is skipped
+    uint32_t* tri_base;
+    tr_layer_counts* counts;
+    tr_tri_record* records;
+    uint32_t* item_counts;
+    uint32_t* chunk_sums;
+    uint32_t* item_base;
+    const unsigned long long* vis;
+    tr_layer_planes planes;
+};
+struct tr_two_layers {
+    tr_layer_work l[2];
+};
+#define TR_PICK_LAYER(two, which) const tr_layer_work W = (which) ? (two).l[1] : (two).l[0]
+
+__global__ __launch_bounds__(1024) void raster_scan_draws_kernel(const tr_two_layers two, const uint32_t* __restrict__ draw_counts,
+                                                                 uint32_t capacity_draws) {
+    TR_PICK_LAYER(two, blockIdx.y);
+    if (W.capacity_triangles == 0u) return;
+    raster_scan_draws_body(W.draws_a, W.draws_b, draw_counts, W.buffer_a, capacity_draws, W.capacity_triangles, W.tri_base, W.counts);
+}
+__global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two) {
+    TR_PICK_LAYER(two, blockIdx.y);
+    if (W.capacity_triangles == 0u) return;
+    raster_setup_body(g, f, W.draws_a, W.draws_b, W.tri_base, W.counts, 1u, W.records, W.item_counts);
+}
+__global__ __launch_bounds__(1024) void raster_scan_items_reduce_kernel(const tr_two_layers two) {
+    TR_PICK_LAYER(two, blockIdx.y);
+    if (W.capacity_triangles == 0u) return;
+    raster_scan_items_reduce_body(W.item_counts, W.counts, W.chunk_sums);
+}
+__global__ __launch_bounds__(1024) void raster_scan_items_chunks_kernel(const tr_two_layers two) {
+    TR_PICK_LAYER(two, blockIdx.y);
+    if (W.capacity_triangles == 0u) return;
+    raster_scan_items_chunks_body(W.chunk_sums, W.counts);
+}
+__global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const tr_two_layers two) {
+    TR_PICK_LAYER(two, blockIdx.y);
+    if (W.capacity_triangles == 0u) return;
+    raster_scan_items_apply_body(W.item_counts, W.chunk_sums, W.counts, W.item_base);
+}
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two) {
+    TR_PICK_LAYER(two, blockIdx.z);
+    raster_resolve_body(g, f, W.records, W.vis, W.planes);
 }
 
 }  // namespace tr

@@ -51,6 +51,7 @@ struct tr_context {
     tr_instance* d_instances = nullptr;
     uint32_t num_vertices = 0, num_indices = 0, num_primitives = 0, num_instances = 0;
     uint32_t max_triangles[2] = {0, 0};       // per layer, if every instance is visible
+    size_t work_capacity = 0, work_draws = 0; // elements per layer in the rasteriser's work buffers
     uint32_t* d_instance_counts = nullptr;
     uint32_t* d_draw_counts = nullptr;
     tr_draw_command* d_draws[TR_NUM_DRAW_BUFFERS] = {nullptr, nullptr, nullptr, nullptr};
@@ -470,7 +471,6 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_colour_tables);
     free_geometry(ctx);
     (void)hipFree(ctx->d_vis[0]);
-    (void)hipFree(ctx->d_vis[1]);
     delete ctx;
     return TR_OK;
 }
@@ -783,12 +783,15 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_instance_counts, np_ * 4u));
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_draw_counts, TR_NUM_DRAW_BUFFERS * 4u));
     for (auto& d : ctx->d_draws) TR_HIP(ctx, hipMalloc((void**)&d, np_ * sizeof(tr_draw_command)));
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_tri_base, (np_ + 1u) * 4u));
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_records, cap * sizeof(tr_tri_record)));
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_counts, cap * 4u));
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_base, (cap + 1u) * 4u));
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_chunk_sums, ((cap + kScanChunk - 1u) / kScanChunk + 1u) * 4u));
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_layer_counts, sizeof(tr_layer_counts)));
+    // rasteriser work buffers, one set per layer (the two front ends run in the same launches)
+    ctx->work_capacity = cap;
+    ctx->work_draws = np_ + 1u;
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_tri_base, 2u * (np_ + 1u) * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_records, 2u * cap * sizeof(tr_tri_record)));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_counts, 2u * cap * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_base, 2u * (cap + 1u) * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_chunk_sums, 2u * ((cap + kScanChunk - 1u) / kScanChunk + 1u) * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_layer_counts, 2u * sizeof(tr_layer_counts)));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_position, g->position, nv * 12u, hipMemcpyHostToDevice, stream));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_normal, g->normal, nv * 12u, hipMemcpyHostToDevice, stream));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_uv, g->uv, nv * 8u, hipMemcpyHostToDevice, stream));
@@ -824,13 +827,12 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
     if (npix > ctx->vis_pixels) {
         TR_HIP(ctx, hipDeviceSynchronize());
         (void)hipFree(ctx->d_vis[0]);
-        (void)hipFree(ctx->d_vis[1]);
         ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
         ctx->vis_pixels = 0;
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], npix * 8u));
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[1], npix * 8u));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u));   // both layers' visibility buffers, cleared by one fill
         ctx->vis_pixels = npix;
     }
+    ctx->d_vis[1] = ctx->d_vis[0] + npix;
     tr_geometry_view gv;
     gv.position = ctx->d_position;
     gv.normal = ctx->d_normal;
@@ -846,40 +848,46 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
     at.textures = ctx->d_textures;
     at.tex_arena = ctx->d_tex_arena;
     at.num_textures = ctx->num_textures;
+    const size_t cap = ctx->work_capacity, chunk_cap = (cap + kScanChunk - 1u) / kScanChunk + 1u;
+    tr_two_layers two;
     for (uint32_t layer = 0; layer < 2u; ++layer) {
-        const tr_draw_command* da = (const tr_draw_command*)draws[layer * 2u];
-        const tr_draw_command* db = (const tr_draw_command*)draws[layer * 2u + 1u];
-        const uint32_t cap = ctx->max_triangles[layer];
-        TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[layer], 0, npix * 8u, stream));
-        if (cap > 0u) {
-            hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1), dim3(1024), 0, stream, da, db, (const uint32_t*)draw_counts,
-                               layer * 2u, ctx->num_primitives, cap, ctx->d_tri_base, ctx->d_layer_counts);
-            hipLaunchKernelGGL(raster_setup_kernel, dim3((cap + 255u) / 256u), dim3(256), 0, stream, gv, fr, da, db,
-                               (const uint32_t*)ctx->d_tri_base, (const tr_layer_counts*)ctx->d_layer_counts, 1u,
-                               ctx->d_records, ctx->d_item_counts);
-            const uint32_t chunks = (cap + kScanChunk - 1u) / kScanChunk;
-            hipLaunchKernelGGL(raster_scan_items_reduce_kernel, dim3(chunks), dim3(1024), 0, stream,
-                               (const uint32_t*)ctx->d_item_counts, (const tr_layer_counts*)ctx->d_layer_counts,
-                               ctx->d_chunk_sums);
-            hipLaunchKernelGGL(raster_scan_items_chunks_kernel, dim3(1), dim3(1024), 0, stream, ctx->d_chunk_sums,
-                               ctx->d_layer_counts);
-            hipLaunchKernelGGL(raster_scan_items_apply_kernel, dim3(chunks), dim3(1024), 0, stream,
-                               (const uint32_t*)ctx->d_item_counts, (const uint32_t*)ctx->d_chunk_sums,
-                               (const tr_layer_counts*)ctx->d_layer_counts, ctx->d_item_base);
+        tr_layer_work& W = two.l[layer];
+        W.draws_a = (const tr_draw_command*)draws[layer * 2u];
+        W.draws_b = (const tr_draw_command*)draws[layer * 2u + 1u];
+        W.buffer_a = layer * 2u;
+        W.capacity_triangles = ctx->max_triangles[layer];
+        W.tri_base = ctx->d_tri_base + layer * ctx->work_draws;
+        W.counts = ctx->d_layer_counts + layer;
+        W.records = ctx->d_records + layer * cap;
+        W.item_counts = ctx->d_item_counts + layer * cap;
+        W.chunk_sums = ctx->d_chunk_sums + layer * chunk_cap;
+        W.item_base = ctx->d_item_base + layer * (cap + 1u);
+        W.vis = ctx->d_vis[layer];
+        W.planes.pos_depth = (float4*)targets[layer]->pos_depth;
+        W.planes.nrm_scale = (float4*)targets[layer]->nrm_scale;
+        W.planes.uv = (float2*)targets[layer]->uv;
+        W.planes.material_id = (uint32_t*)targets[layer]->material_id;
+    }
+    TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u, stream));
+    const uint32_t max_cap = std::max(ctx->max_triangles[0], ctx->max_triangles[1]);
+    if (max_cap > 0u) {
+        const uint32_t chunks = (max_cap + kScanChunk - 1u) / kScanChunk;
+        hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1, 2), dim3(1024), 0, stream, two, (const uint32_t*)draw_counts,
+                           ctx->num_primitives);
+        hipLaunchKernelGGL(raster_setup_kernel, dim3((max_cap + 255u) / 256u, 2), dim3(256), 0, stream, gv, fr, two);
+        hipLaunchKernelGGL(raster_scan_items_reduce_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
+        hipLaunchKernelGGL(raster_scan_items_chunks_kernel, dim3(1, 2), dim3(1024), 0, stream, two);
+        hipLaunchKernelGGL(raster_scan_items_apply_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
+        for (uint32_t layer = 0; layer < 2u; ++layer) {
+            if (ctx->max_triangles[layer] == 0u) continue;
+            const tr_layer_work& W = two.l[layer];
             hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * 8u), dim3(256), 0, stream, gv, fr,
-                               (const tr_tri_record*)ctx->d_records, (const uint32_t*)ctx->d_item_base,
-                               (const tr_layer_counts*)ctx->d_layer_counts, at,
+                               (const tr_tri_record*)W.records, (const uint32_t*)W.item_base, (const tr_layer_counts*)W.counts, at,
                                layer ? (const unsigned long long*)ctx->d_vis[0] : (const unsigned long long*)nullptr,
                                ctx->d_vis[layer]);
         }
-        tr_layer_planes planes;
-        planes.pos_depth = (float4*)targets[layer]->pos_depth;
-        planes.nrm_scale = (float4*)targets[layer]->nrm_scale;
-        planes.uv = (float2*)targets[layer]->uv;
-        planes.material_id = (uint32_t*)targets[layer]->material_id;
-        hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u), dim3(256), 0, stream, gv, fr,
-                           (const tr_tri_record*)ctx->d_records, (const unsigned long long*)ctx->d_vis[layer], planes);
     }
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two);
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
