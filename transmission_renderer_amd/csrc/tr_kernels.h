@@ -592,6 +592,7 @@ struct cluster_list {
     uint32_t l0, l1;        // its first two entries: lists of up to two lights need no load inside the light loop
     bool uniform;           // (scalar) every pixel of the tile is in one cluster: its list is walked on the scalar unit
     uint32_t s_cluster;     // (scalar) that cluster, or 0xFFFFFFFF when it is out of range (no lights)
+    uint32_t s_num, s_l0, s_l1;   // (scalar) its count and the first two entries of its list
 };
 
 // shader/src/lib.rs:88-98: x / y from exact tables (cluster_xy), the depth slice of
@@ -610,13 +611,20 @@ __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, 
     const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cluster);
     c.uniform = ballot(c.cluster != c0) == 0ull;
     c.s_cluster = c0 < L->fp.num_clusters_total ? c0 : 0xFFFFFFFFu;
-    if (c.uniform) {
+    if (c.uniform) {   // count and the head of the list are requested here, a tile phase ahead of the light loop
+        const bool ok = c.s_cluster != 0xFFFFFFFFu && !TR_ABLATE(L, 8u);
+        const uint32_t sc = ok ? c.s_cluster : 0u;
+        const uint32_t n = as_constant(L->cluster_counts)[sc];
+        const TR_CONSTANT uint32_t* list = as_constant(L->light_indices) + (size_t)sc * TR_MAX_LIGHTS_PER_CLUSTER;
+        c.s_l0 = list[0];
+        c.s_l1 = list[1];
+        c.s_num = ok ? min(n, TR_MAX_LIGHTS_PER_CLUSTER) : 0u;
         c.num_lights = c.l0 = c.l1 = 0u;
         return c;
     }
 #else
     c.uniform = false;
-    c.s_cluster = 0u;
+    c.s_cluster = c.s_num = c.s_l0 = c.s_l1 = 0u;
 #endif
     const uint32_t n = ld<uint32_t>(L->cluster_counts, csafe * 4u);
     const uint2 first = ld<uint2>(L->light_indices, c.list_offset);   // (lists are 512-byte aligned)
@@ -720,11 +728,13 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         tile_phase<1>();
         cdlight* lights = as_constant(L2->lights);
         if (cl.uniform) {   // one cluster for the whole tile: count, list and lights all through the scalar unit
-            const uint32_t sc = opaque(cl.s_cluster);
-            uint32_t n = 0u;
-            if (sc != 0xFFFFFFFFu && !TR_ABLATE(L2, 8u)) n = min(as_constant(L2->cluster_counts)[sc], TR_MAX_LIGHTS_PER_CLUSTER);
-            const TR_CONSTANT uint32_t* list = as_constant(L2->light_indices) + (size_t)(sc == 0xFFFFFFFFu ? 0u : sc) * TR_MAX_LIGHTS_PER_CLUSTER;
-            for (uint32_t i = 0; i < n; ++i) eval_punctual<TRANSMISSIVE>(acc, *m2, lights[list[i]], pos, px, transmits);
+            const uint32_t n = cl.s_num;
+            const uint32_t sc = cl.s_cluster == 0xFFFFFFFFu ? 0u : opaque(cl.s_cluster);
+            const TR_CONSTANT uint32_t* list = as_constant(L2->light_indices) + (size_t)sc * TR_MAX_LIGHTS_PER_CLUSTER;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t idx = i == 0u ? cl.s_l0 : i == 1u ? cl.s_l1 : list[i];
+                eval_punctual<TRANSMISSIVE>(acc, *m2, lights[idx], pos, px, transmits);
+            }
             uniform_lights = n;
             return;
         }
