@@ -196,6 +196,7 @@ struct tr_launch {
     const struct tr_dtex* textures;
     const uint32_t* tex_arena;          // RGBA8 texels of every chain
     const float* srgb_to_linear;        // 256 entries
+    const uint32_t* tile_cover;         // optional: one word per 64x4 block tile of the frame, 0 = the layer has no fragment there
     uint32_t* tile_counters;            // per XCD kSubCounters tile counters + one count of finished waves, 256 bytes apart
 };
 typedef const TR_CONSTANT tr_launch claunch;
@@ -1042,6 +1043,13 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) void shade_kernel(const 
         txi = txi * 4u + (j & 3u);
         t.px = F->fp.rect_x0 + txi * 16u + lx;
         t.py = F->fp.rect_y0 + tyi * 4u + ly;
+        if (F->tile_cover && as_constant(F->tile_cover)[tile] == 0u) {   // (scalar) nothing rasterised into this block tile
+            t.mat = TR_NOT_COVERED;
+            t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
+            t.uv = float2{0.f, 0.f};
+            t.cluster_x = t.cluster_y_term = 0u;
+            return;
+        }
         const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
         const uint32_t gpix = mad24(cy - F->fp.g_origin_y, F->fp.g_width, cx - F->fp.g_origin_x);
         if (TR_ABLATE(F, 64u)) {  // profiling only: no G-buffer traffic (synthetic per-lane inputs)

@@ -407,12 +407,17 @@ struct tr_layer_planes {
 __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, const tr_raster_frame f,
                                                              const tr_tri_record* __restrict__ records,
                                                              const unsigned long long* __restrict__ vis,
-                                                             const tr_layer_planes out) {
+                                                             const tr_layer_planes out, uint32_t* __restrict__ tile_cover) {
 #pragma clang fp contract(off)
     const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (px >= f.width || py >= f.height) return;
-    const size_t pix = (size_t)py * f.width + px;
-    const unsigned long long key = vis[pix];
+    const bool in_frame = px < f.width && py < f.height;
+    const size_t pix = in_frame ? (size_t)py * f.width + px : 0u;
+    const unsigned long long key = in_frame ? vis[pix] : 0ull;
+    // one word per 64x4 block tile (this workgroup): does the layer have a fragment in it?  The shading passes of
+    // tr_record_frame skip the plane loads of empty tiles (a transmissive layer is mostly empty).
+    const int any = __syncthreads_or(key != 0ull);
+    if (threadIdx.x == 0) tile_cover[blockIdx.y * gridDim.x + blockIdx.x] = any ? 1u : 0u;
+    if (!in_frame) return;
     if (key == 0ull) {   // no fragment: only the id plane is defined there (the shading passes look at nothing else)
         out.material_id[pix] = TR_NOT_COVERED;
         return;
@@ -457,6 +462,7 @@ struct tr_layer_work {
     uint32_t* item_base;
     const unsigned long long* vis;
     tr_layer_planes planes;
+    uint32_t* tile_cover;                      // [ceil(h/4)][ceil(w/64)] written by the resolve
 };
 struct tr_two_layers {
     tr_layer_work l[2];
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const tr_
 }
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two) {
     TR_PICK_LAYER(two, blockIdx.z);
-    raster_resolve_body(g, f, W.records, W.vis, W.planes);
+    raster_resolve_body(g, f, W.records, W.vis, W.planes, W.tile_cover);
 }
 
 }  // namespace tr

@@ -62,6 +62,8 @@ struct tr_context {
     uint32_t* d_chunk_sums = nullptr;
     tr_layer_counts* d_layer_counts = nullptr;
     unsigned long long* d_vis[2] = {nullptr, nullptr};
+    uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile, written by the resolve
+    const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
     size_t vis_pixels = 0;
     uint32_t num_cus = 256;
 
@@ -360,6 +362,10 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.lut_lines = ctx->d_lut_lines;
     L.levels = ctx->d_levels;
     L.tile_counters = ctx->d_tile_counters;
+    // the coverage map of the layer, when tr_record_frame rasterised it itself and shades the whole frame
+    L.tile_cover = (ctx->cover_hint && fp.rect_x0 == 0u && fp.rect_y0 == 0u && fp.g_origin_x == 0u && fp.g_origin_y == 0u &&
+                    fp.rect_x1 == fp.width && fp.rect_y1 == fp.height && fp.g_width == fp.width)
+                       ? ctx->cover_hint : nullptr;
     L.cluster_x = ctx->d_cluster_x;
     L.cluster_y_term = ctx->d_cluster_y_term;
     L.pos_depth = (const float4*)g->pos_depth;
@@ -471,6 +477,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_colour_tables);
     free_geometry(ctx);
     (void)hipFree(ctx->d_vis[0]);
+    (void)hipFree(ctx->d_tile_cover[0]);
     delete ctx;
     return TR_OK;
 }
@@ -829,10 +836,15 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
         (void)hipFree(ctx->d_vis[0]);
         ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
         ctx->vis_pixels = 0;
+        (void)hipFree(ctx->d_tile_cover[0]);
+        ctx->d_tile_cover[0] = ctx->d_tile_cover[1] = nullptr;
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u));   // both layers' visibility buffers, cleared by one fill
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_tile_cover[0], 2u * (npix / 64u + 65536u + 16384u) * 4u));   // >= 2 * ceil(w/64) * ceil(h/4)
         ctx->vis_pixels = npix;
     }
     ctx->d_vis[1] = ctx->d_vis[0] + npix;
+    const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
+    ctx->d_tile_cover[1] = ctx->d_tile_cover[0] + cover_tiles;
     tr_geometry_view gv;
     gv.position = ctx->d_position;
     gv.normal = ctx->d_normal;
@@ -867,6 +879,7 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
         W.planes.nrm_scale = (float4*)targets[layer]->nrm_scale;
         W.planes.uv = (float2*)targets[layer]->uv;
         W.planes.material_id = (uint32_t*)targets[layer]->material_id;
+        W.tile_cover = ctx->d_tile_cover[layer];
     }
     TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u, stream));
     const uint32_t max_cap = std::max(ctx->max_triangles[0], ctx->max_triangles[1]);
@@ -1320,11 +1333,15 @@ tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream)
         layers[k].origin_x = layers[k].origin_y = 0;
     }
     const tr_rect whole = {0u, 0u, w, h};
+    ctx->cover_hint = ctx->d_tile_cover[0];
     st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
+    ctx->cover_hint = nullptr;
     if (st != TR_OK) return st;
     st = tr_generate_mips(ctx, &f->pyramid, stream);
     if (st != TR_OK) return st;
+    ctx->cover_hint = ctx->d_tile_cover[1];
     st = tr_shade_transmission(ctx, &layers[1], f->uniforms, f->push, &f->pyramid, f->hdr, f->hdr_format, whole, stream);
+    ctx->cover_hint = nullptr;
     if (st != TR_OK) return st;
     // "tonemapping"
     if (f->ldr_out) st = tr_tonemap(ctx, f->hdr, w, h, f->tonemap, f->ldr_out, f->bgra, stream);
