@@ -495,8 +495,9 @@ __global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const tr_
     if (W.capacity_triangles == 0u) return;
     raster_scan_items_apply_body(W.item_counts, W.chunk_sums, W.counts, W.item_base);
 }
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two) {
-    TR_PICK_LAYER(two, blockIdx.z);
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two,
+                                                             uint32_t first_layer) {
+    TR_PICK_LAYER(two, blockIdx.z + first_layer);
     raster_resolve_body(g, f, W.records, W.vis, W.planes, W.tile_cover);
 }
 

@@ -900,7 +900,7 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
                                ctx->d_vis[layer]);
         }
     }
-    hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two);
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two, 0u);
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
