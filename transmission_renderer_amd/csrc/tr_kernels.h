@@ -997,6 +997,12 @@ constexpr uint32_t kTileCounterWords = 8u * kXcdCounterWords;
 #ifndef TR_WAVE_BLOCKS
 #define TR_WAVE_BLOCKS 1
 #endif
+// Wave tile shape: 16x4 pixels (block tile 64x4), or TR_TILE_8X8: 8x8 (block tile 32x8)
+#ifndef TR_TILE_8X8
+#define TR_TILE_8X8 0
+#endif
+constexpr uint32_t kWaveTileW = TR_TILE_8X8 ? 8u : 16u, kWaveTileH = TR_TILE_8X8 ? 8u : 4u;
+constexpr uint32_t kBlockTileW = 4u * kWaveTileW, kBlockTileH = kWaveTileH;
 #ifndef TR_NT_STORE
 #define TR_NT_STORE 1
 #endif
@@ -1018,7 +1024,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) void shade_kernel(const 
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t lx = lane & 15u, ly = lane >> 4;                 // position inside the wave's 16x4 tile
+    const uint32_t lx = lane & (kWaveTileW - 1u), ly = lane / kWaveTileW;   // position inside the wave's tile
 
     const uint32_t ntiles = L->fp.tiles_x * L->fp.tiles_y;
     const uint32_t xcd = blockIdx.x & 7u;
@@ -1041,9 +1047,9 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) void shade_kernel(const 
             ++tyi;
         }
         txi = txi * 4u + (j & 3u);
-        t.px = F->fp.rect_x0 + txi * 16u + lx;
-        t.py = F->fp.rect_y0 + tyi * 4u + ly;
-        if (F->tile_cover && as_constant(F->tile_cover)[tile] == 0u) {   // (scalar) nothing rasterised into this block tile
+        t.px = F->fp.rect_x0 + txi * kWaveTileW + lx;
+        t.py = F->fp.rect_y0 + tyi * kWaveTileH + ly;
+        if (!TR_TILE_8X8 && F->tile_cover && as_constant(F->tile_cover)[tile] == 0u) {   // (scalar) nothing rasterised into this block tile
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
             t.uv = float2{0.f, 0.f};
@@ -1178,13 +1184,13 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) void shade_kernel(const 
                 // clamped to the frame edge read the same pixel as their partner: zero as well)
                 const bool covered = cur.mat != TR_NOT_COVERED;
                 auto swz_x = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x041F)); };  // lane ^ 1
-                auto swz_y = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); };  // lane ^ 16
+                auto swz_y = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), TR_TILE_8X8 ? 0x201F : 0x401F)); };  // lane ^ 16 (^ 8): the pixel below / above
                 // (every swizzle is evaluated by the whole wave, outside any condition: a lane-crossing read under a
                 // short-circuit would run with the uncovered lanes switched off and read zeros from them)
                 const int mat_x = __builtin_amdgcn_ds_swizzle((int)cur.mat, 0x041F);
-                const int mat_y = __builtin_amdgcn_ds_swizzle((int)cur.mat, 0x401F);
+                const int mat_y = __builtin_amdgcn_ds_swizzle((int)cur.mat, TR_TILE_8X8 ? 0x201F : 0x401F);
                 const bool cov_x = covered & (mat_x != (int)TR_NOT_COVERED), cov_y = covered & (mat_y != (int)TR_NOT_COVERED);
-                const float sgn_x = (lane & 1u) ? -1.0f : 1.0f, sgn_y = (lane & 16u) ? -1.0f : 1.0f;
+                const float sgn_x = (lane & 1u) ? -1.0f : 1.0f, sgn_y = (lane & kWaveTileW) ? -1.0f : 1.0f;
                 const float nvx = -(S->fp.view_position[0] - cur.pd.x), nvy = -(S->fp.view_position[1] - cur.pd.y),
                             nvz = -(S->fp.view_position[2] - cur.pd.z);
                 auto ddx = [&](float v) { const float d = (swz_x(v) - v) * sgn_x; return cov_x ? d : 0.0f; };

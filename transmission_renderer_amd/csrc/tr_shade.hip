@@ -286,8 +286,8 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     fp->rect_y0 = rect.y0;
     fp->rect_x1 = rect.x1;
     fp->rect_y1 = rect.y1;
-    fp->tiles_x = (rect.x1 - rect.x0 + 63u) / 64u;
-    fp->tiles_y = (rect.y1 - rect.y0 + 3u) / 4u;
+    fp->tiles_x = (rect.x1 - rect.x0 + kBlockTileW - 1u) / kBlockTileW;
+    fp->tiles_y = (rect.y1 - rect.y0 + kBlockTileH - 1u) / kBlockTileH;
     fp->tiles_x_magic = (uint32_t)(0x100000000ull / fp->tiles_x > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->tiles_x);
 #if TR_ABLATION
     if (const char* e = std::getenv("TR_ABLATE")) fp->ablate = (uint32_t)std::atoi(e);  // profiling builds only
