@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
                                                      const tr_layer_counts* __restrict__ counts,
                                                      const tr_alpha_tables alpha,
                                                      const unsigned long long* __restrict__ behind /* layer 0's buffer or null */,
-                                                     unsigned long long* __restrict__ vis) {
+                                                     unsigned long long* __restrict__ vis,
+                                                     uint32_t* __restrict__ tile_cover /* [ceil(h/4)][ceil(w/64)], zeroed */) {
 #pragma clang fp contract(off)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves = gridDim.x * 4u;
@@ -390,6 +391,15 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
                 hit = !(alpha_v < m.alpha_clipping_cutoff);
             }
             if (hit) atomicMax(&vis[pix], ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)t);
+            // the 64x4 block tiles that received a fragment (the 8x8 block lies in two of them, one above the other):
+            // the resolve and, inside tr_record_frame, the shading passes skip the others
+            const unsigned long long hits = ballot(hit);
+            if (hits != 0ull && lane == 0u) {
+                const uint32_t cover_w = (f.width + 63u) >> 6;
+                uint32_t* c = tile_cover + (size_t)(by * 2u) * cover_w + (bx >> 3);
+                if ((uint32_t)hits != 0u) c[0] = 1u;
+                if ((uint32_t)(hits >> 32) != 0u) c[cover_w] = 1u;
+            }
         }
       }
     }
@@ -407,17 +417,18 @@ struct tr_layer_planes {
 __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, const tr_raster_frame f,
                                                              const tr_tri_record* __restrict__ records,
                                                              const unsigned long long* __restrict__ vis,
-                                                             const tr_layer_planes out, uint32_t* __restrict__ tile_cover) {
+                                                             const tr_layer_planes out, const uint32_t* __restrict__ tile_cover) {
 #pragma clang fp contract(off)
     const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
-    const bool in_frame = px < f.width && py < f.height;
-    const size_t pix = in_frame ? (size_t)py * f.width + px : 0u;
-    const unsigned long long key = in_frame ? vis[pix] : 0ull;
-    // one word per 64x4 block tile (this workgroup): does the layer have a fragment in it?  The shading passes of
-    // tr_record_frame skip the plane loads of empty tiles (a transmissive layer is mostly empty).
-    const int any = __syncthreads_or(key != 0ull);
-    if (threadIdx.x == 0) tile_cover[blockIdx.y * gridDim.x + blockIdx.x] = any ? 1u : 0u;
-    if (!in_frame) return;
+    if (px >= f.width || py >= f.height) return;
+    const size_t pix = (size_t)py * f.width + px;
+    // one word per 64x4 block tile (this workgroup), set by raster_kernel when a fragment landed in it: an untouched tile
+    // has no fragment, its visibility words need not be read
+    if (as_constant(tile_cover)[blockIdx.y * gridDim.x + blockIdx.x] == 0u) {
+        out.material_id[pix] = TR_NOT_COVERED;
+        return;
+    }
+    const unsigned long long key = vis[pix];
     if (key == 0ull) {   // no fragment: only the id plane is defined there (the shading passes look at nothing else)
         out.material_id[pix] = TR_NOT_COVERED;
         return;
@@ -462,7 +473,7 @@ struct tr_layer_work {
     uint32_t* item_base;
     const unsigned long long* vis;
     tr_layer_planes planes;
-    uint32_t* tile_cover;                      // [ceil(h/4)][ceil(w/64)] written by the resolve
+    uint32_t* tile_cover;                      // [ceil(h/4)][ceil(w/64)]: zeroed with the visibility buffers, set by raster_kernel
 };
 struct tr_two_layers {
     tr_layer_work l[2];

@@ -62,7 +62,7 @@ struct tr_context {
     uint32_t* d_chunk_sums = nullptr;
     tr_layer_counts* d_layer_counts = nullptr;
     unsigned long long* d_vis[2] = {nullptr, nullptr};
-    uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile, written by the resolve
+    uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
     size_t vis_pixels = 0;
     uint32_t num_cus = 256;
@@ -477,7 +477,6 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_colour_tables);
     free_geometry(ctx);
     (void)hipFree(ctx->d_vis[0]);
-    (void)hipFree(ctx->d_tile_cover[0]);
     delete ctx;
     return TR_OK;
 }
@@ -836,14 +835,14 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
         (void)hipFree(ctx->d_vis[0]);
         ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
         ctx->vis_pixels = 0;
-        (void)hipFree(ctx->d_tile_cover[0]);
         ctx->d_tile_cover[0] = ctx->d_tile_cover[1] = nullptr;
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u));   // both layers' visibility buffers, cleared by one fill
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_tile_cover[0], 2u * (npix / 64u + 65536u + 16384u) * 4u));   // >= 2 * ceil(w/64) * ceil(h/4)
+        // both layers' visibility buffers and, behind them, their tile coverage maps: cleared by one fill
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 2u * (npix / 64u + 65536u + 16384u) * 4u));
         ctx->vis_pixels = npix;
     }
     ctx->d_vis[1] = ctx->d_vis[0] + npix;
     const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
+    ctx->d_tile_cover[0] = (uint32_t*)(ctx->d_vis[0] + 2u * npix);
     ctx->d_tile_cover[1] = ctx->d_tile_cover[0] + cover_tiles;
     tr_geometry_view gv;
     gv.position = ctx->d_position;
@@ -881,7 +880,7 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
         W.planes.material_id = (uint32_t*)targets[layer]->material_id;
         W.tile_cover = ctx->d_tile_cover[layer];
     }
-    TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u, stream));
+    TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u + 2u * cover_tiles * 4u, stream));
     const uint32_t max_cap = std::max(ctx->max_triangles[0], ctx->max_triangles[1]);
     if (max_cap > 0u) {
         const uint32_t chunks = (max_cap + kScanChunk - 1u) / kScanChunk;
@@ -897,7 +896,7 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
             hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * 8u), dim3(256), 0, stream, gv, fr,
                                (const tr_tri_record*)W.records, (const uint32_t*)W.item_base, (const tr_layer_counts*)W.counts, at,
                                layer ? (const unsigned long long*)ctx->d_vis[0] : (const unsigned long long*)nullptr,
-                               ctx->d_vis[layer]);
+                               ctx->d_vis[layer], ctx->d_tile_cover[layer]);
         }
     }
     hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two, 0u);
