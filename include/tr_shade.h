@@ -519,6 +519,21 @@ tr_status tr_fresnel_schlick(tr_context* ctx, const void* view_dot_halfway_dev, 
 tr_status tr_compute_f0(tr_context* ctx, const void* metallic_dev, const void* index_of_refraction_dev,
                         const void* diffuse_colour_dev, uint32_t count, void* out_dev, void* stream);
 
+/* `LightClusterCoefficients::get_depth_slice` (shared-structs/src/lib.rs:54-63; called per fragment at
+ * shader/src/lib.rs:88-98, 205-215) over an array: frag_depth_dev = float[count] (`frag_coord.z`), slices_out_dev =
+ * uint32_t[count].  Index work: BIT-EXACT with the reference's fp32 arithmetic (evaluated with the host's libm) for
+ * every depth in [0, +inf] and NaN — the shading passes call the same device function for their cluster lookup.
+ * Coefficients whose far-plane slice exceeds TR_MAX_DEPTH_SLICES return TR_ERR_UNSUPPORTED. */
+tr_status tr_get_depth_slice(tr_context* ctx, const tr_light_cluster_coefficients* coefficients, const void* frag_depth_dev,
+                             uint32_t count, void* slices_out_dev, void* stream);
+/* Host only (no device needed): the table behind that exactness.  get_depth_slice is a non-increasing step function
+ * of a non-negative depth; thresholds_out[k] (k = 1 .. *max_slice_out) receives the LARGEST depth whose slice is >= k,
+ * found by bisection over bit patterns with the reference's own fp32 operations; thresholds_out[0] = +inf,
+ * thresholds_out[*max_slice_out + 1] = -1.  So slice(d) = #{k >= 1 : d <= thresholds_out[k]} for d in [0, +inf].
+ * thresholds_out must hold TR_MAX_DEPTH_SLICES + 2 floats. */
+tr_status tr_depth_slice_thresholds(const tr_light_cluster_coefficients* coefficients, float* thresholds_out,
+                                    uint32_t* max_slice_out);
+
 /* ------------------------------------------------------------------ tonemap */
 
 /* Host only: Lottes' curve constants from the un-baked parameters (what colstodian's

@@ -282,11 +282,14 @@ void o_light_cluster_coefficients_new(real z_near, real z_far, uint32_t slices,
     out->bias = -((real)slices * R_LOG2(z_near) / R_LOG2(z_far / z_near));
 }
 
-/* shared-structs/src/lib.rs:54-63 */
-uint32_t o_get_depth_slice(const tr_light_cluster_coefficients* c, real frag_depth) {
-    real depth_range = R(2.0) * (R(1.0) - frag_depth) - R(1.0);
-    real linear = R(2.0) * c->z_near * c->z_far / (c->z_far + c->z_near - depth_range * (c->z_far - c->z_near));
-    return f32_as_u32(R_MAX(R_LOG2(linear) * c->scale + c->bias, R(0.0)));
+/* shared-structs/src/lib.rs:54-63.  Index work: evaluated in fp32 in BOTH builds of this file — the fp64 twin
+ * exists to show how much of a pixel's VALUE is rounding noise of the reference's formulas, and must read the
+ * same light list as the reference to do so. */
+uint32_t o_get_depth_slice(const tr_light_cluster_coefficients* c, real frag_depth_in) {
+    float frag_depth = (float)frag_depth_in;
+    float depth_range = 2.0f * (1.0f - frag_depth) - 1.0f;
+    float linear = 2.0f * c->z_near * c->z_far / (c->z_far + c->z_near - depth_range * (c->z_far - c->z_near));
+    return f32_as_u32((real)fmaxf(log2f(linear) * c->scale + c->bias, 0.0f));
 }
 
 /* shared-structs/src/lib.rs:129-138 */
@@ -933,8 +936,9 @@ static void get_diffuse(const o_scene* s, const tr_material_info* m, o_vec2 uv, 
 
 /* cluster index: shader/src/lib.rs:88-98 / 205-215 */
 static uint32_t cluster_index(const tr_uniforms* u, const real frag_coord[4]) {
-    uint32_t cx = f32_as_u32(frag_coord[0] / u->cluster_size_in_pixels[0]);
-    uint32_t cy = f32_as_u32(frag_coord[1] / u->cluster_size_in_pixels[1]);
+    /* (index work: fp32 division in both builds, see o_get_depth_slice) */
+    uint32_t cx = f32_as_u32((real)((float)frag_coord[0] / u->cluster_size_in_pixels[0]));
+    uint32_t cy = f32_as_u32((real)((float)frag_coord[1] / u->cluster_size_in_pixels[1]));
     uint32_t cz = o_get_depth_slice(&u->light_clustering_coefficients, frag_coord[2]);
     return cz * u->num_clusters[0] * u->num_clusters[1] + cy * u->num_clusters[0] + cx;
 }

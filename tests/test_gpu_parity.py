@@ -1,8 +1,19 @@
 """GPU parity (run with -m gpu on an MI355X): every pixel comes from libtr_shade.so through the C ABI and is
 checked against the CPU oracle on the same seeded inputs.
 
-Tolerances (north_star: frames within 1e-4 per-channel RMSE of the reference, on the RGBA16F HDR target)
-  * HDR values span 1e-9 .. 4e3; fp32 itself resolves 2.4e-4 at 4e3 and the RGBA16F target 2 at 4e3, so errors
+Tolerances (north_star: frames within 1e-4 per-channel RMSE of the reference, on the RGBA16F HDR target).  The
+pinned object is the fp32 oracle (bit-identical to the reference's compiled SPIR-V, tests/test_oracle_vs_spirv.py).
+      P0  the FRAME AS PRESENTED: both RGBA16F attachments through the reference's tonemap (fragment_tonemap, Lottes,
+          linear [0, 1]): plain per-channel RMSE(gpu, oracle_fp32) <= 1e-4 over ALL pixels, no normalisation, no
+          exclusions                                                                              (measured 1.0-1.6e-5)
+      P1  the HDR attachment itself, ALL pixels, against oracle_fp32: per-channel RMSE of (gpu - ref) / max(|ref|, 1)
+          <= 1e-4 (HDR values reach 4e5 on glossy highlights, where one fp32 ulp is 0.03 and RGBA16F overflows: a
+          raw difference is not a meaningful number there; it is printed by tools/gpu_parity_report.py).
+          (measured 1e-6 .. 6e-5).  One configuration (250x130, three lights, roughness down to 0.02) is dominated
+          by pixels where the REFERENCE'S OWN fp32 formulas are ill-conditioned (below): there oracle_fp32 is 2.3e-4
+          from its own fp64 evaluation, and P1 asserts instead that the GPU adds nothing to that:
+          RMSE(gpu, oracle_fp32) <= RMSE(oracle_fp32, oracle_fp64) + 1e-5.
+  * HDR values span 1e-9 .. 4e5; fp32 itself resolves 0.03 at 4e5 and the RGBA16F target 2 at 4e3, so HDR errors
     are measured relative to max(|reference|, 1): absolute below 1, relative above.
   * The reference's own fp32 formulas are ill-conditioned on a small set of pixels (d_ggx at low roughness:
     1 - (n.h)^2 is needed to ~1e-9): there the fp32 oracle differs from the same formulas in fp64 by up to
@@ -60,16 +71,38 @@ def _rmse(e):
     return np.sqrt((e[..., :3] ** 2).mean(axis=(0, 1)))
 
 
-def _check_against_oracles(got32, got16, o32, o64, o16_64, what, allow_outliers=0.0):
+_TONEMAP = None
+
+
+def _display(frame16):
+    """The frame as the reference presents it: fragment_tonemap (shader/src/lib.rs:683-697; Lottes operator with
+    tr_lottes_defaults) of the RGBA16F attachment, linear [0, 1] before the sRGB encode."""
+    global _TONEMAP
+    if _TONEMAP is None:
+        from transmission_renderer_amd import _lib
+        lp, _TONEMAP = wire.LottesParams(), wire.TonemapParams()
+        assert _lib.load().tr_lottes_defaults(C.byref(lp)) == 0
+        assert _lib.load().tr_bake_lottes_params(C.byref(lp), C.byref(_TONEMAP)) == 0
+    return oracle.tonemap_frame(np.ascontiguousarray(frame16, dtype=np.float16), _TONEMAP)[1].astype(np.float64)
+
+
+def _check_against_oracles(got32, got16, o32, o64, o16_64, what, o16_32=None):
     assert np.isfinite(got32).all(), what
+    # P0: the presented frame against the pinned fp32 oracle's: plain RMSE, all pixels
+    if o16_32 is None:
+        with np.errstate(over="ignore"):
+            o16_32 = o32.astype(np.float16)
+    p0 = np.sqrt(((_display(got16) - _display(o16_32)) ** 2).mean(axis=(0, 1)))
+    assert p0.max() <= 1e-4, (what, "P0 display-referred RMSE vs oracle32", p0)
+    # P1: the HDR attachment against the pinned fp32 oracle, all pixels
+    p1 = _rmse(_norm_err(got32, o32)).max()
+    noise = _rmse(_norm_err(o32, o64)).max()      # the reference's own fp32 rounding noise on this input
+    print(f"[parity] {what}: P0 {p0.max():.2e}  P1 rmse(gpu, oracle32) {p1:.2e}  rmse(oracle32, oracle64) {noise:.2e}")
+    if noise <= 5e-5:
+        assert p1 <= 1e-4, (what, "P1 all-pixel RMSE vs oracle32", p1)
+    else:   # an ill-conditioned input: the fp32 reference is not reproducible to 1e-4 by any other evaluation order
+        assert p1 <= noise + 1e-5, (what, "P1 (ill-conditioned reference)", p1, noise)
     e64 = _norm_err(got32, o64)
-    if allow_outliers:   # pixels that took a different light list (depth-slice boundary moved by one pixel)
-        out = np.abs(e64).max(axis=2) > 5e-3
-        assert out.mean() <= allow_outliers, (what, "outliers", out.mean())
-        keep = ~out
-        got32, got16, o32, o64, o16_64 = (np.where(keep[..., None], a, 1.0) for a in (got32, got16, o32, o64, o16_64))
-        got16, o16_64 = got16.astype(np.float16), o16_64.astype(np.float16)
-        e64 = _norm_err(got32, o64)
     assert _rmse(e64).max() <= 1e-4, (what, "T1", _rmse(e64))
     assert np.abs(e64).max() <= 5e-3, (what, "T1 max", np.abs(e64).max())
     # T2: the RGBA16F target
@@ -128,7 +161,7 @@ def test_transmissive_pass_parity(renderer, ggx_lut, w, h, nl, coverage, rough):
     holes = scene["gbuffer"]["material_id"] == wire.NOT_COVERED
     assert (got32[holes] == 0.125).all() and (got16[holes] == np.float16(0.125)).all()   # untouched
     assert (got32[~holes][:, 3] == 1.0).all()
-    _check_against_oracles(got32, got16, o32, o64, o16_64, f"transmission {w}x{h} N={nl}")
+    _check_against_oracles(got32, got16, o32, o64, o16_64, f"transmission {w}x{h} N={nl}", o16_32=o16)
 
 
 @pytest.mark.parametrize("w,h,spot", [(256, 256, False), (250, 130, True)])
@@ -148,14 +181,14 @@ def test_opaque_pass_parity(renderer, ggx_lut, w, h, spot):
     r.shade_opaque(g, scene["uniforms"], scene["push"], h32, None)
     r.shade_opaque(g, scene["uniforms"], scene["push"], h16, pyr)
     torch.cuda.synchronize()
-    _, o32, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8)
+    o16, o32, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8)
     o16_64, o64, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
     got32, got16 = h32.cpu().numpy(), h16.cpu().numpy()
     holes = scene["gbuffer"]["material_id"] == wire.NOT_COVERED
     np.testing.assert_array_equal(got32[holes], np.broadcast_to(np.float32([0, 0, 0, 1]), got32[holes].shape))
     # both attachments get the same value (lib.rs:247-248)
     np.testing.assert_array_equal(pyr.level(0).cpu().numpy().view(np.uint16), got16.view(np.uint16))
-    _check_against_oracles(got32, got16, o32, o64, o16_64, f"opaque {w}x{h} spot={spot}")
+    _check_against_oracles(got32, got16, o32, o64, o16_64, f"opaque {w}x{h} spot={spot}", o16_32=o16)
 
 
 def test_parity_with_assigned_cluster_lists(renderer, ggx_lut):
@@ -195,12 +228,10 @@ def test_parity_with_assigned_cluster_lists(renderer, ggx_lut):
     r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
     r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t16)
     torch.cuda.synchronize()
-    _, o32 = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8)
+    o16, o32 = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8)
     o16_64, o64 = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8, fp64=True)
-    # lanes whose depth slice differs between v_log_f32 and log2f sit on a slice boundary: compare only pixels
-    # whose light list is the same on both sides (all but a handful)
-    _check_against_oracles(t32.cpu().numpy(), t16.cpu().numpy(), o32, o64, o16_64, "assigned cluster lists",
-                           allow_outliers=2e-3)
+    # every pixel takes the light list the reference takes (the depth slice is bit-exact): no exclusions
+    _check_against_oracles(t32.cpu().numpy(), t16.cpu().numpy(), o32, o64, o16_64, "assigned cluster lists", o16_32=o16)
 
 
 def test_debug_clusters_and_cluster_lookup_exact(renderer, ggx_lut):
@@ -221,8 +252,9 @@ def test_debug_clusters_and_cluster_lookup_exact(renderer, ggx_lut):
     torch.cuda.synchronize()
     _, o32, _ = oracle.shade_opaque(b, scene["gbuffer"])
     got = h32.cpu().numpy()
-    mism = (np.abs(got - o32).max(axis=2) > 1e-6).mean()
-    assert mism <= 2e-3, mism   # a depth-slice boundary can move by one pixel (v_log_f32 vs log2f); nothing else may
+    # the debug view is a pure function of (light count, cluster id): every pixel shows the reference's cluster
+    assert np.abs(got - o32).max() <= 1e-6, (np.abs(got - o32).max(), (np.abs(got - o32).max(axis=2) > 1e-6).sum())
+    assert len(np.unique(np.round(o32.reshape(-1, 4), 4), axis=0)) >= 8      # several clusters / counts in view
 
 
 @pytest.mark.parametrize("w,h", [(256, 256), (250, 130), (1920, 1080), (3, 5)])
@@ -441,11 +473,45 @@ def test_many_lights_long_and_ragged_lists(renderer, ggx_lut):
     _, want_t = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8, fp64=True)
     _, want_o, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
     for got, want, what in ((t32.cpu().numpy(), want_t, "transmission"), (o32.cpu().numpy(), want_o, "opaque")):
+        e = _norm_err(got, want)                 # every pixel: the cluster index is bit-exact, so the lists agree
+        assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (what, _rmse(e), np.abs(e).max())
+
+
+def test_borrowed_tables_counting_past_the_list_capacity(renderer, ggx_lut):
+    """Tables bound through tr_set_cluster_tables are the caller's: a reference-style counter keeps counting past
+    the 128 slots of a list (shader/src/lib.rs:634-643 stores only the first 128).  The passes clamp the count to
+    the capacity on BOTH light-loop paths — tiles inside one cluster (scalar walk) and tiles that straddle clusters
+    (per-lane walk) — so a frame does not change with the tile/cluster alignment."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    w, h = 250, 130          # clusters are 250/16 = 15.6 px wide: most 16x4 wave tiles straddle two of them
+    scene = synthetic.make_scene(w, h, num_point_lights=3)
+    rng = np.random.default_rng(9)
+    cap = wire.MAX_LIGHTS_PER_CLUSTER
+    counts = rng.integers(cap - 3, cap + 120, wire.NUM_CLUSTERS).astype(np.uint32)      # 125 .. 247
+    lists = rng.integers(0, 3, (wire.NUM_CLUSTERS, cap)).astype(np.uint32)              # different in every cluster
+    for l in scene["lights"]:
+        for k in range(3):
+            l.colour_emission_and_falloff_distance_sq[k] *= 1.0 / 64.0                   # ~128 evaluations per pixel
+    scene["cluster_counts"], scene["light_indices"] = counts, lists.reshape(-1)
+    _upload_scene(r, scene)
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    tex = oracle.new_pyramid(w, h, synthetic.make_opaque_mip0(w, h))
+    oracle.generate_mips(w, h, tex)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.texels.copy_(torch.from_numpy(tex).to(r.device))
+    t32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    o32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
+    r.shade_opaque(g, scene["uniforms"], scene["push"], o32, None)
+    torch.cuda.synchronize()
+    clamped = dict(scene, cluster_counts=np.minimum(counts, cap))
+    b = oracle.SceneBinding(clamped, ggx_lut)
+    _, want_t = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8, fp64=True)
+    _, want_o, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
+    for got, want, what in ((t32.cpu().numpy(), want_t, "transmission"), (o32.cpu().numpy(), want_o, "opaque")):
         e = _norm_err(got, want)
-        out = np.abs(e).max(axis=2) > 5e-3       # pixels on a depth-slice boundary take a neighbouring cluster's list
-        assert out.mean() <= 3e-3, (what, out.mean())
-        e = np.where(out[..., None], 0.0, e)
-        assert _rmse(e).max() <= 1e-4, (what, _rmse(e))
+        assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (what, _rmse(e), np.abs(e).max())
 
 
 def test_8k_frame_bands_and_oracle_rows(renderer, ggx_lut):

@@ -170,8 +170,10 @@ def test_rasterize_then_shade_end_to_end(renderer, ggx_lut):
     assert fin.mean() > 0.995
     e = np.where(fin[..., None], (got - want) / np.maximum(np.abs(want), 1.0), 0.0)
     rmse = np.sqrt((e[..., :3] ** 2).mean(axis=(0, 1))).max()
-    assert rmse <= 2e-3, rmse     # silhouettes: quad partners from different surfaces change LODs / TBN frames
-    assert np.quantile(np.abs(e), 0.98) <= 2e-3
+    # the layers are bit-identical on both sides, so this is the shading passes' bound (measured 3e-5: the opaque
+    # pass flips ~25 texels of mip 0 by one half-precision step, everything downstream follows the oracle)
+    assert rmse <= 1e-4, rmse
+    assert np.quantile(np.abs(e), 0.999) <= 2e-3
 
 
 def test_raster_error_paths(ggx_lut):

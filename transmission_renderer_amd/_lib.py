@@ -22,7 +22,7 @@ SYMBOLS = (
     "tr_write_cluster_data", "tr_assign_lights_to_clusters", "tr_shade_opaque",
     "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap", "tr_record_frame",
     "tr_basic_brdf", "tr_transmission_btdf", "tr_ibl_volume_refraction", "tr_light_direction_and_attenuation", "tr_d_ggx",
-    "tr_v_smith_ggx_correlated", "tr_fresnel_schlick", "tr_compute_f0",
+    "tr_v_smith_ggx_correlated", "tr_fresnel_schlick", "tr_compute_f0", "tr_get_depth_slice", "tr_depth_slice_thresholds",
 )
 
 _lib = None
@@ -117,6 +117,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # (ctx, <nptr input arrays>, count, out, stream)
         fn.restype = i32
         fn.argtypes = [vp] + [vp] * nptr + [u32, vp, vp]
+    lib.tr_get_depth_slice.restype = i32
+    lib.tr_get_depth_slice.argtypes = [vp, C.POINTER(wire.LightClusterCoefficients), vp, u32, vp, vp]
+    lib.tr_depth_slice_thresholds.restype = i32
+    lib.tr_depth_slice_thresholds.argtypes = [C.POINTER(wire.LightClusterCoefficients), C.POINTER(C.c_float), C.POINTER(u32)]
     lib.tr_ibl_volume_refraction.restype = i32
     lib.tr_ibl_volume_refraction.argtypes = [vp, vp, u32, C.POINTER(wire.Pyramid), vp, vp]
     if lib.tr_abi_version() != 1:

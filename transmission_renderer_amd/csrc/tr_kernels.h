@@ -144,10 +144,11 @@ struct tr_frame_params {
     float view_position[3];
     float log2_fb_width;         // log2(framebuffer_size.x as f32)
     float sun_dir[3];
-    float slice_k;               // depth slice = slice_k - lcc_scale * log2(slice_a * depth + slice_b)
-    float sun_intensity[3];
+    float slice_k;               // depth slice ~ slice_k - lcc_scale * log2(slice_fpn - (2 (1 - depth) - 1) * slice_fmn),
+    float sun_intensity[3];      //   made exact against the slice_thr table (depth_slice)
     float lcc_scale;
-    float slice_a, slice_b;
+    float slice_fpn, slice_fmn;  // z_far + z_near, z_far - z_near (fp32, as the reference forms them)
+    uint32_t slice_max;          // get_depth_slice(+0.0): the last slice a depth in [0, inf] can fall into
     uint32_t clusters_xy;        // num_clusters.x * num_clusters.y
     uint32_t num_clusters_total;
     uint32_t debug_clusters;
@@ -196,6 +197,7 @@ struct tr_launch {
     const struct tr_dtex* textures;
     const uint32_t* tex_arena;          // RGBA8 texels of every chain
     const float* srgb_to_linear;        // 256 entries
+    const float* slice_thr;             // [slice_max + 2] depth thresholds of get_depth_slice, see depth_slice()
     const uint32_t* tile_cover;         // optional: one word per 64x4 block tile of the frame, 0 = the layer has no fragment there
     uint32_t* tile_counters;            // per XCD kSubCounters tile counters + one count of finished waves, 256 bytes apart
 };
@@ -596,13 +598,58 @@ struct cluster_list {
     uint32_t s_num, s_l0, s_l1;   // (scalar) its count and the first two entries of its list
 };
 
-// shader/src/lib.rs:88-98: x / y from exact tables (cluster_xy), the depth slice of
-// shared-structs/src/lib.rs:54-63 folded to  slice = u32(max(K - scale * log2(2n + 2 depth (f - n)), 0)).
+// LightClusterCoefficients::get_depth_slice (shared-structs/src/lib.rs:43-63), BIT-EXACT for every depth in
+// [0, +inf] and NaN (index work).  The reference computes
+//     u32(max(log2(2nf / (f + n - (2 (1 - d) - 1)(f - n))) * scale + bias, 0))
+// in fp32; that is a composition of monotone correctly-rounded steps, so the slice is a non-increasing step function
+// of the depth's bit pattern, and the host (build_slice_thresholds, with the reference's own arithmetic and libm)
+// finds by bisection thr[k] = the largest depth whose slice is >= k  (thr[0] = +inf, thr[slice_max + 1] = -1).
+// The kernel estimates the slice with one v_log_f32 — the denominator formed by the reference's own roundings, because
+// 1 - d loses the low bits of a far depth and the estimate must follow that noise (~3e-3 slices at the far plane) —
+// which is within ~1e-5 of the reference's fp32 value; a wave none of whose lanes lies within 2.5e-4 of a slice
+// boundary is done, any other fetches the two thresholds around each lane's estimate and corrects it by +-1.
+__device__ __forceinline__ float slice_denominator(float depth, float fpn, float fmn) {
+#pragma clang fp contract(off)
+    const float depth_range = 2.0f * (1.0f - depth) - 1.0f;
+    return fpn - depth_range * fmn;
+}
+__device__ __forceinline__ uint32_t cvt_u32_sat(float x) {   // v_cvt_u32_f32: saturating, NaN -> 0 (Rust `as u32`)
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+constexpr float kSliceGuard = 2.5e-4f;
+struct slice_params {   // (scalar registers)
+    float scale, fpn, fmn, k;
+    uint32_t max;
+    const float* thr;
+};
+#ifndef TR_EXACT_SLICE
+#define TR_EXACT_SLICE 1   // 0 (experiments only, tools/ab_kernel.py): round 1's estimate-only slice, what exactness costs
+#endif
+__device__ __forceinline__ uint32_t depth_slice(const slice_params& sp, float depth) {
+#if !TR_EXACT_SLICE
+    return (uint32_t)fmaxf(fmaf(-sp.scale, fast_log2(fmaf(depth, 2.0f * sp.fmn, sp.fpn - sp.fmn)), sp.k), 0.0f);
+#endif
+    const float zs = fmaf(-sp.scale, fast_log2(slice_denominator(depth, sp.fpn, sp.fmn)), sp.k);
+    uint32_t cz = cvt_u32_sat(zs);
+    const float fr = __builtin_amdgcn_fractf(zs);
+    if (ballot(fabsf(fr - 0.5f) > 0.5f - kSliceGuard) != 0ull) {   // (rare) a lane near a slice boundary
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        const uint32_t k = min(cz, sp.max);
+        const f2u t = ld<f2u>(sp.thr, k * 4u);                      // thr[k], thr[k + 1]
+        const uint32_t fixed = k + (depth <= t.y ? 1u : 0u) - (depth > t.x ? 1u : 0u);
+        cz = depth >= 0.0f ? fixed : cz;                            // (negative depths: no frag_coord.z is; estimate kept)
+    }
+    return cz;
+}
+
+// shader/src/lib.rs:88-98: x / y from exact tables (cluster_xy), the depth slice from depth_slice().
 __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, uint32_t cluster_xy) {
     cluster_list c;
-    const float zs = fmaf(-L->fp.lcc_scale, fast_log2(fmaf(depth, L->fp.slice_a, L->fp.slice_b)), L->fp.slice_k);
-    const uint32_t cz = (uint32_t)fmaxf(zs, 0.0f);  // v_cvt_u32_f32 saturates, NaN -> 0 (Rust `as u32`)
-    c.cluster = mad24(cz, L->fp.clusters_xy, cluster_xy);   // (cz saturates far below 2^24 * clusters_xy)
+    const uint32_t cz = depth_slice(slice_params{L->fp.lcc_scale, L->fp.slice_fpn, L->fp.slice_fmn, L->fp.slice_k,
+                                                 L->fp.slice_max, L->slice_thr}, depth);
+    c.cluster = mad24(cz, L->fp.clusters_xy, cluster_xy);   // (cz <= slice_max for every depth >= 0: far below 2^24)
     const bool in_range = c.cluster < L->fp.num_clusters_total;  // out-of-range reads as 0 lights (robust access)
     const uint32_t csafe = in_range ? c.cluster : 0u;
     c.list_offset = csafe * (TR_MAX_LIGHTS_PER_CLUSTER * 4u);
@@ -631,7 +678,7 @@ __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, 
     const uint2 first = ld<uint2>(L->light_indices, c.list_offset);   // (lists are 512-byte aligned)
     c.l0 = first.x;
     c.l1 = first.y;
-    c.num_lights = in_range ? n : 0u;
+    c.num_lights = in_range ? min(n, TR_MAX_LIGHTS_PER_CLUSTER) : 0u;   // (borrowed tables may count past the 128 slots, like the reference's counter)
     if (TR_ABLATE(L, 8u)) c.num_lights = 0;
     return c;
 }
@@ -1282,6 +1329,15 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) void shade_kernel(const 
         atomicAdd(&tr_timing_counters[7][blockIdx.x & 1023u], __builtin_amdgcn_s_memrealtime() - t_real);
     }
 #endif
+}
+
+// LightClusterCoefficients::get_depth_slice over an array (tr_get_depth_slice): the passes' own device function.
+__global__ __launch_bounds__(256) void depth_slice_kernel(const float* __restrict__ depth, uint32_t count, const slice_params sp,
+                                                          uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const float d = depth[min(i, count - 1u)];   // (every lane of the wave runs depth_slice: it ballots)
+    const uint32_t z = depth_slice(sp, d);
+    if (i < count) out[i] = z;
 }
 
 // ------------------------------------------------------------------------ material digestion

@@ -66,6 +66,8 @@ struct tr_context {
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
     size_t vis_pixels = 0;
     uint32_t num_cus = 256;
+    bool occupancy_fallback = false;     // the occupancy query failed: the grid was sized for 8 waves per SIMD
+    bool mip_tail_attr_set = false;      // hipFuncSetAttribute(mip_tail_kernel, 160 KiB of LDS) done on this context's device
 
     // lights (as the shading kernels and as the cluster assignment read them)
     tr_dlight* d_lights = nullptr;
@@ -100,6 +102,13 @@ struct tr_context {
     float cl_sx = 0.0f, cl_sy = 0.0f;
     std::vector<uint16_t> stage_cluster_x;
     std::vector<uint32_t> stage_cluster_y;
+
+    // depth-slice thresholds of the bound LightClusterCoefficients (build_slice_thresholds)
+    float* d_slice_thr = nullptr;
+    tr_light_cluster_coefficients slice_coeffs{};
+    bool slice_valid = false;
+    uint32_t slice_max = 0;
+    float h_slice_thr[TR_MAX_DEPTH_SLICES + 2]{};
 };
 
 namespace {
@@ -247,6 +256,53 @@ tr_status ensure_cluster_tables(tr_context* ctx, const tr_uniforms* u, uint32_t 
     return TR_OK;
 }
 
+// LightClusterCoefficients::get_depth_slice (shared-structs/src/lib.rs:43-63) with the reference's own fp32
+// operations and the host's libm (what the oracle restates).
+inline uint32_t depth_slice_reference(const tr_light_cluster_coefficients& c, float frag_depth) {
+#pragma clang fp contract(off)
+    const float depth_range = 2.0f * (1.0f - frag_depth) - 1.0f;
+    const float linear = 2.0f * c.z_near * c.z_far / (c.z_far + c.z_near - depth_range * (c.z_far - c.z_near));
+    return f32_as_u32(std::fmax(std::log2(linear) * c.scale + c.bias, 0.0f));
+}
+
+// thr[k] = the largest depth in [0, +inf] whose slice is >= k, by bisection over the bit patterns (the slice is a
+// non-increasing step function of a non-negative depth); thr[0] = +inf, thr[slice_max + 1] = -1 (no depth >= 0 is
+// below it).  slice(d) = #{k >= 1 : d <= thr[k]}: the kernels' depth_slice() corrects its estimate with two of them.
+tr_status build_slice_thresholds(const tr_light_cluster_coefficients& c, float* thr, uint32_t* slice_max) {
+    const uint32_t top = depth_slice_reference(c, 0.0f);
+    if (top > TR_MAX_DEPTH_SLICES) return TR_ERR_UNSUPPORTED;
+    const uint32_t inf_bits = 0x7F800000u;
+    std::memcpy(&thr[0], &inf_bits, 4);
+    for (uint32_t k = 1; k <= top; ++k) {
+        uint32_t lo = 0u, hi = inf_bits;   // slice(lo) >= k > slice(hi)   (slice(+inf) = 0)
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            float d;
+            std::memcpy(&d, &mid, 4);
+            if (depth_slice_reference(c, d) >= k) lo = mid;
+            else hi = mid;
+        }
+        std::memcpy(&thr[k], &lo, 4);
+    }
+    thr[top + 1u] = -1.0f;
+    *slice_max = top;
+    return TR_OK;
+}
+
+tr_status ensure_slice_thresholds(tr_context* ctx, const tr_uniforms* u, hipStream_t stream) {
+    const tr_light_cluster_coefficients& c = u->light_clustering_coefficients;
+    if (ctx->slice_valid && std::memcmp(&ctx->slice_coeffs, &c, 20) == 0) return TR_OK;   // (the five fields, not the padding)
+    uint32_t top = 0;
+    const tr_status st = build_slice_thresholds(c, ctx->h_slice_thr, &top);
+    if (st != TR_OK) return st;
+    // (stream order protects the launches that still read the previous table)
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_slice_thr, ctx->h_slice_thr, sizeof(float) * (top + 2u), hipMemcpyHostToDevice, stream));
+    ctx->slice_coeffs = c;
+    ctx->slice_max = top;
+    ctx->slice_valid = true;
+    return TR_OK;
+}
+
 tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u,
                             const tr_push_constants* pc, tr_rect rect, tr_frame_params* fp) {
     const uint32_t fw = pc->framebuffer_size[0], fh = pc->framebuffer_size[1];
@@ -265,14 +321,16 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     std::memcpy(fp->sun_dir, u->sun_dir, sizeof(fp->sun_dir));
     std::memcpy(fp->sun_intensity, u->sun_intensity, sizeof(fp->sun_intensity));
     {
-        // get_depth_slice (shared-structs/src/lib.rs:54-63) folded: linear = 2nf / (2n + 2 d (f - n)), so
-        // log2(linear) * scale + bias = K - scale * log2(slice_a * d + slice_b)
+        // get_depth_slice (shared-structs/src/lib.rs:54-63): log2(linear) * scale + bias = K - scale * log2(denominator);
+        // the kernels form the denominator with the reference's own roundings and settle the integer against
+        // the threshold table (depth_slice in tr_kernels.h)
         const tr_light_cluster_coefficients& c = u->light_clustering_coefficients;
         const double n = c.z_near, f = c.z_far;
         fp->lcc_scale = c.scale;
-        fp->slice_a = (float)(2.0 * (f - n));
-        fp->slice_b = (float)(2.0 * n);
+        fp->slice_fpn = c.z_far + c.z_near;
+        fp->slice_fmn = c.z_far - c.z_near;
         fp->slice_k = (float)(std::log2(2.0 * n * f) * (double)c.scale + (double)c.bias);
+        fp->slice_max = ctx->slice_max;
     }
     fp->clusters_xy = u->num_clusters[0] * u->num_clusters[1];
     fp->num_clusters_total = ctx->num_clusters_total;
@@ -366,6 +424,7 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.tile_cover = (ctx->cover_hint && fp.rect_x0 == 0u && fp.rect_y0 == 0u && fp.g_origin_x == 0u && fp.g_origin_y == 0u &&
                     fp.rect_x1 == fp.width && fp.rect_y1 == fp.height && fp.g_width == fp.width)
                        ? ctx->cover_hint : nullptr;
+    L.slice_thr = ctx->d_slice_thr;
     L.cluster_x = ctx->d_cluster_x;
     L.cluster_y_term = ctx->d_cluster_y_term;
     L.pos_depth = (const float4*)g->pos_depth;
@@ -418,14 +477,21 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
     if (!ctx) return TR_ERR_OUT_OF_MEMORY;
     ctx->device = device_ordinal;
     {
-        // persistent grid: kGridRounds (4) times the resident blocks per CU with the static tile order (measured on
-        // MI355X, 8 waves per SIMD: 1 / 2 / 4 / 6 / 8 / 32 rounds -> 117 / 115 / 112 / 111 / 111 / 117 us in the
-        // profiling build: the uneven ends of the waves' runs are spread over more, shorter runs), 1/8 of them per XCD
+        // Grid of the shading kernels: kGridRounds times the waves one CU holds (measured on MI355X, 8 waves per SIMD:
+        // 1 / 2 / 4 / 6 / 8 / 32 rounds -> 117 / 115 / 112 / 111 / 111 / 117 us in the profiling build: the uneven ends
+        // of the waves' runs are spread over more, shorter runs), 1/8 of them per XCD.  The occupancy is asked for the
+        // block size that is launched (one-wave workgroups: 64 threads -> resident WAVES per CU; 32 when the kernel
+        // holds 8 waves per SIMD); blocks_per_xcd counts units of four waves (persistent_grid's callers multiply by 4).
+        // The TEXTURED variants hold fewer waves (4 per SIMD) and are launched with the same grid: 16 rounds for them.
         hipDeviceProp_t prop;
-        int resident = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, shade_kernel<true, uint2>, 256, 0) != hipSuccess ||
-            resident <= 0)
-            resident = 4;
+        int resident_waves = 0;
+        const int launched_block = TR_WAVE_BLOCKS ? 64 : 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_waves, shade_kernel<true, uint2>, launched_block, 0) != hipSuccess ||
+            resident_waves <= 0) {
+            resident_waves = 32 * 64 / launched_block;   // 8 waves per SIMD (the kernel is built for 64 VGPRs)
+            ctx->occupancy_fallback = true;
+        }
+        const int resident = resident_waves * launched_block / 256 > 0 ? resident_waves * launched_block / 256 : 1;
         if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount >= 8) {
             ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * kGridRounds;
             ctx->num_cus = (uint32_t)prop.multiProcessorCount;
@@ -433,10 +499,12 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
     }
     if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_slice_thr, sizeof(float) * (TR_MAX_DEPTH_SLICES + 2)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_colour_tables, sizeof(tr_colour_tables)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_tile_counters, kTileCounterWords * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(ctx->d_tile_counters, 0, kTileCounterWords * sizeof(uint32_t)) != hipSuccess) {
         (void)hipFree(ctx->d_levels);
+        (void)hipFree(ctx->d_slice_thr);
         (void)hipFree(ctx->d_colour_tables);
         (void)hipFree(ctx->d_tile_counters);
         delete ctx;
@@ -447,6 +515,7 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         fill_colour_tables(&tables);
         if (hipMemcpy(ctx->d_colour_tables, &tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(ctx->d_levels);
+            (void)hipFree(ctx->d_slice_thr);
             (void)hipFree(ctx->d_colour_tables);
             (void)hipFree(ctx->d_tile_counters);
             delete ctx;
@@ -469,6 +538,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_lut_pairs);
     (void)hipFree(ctx->d_lut_lines);
     (void)hipFree(ctx->d_levels);
+    (void)hipFree(ctx->d_slice_thr);
     (void)hipFree(ctx->d_tile_counters);
     (void)hipFree(ctx->d_cluster_x);
     (void)hipFree(ctx->d_cluster_y_term);
@@ -965,6 +1035,36 @@ tr_status tr_assign_lights_to_clusters(tr_context* ctx, const float view_matrix[
     return TR_OK;
 }
 
+tr_status tr_depth_slice_thresholds(const tr_light_cluster_coefficients* c, float* thresholds_out, uint32_t* max_slice_out) {
+    if (!c || !thresholds_out || !max_slice_out) return TR_ERR_INVALID_ARGUMENT;
+    return build_slice_thresholds(*c, thresholds_out, max_slice_out);
+}
+
+tr_status tr_get_depth_slice(tr_context* ctx, const tr_light_cluster_coefficients* c, const void* frag_depth, uint32_t count,
+                             void* slices_out, void* stream_) {
+    if (!ctx || !c || !frag_depth || !slices_out || ((uintptr_t)frag_depth & 3u) || ((uintptr_t)slices_out & 3u))
+        return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    tr_uniforms u;
+    std::memset(&u, 0, sizeof(u));
+    u.light_clustering_coefficients = *c;
+    const tr_status st = ensure_slice_thresholds(ctx, &u, stream);
+    if (st != TR_OK) return st;
+    slice_params sp;
+    sp.scale = c->scale;
+    sp.fpn = c->z_far + c->z_near;
+    sp.fmn = c->z_far - c->z_near;
+    sp.k = (float)(std::log2(2.0 * (double)c->z_near * (double)c->z_far) * (double)c->scale + (double)c->bias);
+    sp.max = ctx->slice_max;
+    sp.thr = ctx->d_slice_thr;
+    hipLaunchKernelGGL(depth_slice_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, (const float*)frag_depth, count,
+                       sp, (uint32_t*)slices_out);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
 tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u, const tr_push_constants* pc,
                           void* hdr_out, tr_format format, void* opaque_mip0_out, tr_rect rect, void* stream_) {
     if (!ctx || !g || !u || !pc || !hdr_out || !g->pos_depth || !g->nrm_scale || !g->material_id)
@@ -974,7 +1074,9 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     tr_frame_params fp;
-    tr_status st = fill_frame_params(ctx, g, u, pc, rect, &fp);
+    tr_status st = ensure_slice_thresholds(ctx, u, stream);
+    if (st != TR_OK) return st;
+    st = fill_frame_params(ctx, g, u, pc, rect, &fp);
     if (st != TR_OK) return st;
     st = ensure_digested(ctx, stream);
     if (st != TR_OK) return st;
@@ -1052,10 +1154,9 @@ tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* p, void* stream_) 
             tp.height[k] = level_dim(p->height, k);
             if (k >= l) lds_texels += (size_t)tp.width[k] * tp.height[k];
         }
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)mip_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
+        if (!ctx->mip_tail_attr_set) {   // function attributes are per device: kept in the context, not process-wide
+            TR_HIP(ctx, hipFuncSetAttribute((const void*)mip_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->mip_tail_attr_set = true;
         }
         hipLaunchKernelGGL(mip_tail_kernel, dim3(1), dim3(1024), lds_texels * sizeof(uint2), stream, base, tp);
     }
@@ -1074,7 +1175,9 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     tr_frame_params fp;
-    tr_status st = fill_frame_params(ctx, g, u, pc, rect, &fp);
+    tr_status st = ensure_slice_thresholds(ctx, u, stream);
+    if (st != TR_OK) return st;
+    st = fill_frame_params(ctx, g, u, pc, rect, &fp);
     if (st != TR_OK) return st;
     st = ensure_digested(ctx, stream);
     if (st != TR_OK) return st;

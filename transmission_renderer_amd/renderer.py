@@ -235,6 +235,15 @@ class TransmissionRenderer:
         self._check(self.lib.tr_upload_ggx_lut(self._ctx, rgba8.ctypes.data_as(C.c_void_p), w, h, self._stream()),
                     "tr_upload_ggx_lut")
 
+    def get_depth_slice(self, coefficients: wire.LightClusterCoefficients, frag_depth: torch.Tensor) -> torch.Tensor:
+        """`LightClusterCoefficients::get_depth_slice` (shared-structs/src/lib.rs:54-63) over a float32 device array;
+        bit-exact with the reference's fp32 arithmetic (the passes' own cluster-lookup function)."""
+        assert frag_depth.dtype == torch.float32 and frag_depth.is_contiguous() and frag_depth.device == self.device
+        out = torch.empty(frag_depth.shape, dtype=torch.int32, device=self.device)
+        self._check(self.lib.tr_get_depth_slice(self._ctx, C.byref(coefficients), frag_depth.data_ptr(), frag_depth.numel(),
+                                                out.data_ptr(), self._stream()), "tr_get_depth_slice")
+        return out
+
     # ---- clustered-light build (SURVEY.md 8f row f2)
     def write_cluster_data(self, uniforms: wire.Uniforms, inverse_perspective: np.ndarray, screen_dimensions) -> torch.Tensor:
         """`write_cluster_data` (shader/src/lib.rs:519-594): (num_clusters, 8) float32 view-space AABBs."""
