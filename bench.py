@@ -4,13 +4,21 @@
 metric   shaded Mpixels/s (+ p50 frame ms) of the 4K transmissive pass: `fragment_transmission`
          (shader/src/lib.rs:37-162) over a fully covered synthetic TGB-v1 G-buffer, DragonAttenuation's
          light rig (sun + 1 punctual light), RGBA16F target, inputs resident in HBM.
-step     one transmissive pass over one frame (tr_shade_transmission on the current stream).
-N > 1    one process per GPU (torch.distributed / RCCL for rendezvous + barriers only): screen row bands,
-         weak scaling — every rank shades 3840x2160 = 8.29 Mpx of a frame that grows with N
-         (N=2 3840x4320, N=4 7680x4320 (the 8K of BASELINE config 5), N=8 7680x8640); replicated read-only
-         inputs (tables, LUT, opaque pyramid), no data-path collective inside the timed region.  The frame
-         composite (RCCL all-gather of the bands, sharded.allgather_frame) is timed separately and reported
-         as `composite_allgather_ms`; it is xGMI-bound and not part of `value`.
+step     one transmissive pass over one 3840x2160 frame (tr_shade_transmission) — at N > 1 followed by the
+         composite (tr_allgather_frame: RCCL all-gather of the row bands).
+
+python bench.py --gpus N   starts by itself: with WORLD_SIZE unset and N > 1 it spawns N child processes (one per
+         GPU, before anything touches a GPU) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 set; under
+         torch.distributed.run it uses the environment it is given.
+
+N > 1    BASELINE config 4 / north_star: ONE 3840x2160 frame cut into N row bands (tr_band_rows: 4-row aligned), one
+         process per GPU, replicated read-only inputs (tables, LUT, opaque pyramid), no collective while shading:
+         STRONG scaling (`--scaling strong`, the default).  The timed step is band kernel + composite, pipelined the
+         way a renderer would run it (`--composite overlap`: frame k's all-gather runs on a second stream under frame
+         k+1's shading, two frame buffers); `value` = frame pixels x K / wall time of the K steps, max over ranks.
+         Reported next to it: the kernel-only rate (no composite), the composite alone, rank 0's whole-frame
+         single-GPU time measured in the same run and both speed-ups over it.
+         `--scaling weak` keeps round 1's mode (every rank shades 8.29 Mpx of a frame that grows with N).
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,6 +27,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,14 +36,80 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 ALGORITHMIC_BYTES_PER_PIXEL = 60  # 44 B G-buffer read + 8 B opaque-colour read + 8 B RGBA16F write
 READ_BYTES_PER_PIXEL = 52
+# what the variant that runs here has to move: the untextured kernel does not read the 8 B/px uv plane
+NEEDED_BYTES_PER_PIXEL = 52       # 16 + 16 + 4 (planes) + 8 (opaque colour) + 8 (write)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--lights", type=int, default=1, help="punctual lights besides the sun (DragonAttenuation: 1)")
+    ap.add_argument("--roughness-override", type=float, default=None, help="BASELINE config 3 uses 0.25")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--composite", choices=("overlap", "serial", "none"), default="overlap",
+                    help="N > 1: how the composite all-gather enters the timed step")
+    ap.add_argument("--all-transmissive", action="store_true",
+                    help="every synthetic material gets transmission_factor 1 (DragonAttenuation's is 1): no tile skips "
+                         "the refraction taps; the default run reports this variant beside the headline number")
+    ap.add_argument("--no-variants", action="store_true", help="N = 1: skip the extra reported variants")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-gpu-reference", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--launch-timeout-s", type=float, default=1500.0)
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="no GPU: the ranks rendezvous over gloo, cut the frame into bands and composite a host frame "
+                         "(covers the launcher and the band arithmetic; tests/test_bench_launch.py)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(args) -> int:
+    """N fresh processes, one per GPU.  This parent never touches a GPU (it does not even import torch) and never
+    replaces itself: it waits for the children and returns the worst exit code."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this pool)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    deadline = time.time() + args.launch_timeout_s
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed or time.time() > deadline:
+            for i, p in enumerate(procs):      # the exact PIDs started above
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+            if not failed:
+                sys.stderr.write(f"bench.py: ranks did not finish within {args.launch_timeout_s:.0f} s\n")
+                return 124
+            break
+        time.sleep(0.05)
+    return max(abs(c) for c in codes)
+
+
+# ------------------------------------------------------------------------------------------------ helpers
 def frame_size_for(n_gpus: int, base_w: int, base_h: int):
     """Weak scaling: per-rank pixel count fixed; the frame doubles in height, then width, then height."""
     w, h, k = base_w, base_h, n_gpus
@@ -48,8 +124,9 @@ def frame_size_for(n_gpus: int, base_w: int, base_h: int):
     return w, h
 
 
-def make_mip0_torch(width: int, height: int, device) -> torch.Tensor:
+def make_mip0_torch(width: int, height: int, device):
     """Same procedural opaque frame as synthetic.make_opaque_mip0, evaluated on the device (bench input only)."""
+    import torch
     xs = (torch.arange(width, dtype=torch.float32, device=device) + 0.5)[None, :]
     ys = (torch.arange(height, dtype=torch.float32, device=device) + 0.5)[:, None]
     sq = max(width // 120, 2)
@@ -70,8 +147,8 @@ def make_mip0_torch(width: int, height: int, device) -> torch.Tensor:
 
 def cpu_baseline(scene, lut, width, height, budget_s=12.0):
     """The oracle (scalar fp32 C restatement of the reference, row-band threads) timed on this host's cores on a
-    bounded sample of the same workload: whole rows from the middle of the frame, sized from a short probe so
-    the timed run costs about `budget_s` seconds."""
+    bounded sample of the same workload: whole frames, as many as fit the budget."""
+    import numpy as np
     from oracle import oracle
     from transmission_renderer_amd import synthetic
     cores = os.cpu_count() or 1
@@ -99,83 +176,141 @@ def cpu_baseline(scene, lut, width, height, budget_s=12.0):
                       f"frame ({rows_total * width / 1e6:.1f} Mpx) in {dt:.1f} s, {cores} threads"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--lights", type=int, default=1, help="punctual lights besides the sun (DragonAttenuation: 1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
-    args = ap.parse_args()
+def selftest_cpu(args, world, rank):
+    """Launcher + band arithmetic + composite order without a GPU (gloo, host tensors)."""
+    import torch
+    import torch.distributed as dist
+    from transmission_renderer_amd import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h = 96, args.height if args.height != 2160 else 54
+    rows, y0, y1 = sharded.band_rows(h, world, rank)
+    frame = torch.zeros((rows * world, w, 4), dtype=torch.float16)
+    frame[y0:y1] = float(rank + 1)
+    comp = sharded.Compositor(world, rank)
+    comp.allgather_rows(frame)
+    want = torch.zeros_like(frame)
+    for r in range(world):
+        _, a, b = sharded.band_rows(h, world, r)
+        want[a:b] = float(r + 1)
+    ok = bool(torch.equal(frame[:h], want[:h]))
+    if world > 1:
+        flag = torch.tensor([int(ok)])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": "ok" if ok else "FAILED", "n_ranks": world, "frame": [w, h], "rows_per_rank": rows,
+                          "bands": [list(sharded.band_rows(h, world, r)[1:]) for r in range(world)],
+                          "composite": comp.backend}), flush=True)
+    return 0 if ok else 1
 
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-        args.gpus = world
+    if args.selftest_cpu:
+        return selftest_cpu(args, world, rank)
+    import numpy as np
+    import torch
     distributed = world > 1
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from transmission_renderer_amd import synthetic, wire
+    from transmission_renderer_amd import sharded, synthetic
     from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer, load_ggx_lut
 
-    fw, fh = frame_size_for(world, args.width, args.height)
-    band_rows = fh // world
-    y0, y1 = rank * band_rows, (rank + 1) * band_rows
+    K, W = args.steps, args.warmup
+    strong = args.scaling == "strong"
+    fw, fh = (args.width, args.height) if strong else frame_size_for(world, args.width, args.height)
+    rows_per_rank, y0, y1 = sharded.band_rows(fh, world, rank)
+    padded = rows_per_rank * world
+    composite = args.composite if distributed else "none"
 
     r = TransmissionRenderer(local_rank)
     dev = r.device
-    scene = synthetic.make_scene(fw, fh, num_point_lights=args.lights, with_gbuffer=False)
+    scene = synthetic.make_scene(fw, fh, num_point_lights=args.lights, with_gbuffer=False,
+                                 roughness_override=args.roughness_override)
+    if args.all_transmissive:
+        for m in scene["materials"]:
+            m.transmission_factor = 1.0
     lut = load_ggx_lut()
     r.upload_materials(scene["materials"])
     r.upload_lights(scene["lights"])
     r.upload_ggx_lut(lut)
     r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(dev),
                          torch.from_numpy(scene["light_indices"].view(np.int32)).to(dev))
-    band = synthetic.make_gbuffer(fw, fh, rows=(y0, y1))          # this rank's screen tile only
-    g = GBufferPlanes.from_numpy(band, dev)
-    pyr = OpaquePyramid(fw, fh, dev)                              # replicated read-only input
+    g = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh, rows=(y0, y1)), dev)   # this rank's screen tile only
+    pyr = OpaquePyramid(fw, fh, dev)                                                  # replicated read-only input
     pyr.level(0).copy_(make_mip0_torch(fw, fh, dev))
     r.generate_mips(pyr)
-    hdr = torch.zeros((fh, fw, 4), dtype=torch.float16, device=dev)
+    frames = [torch.zeros((padded, fw, 4), dtype=torch.float16, device=dev) for _ in range(2 if composite == "overlap" else 1)]
     uniforms, push = scene["uniforms"], scene["push"]
     rect = (0, y0, fw, y1)
+    comp = sharded.Compositor(world, rank, renderer=r) if distributed else None
     torch.cuda.synchronize()
 
-    def step():
-        r.shade_transmission(g, uniforms, push, pyr, hdr, rect)
+    compute = torch.cuda.current_stream()
+    comm = torch.cuda.Stream() if composite == "overlap" else None
+    shaded = [torch.cuda.Event() for _ in frames]
+    gathered = [None for _ in frames]
+    launches = {"count": 0}
 
-    # Untimed warm-up: W steps — and before them, as many as it takes to have kept the GPU busy for 50 ms: its clocks
-    # ramp over the first ~10 ms of load (measured: the first ~70 back-to-back 4K launches run 10-15 % slow), and the
-    # metric is steady-state throughput.
+    def shade(buf):
+        r.shade_transmission(g, uniforms, push, pyr, buf, rect)
+        launches["count"] += 1
+
+    def step(k):
+        """One step of the metric: this rank's band of the frame (+ the composite, N > 1)."""
+        i = k % len(frames)
+        buf = frames[i]
+        if composite == "overlap":
+            if gathered[i] is not None:
+                compute.wait_event(gathered[i])        # the buffer's previous composite has left it
+            shade(buf)
+            shaded[i].record(compute)
+            with torch.cuda.stream(comm):
+                comm.wait_event(shaded[i])
+                comp.allgather_rows(buf)
+                ev = torch.cuda.Event()
+                ev.record(comm)
+                gathered[i] = ev
+        else:
+            shade(buf)
+            if composite == "serial":
+                comp.allgather_rows(buf)
+
+    # Untimed warm-up: W steps — and before them, as many band launches as it takes to have kept the GPU busy for
+    # 50 ms: its clocks ramp over the first ~10 ms of load (the first ~70 back-to-back 4K launches run 10-15 % slow),
+    # and the metric is steady-state throughput.  The count is reported (`clock_ramp_launches`).
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.05:
         for _ in range(16):
-            step()
+            shade(frames[0])
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
+    clock_ramp_launches = launches["count"]
+    for k in range(W):
+        step(k)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    # Timed region: exactly K launches back to back, bracketed by the barrier + synchronize pairs (wall clock -> value)
-    # and by ONE pair of HIP events on the launch stream (-> the kernel's average launch duration for the roofline).
-    # No per-launch events here: each record is a barrier packet between two launches and costs them ~5 us apiece.
+    # Timed region: exactly K steps back to back, bracketed by the barrier + synchronize pairs (wall clock -> value).
+    # At N = 1 ONE pair of HIP events on the launch stream brackets the K launches (-> the kernel's average launch
+    # duration for the roofline); no per-launch events: each record is a barrier packet that costs ~5 us.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for i in range(args.steps):
-        step()
+    for k in range(K):
+        step(W + k)
     ev1.record()
     torch.cuda.synchronize()
     if distributed:
@@ -186,78 +321,166 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    avg_launch_ms = ev0.elapsed_time(ev1) / args.steps
-    # Second pass, outside the timed region: per-launch events for the frame-time percentiles of the metric.
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    for i in range(args.steps):
-        starts[i].record()
-        step()
-        ends[i].record()
-    torch.cuda.synchronize()
-    kernel_ms = np.array([s.elapsed_time(e) for s, e in zip(starts, ends)], dtype=np.float64)
+    region_ms = ev0.elapsed_time(ev1) / K
 
+    # ---- outside the timed region -------------------------------------------------------------------------------
+    def timed_launches(n, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    # the band kernel alone, back to back (at N = 1 the timed region already is exactly this)
+    kernel_ms = region_ms if not distributed else timed_launches(K, lambda: shade(frames[0]))
+    kernel_ms_max = kernel_ms
     composite_ms = None
     if distributed:
-        from transmission_renderer_amd import sharded
-        for _ in range(3):
-            sharded.allgather_frame(hdr, world)
-        torch.cuda.synchronize()
+        t = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_ms_max = float(t.item())
         dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            sharded.allgather_frame(hdr, world)
-        e1.record()
+        composite_ms = timed_launches(max(10, K // 4), lambda: comp.allgather_rows(frames[0]))
+        t = torch.tensor([composite_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        composite_ms = float(t.item())
+    # per-launch events for the frame-time percentiles of the metric
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    for i in range(K):
+        starts[i].record()
+        shade(frames[0])
+        ends[i].record()
+    torch.cuda.synchronize()
+    per_launch_ms = np.array([s.elapsed_time(e) for s, e in zip(starts, ends)], dtype=np.float64)
+    # a launch + synchronise per step (what a host loop that waits for every frame sees: the GPU never reaches its
+    # steady-state clocks in this pattern)
+    sync_ms = []
+    for _ in range(50):
+        t1 = time.perf_counter()
+        shade(frames[0])
         torch.cuda.synchronize()
-        composite_ms = e0.elapsed_time(e1) / 10.0
+        sync_ms.append((time.perf_counter() - t1) * 1e3)
+    launch_log = [("clock_ramp", clock_ramp_launches), ("warmup", W), ("timed", K)]
+    if distributed:
+        launch_log.append(("kernel_only", K))
+    launch_log += [("percentiles", K), ("launch_sync", 50)]
 
-    pixels_rank = band_rows * fw
-    pixels_total = pixels_rank * world
-    ms_per_step = elapsed / args.steps * 1e3
-    value = pixels_total * args.steps / elapsed / 1e6
-    avg_kernel_s = avg_launch_ms * 1e-3
-    achieved = pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL / avg_kernel_s / 1e9
+    pixels_rank = (y1 - y0) * fw
+    pixels_frame = fw * fh                     # strong: all ranks together shade one frame per step
+    pixels_step = pixels_frame if strong else pixels_rank * world
+    value = pixels_step * K / elapsed / 1e6
+    ms_per_step = elapsed / K * 1e3
+
+    single_gpu_ms = None
+    if distributed and strong and not args.no_single_gpu_reference:
+        if rank == 0:                          # the same frame on ONE GPU, same run: the denominator of the speed-ups
+            gw = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh), dev)
+            whole = torch.zeros((fh, fw, 4), dtype=torch.float16, device=dev)
+            fn = lambda: r.shade_transmission(gw, uniforms, push, pyr, whole)   # noqa: E731
+            timed_launches(64, fn)
+            single_gpu_ms = timed_launches(K, fn)
+            del gw, whole
+        dist.barrier()
+
+    variants = {}
+    if not distributed and not args.no_variants and not args.all_transmissive:
+        # DragonAttenuation's material has transmission_factor 1: no tile skips the refraction taps and the btdf lobes
+        for m in scene["materials"]:
+            m.transmission_factor = 1.0
+        r.upload_materials(scene["materials"])
+        timed_launches(200, lambda: shade(frames[0]))
+        ms = timed_launches(K, lambda: shade(frames[0]))
+        launch_log += [("all_transmissive_ramp", 200), ("all_transmissive", K)]
+        variants["all_transmissive"] = {
+            "avg_kernel_ms": round(ms, 4), "Mpixels_per_s": round(pixels_rank / ms / 1e3, 1),
+            "frac": round(pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "every synthetic material with transmission_factor = 1 (in the headline scene 4 of 16 have 0 and skip "
+                    "the refraction taps, LUT and btdf lobes)"}
 
     if rank == 0:
+        kernel_s = kernel_ms * 1e-3
+        achieved = pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL / kernel_s / 1e9
         out = {
             "metric": "shaded Mpixels/sec, 4K transmissive pass (fragment_transmission over a synthetic TGB-v1 G-buffer)",
-            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "p50_frame_ms": round(float(np.percentile(kernel_ms, 50)), 4),
-            "p10_frame_ms": round(float(np.percentile(kernel_ms, 10)), 4),
-            "p90_frame_ms": round(float(np.percentile(kernel_ms, 90)), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"transmissive pass, {args.width}x{args.height} px per GPU (frame {fw}x{fh}), "
-                                   f"TGB-v1 synthetic G-buffer fully covered, 16 materials, sun + {args.lights} "
-                                   f"punctual light(s) (DragonAttenuation rig), RGBA16F target, {pyr.levels}-level "
-                                   f"opaque pyramid, ggx_lut.png",
-                       "pixels_per_gpu": pixels_rank, "sharding": f"{world} row band(s) of {band_rows} rows"},
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(ms_per_step, 4), "p50_frame_ms": round(float(np.percentile(per_launch_ms, 50)), 4),
+            "p10_frame_ms": round(float(np.percentile(per_launch_ms, 10)), 4),
+            "p90_frame_ms": round(float(np.percentile(per_launch_ms, 90)), 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"transmissive pass, frame {fw}x{fh}"
+                                   + (f" in {world} row bands of {rows_per_rank} rows" if distributed else "")
+                                   + f", TGB-v1 synthetic G-buffer fully covered, 16 materials"
+                                   + (" (all transmission_factor 1)" if args.all_transmissive else "")
+                                   + (f", roughness override {args.roughness_override}" if args.roughness_override is not None else "")
+                                   + f", sun + {args.lights} punctual light(s) (DragonAttenuation rig), RGBA16F target, "
+                                     f"{pyr.levels}-level opaque pyramid, ggx_lut.png",
+                       "pixels_per_step": pixels_step, "pixels_per_gpu": pixels_rank,
+                       "sharding": f"{world} row band(s) of {rows_per_rank} rows (tr_band_rows)",
+                       "composite": ("none (one GPU holds the frame)" if not distributed else
+                                     f"{composite}: {comp.backend}")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "tr::shade_kernel<true, uint2>", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                         "kernel": "tr::shade_kernel<true, uint2, false>", "avg_kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL,
-                         "read_only_frac": round(pixels_rank * READ_BYTES_PER_PIXEL / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4)},
+                         "read_only_frac": round(pixels_rank * READ_BYTES_PER_PIXEL / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "bytes_needed_per_pixel": NEEDED_BYTES_PER_PIXEL,
+                         "frac_bytes_needed": round(pixels_rank * NEEDED_BYTES_PER_PIXEL / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "60 B/px is SURVEY 8d's figure; this untextured variant never loads the 8 B/px uv plane "
+                                 "(bytes_needed 52 B/px), and tiles of materials with transmission_factor 0 skip the 8 B/px "
+                                 "opaque-colour read (see variants.all_transmissive)"},
+            "clock_ramp_launches": clock_ramp_launches,
+            "launch_sync_p50_ms": round(float(np.percentile(sync_ms, 50)), 4),
+            "launch_log": launch_log,
         }
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and world == 1 and not args.all_transmissive and args.roughness_override is None:
             try:
                 with open(traffic_file) as f:
                     tr_ = json.load(f)
-                if tr_.get("width") == fw and tr_.get("height") == fh and tr_.get("lights") == args.lights and world == 1:
+                if tr_.get("width") == fw and tr_.get("height") == fh and tr_.get("lights") == args.lights:
                     out["roofline"]["traffic"] = tr_["hbm_bytes_per_launch"]
+                    out["roofline"]["achieved_from_traffic"] = round(tr_["hbm_bytes_per_launch"] / kernel_s / 1e9, 1)
+                    out["roofline"]["frac_from_traffic"] = round(tr_["hbm_bytes_per_launch"] / kernel_s / 1e9 / HBM_PEAK_GBS, 4)
                     out["roofline"]["traffic_source"] = tr_.get("source")
             except Exception:
                 pass
-        if composite_ms is not None:
+        if distributed:
+            out["kernel_only"] = {"ms_per_step": round(kernel_ms_max, 4),
+                                  "Mpixels_per_s": round(pixels_step / kernel_ms_max / 1e3, 1),
+                                  "note": "the band kernels alone, max over ranks, no composite"}
             out["composite_allgather_ms"] = round(composite_ms, 4)
+            if single_gpu_ms is not None:
+                out["single_gpu_ms"] = round(single_gpu_ms, 4)
+                out["speedup_vs_1gpu"] = {"kernel_only": round(single_gpu_ms / kernel_ms_max, 3),
+                                          "with_composite": round(single_gpu_ms / ms_per_step, 3)}
+        if variants:
+            out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
+            if variants:   # the CPU baseline shades the headline scene
+                scene = synthetic.make_scene(fw, fh, num_point_lights=args.lights, with_gbuffer=False,
+                                             roughness_override=args.roughness_override)
             out["cpu_baseline"] = cpu_baseline(scene, lut, fw, fh, args.cpu_budget_s)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
+        comp.close()
         dist.destroy_process_group()
     r.close()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_children(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        args.gpus = world
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -39,7 +39,8 @@ enum {
     TR_ERR_HIP = 3,              /* a HIP runtime call failed; see tr_last_hip_error */
     TR_ERR_TABLES_MISSING = 4,   /* a pass was launched before its tables were set  */
     TR_ERR_OUT_OF_MEMORY = 5,
-    TR_ERR_UNSUPPORTED = 6
+    TR_ERR_UNSUPPORTED = 6,
+    TR_ERR_COMM = 7              /* RCCL could not be loaded or a collective call failed; see tr_comm_last_error */
 };
 
 /* ------------------------------------------------- wire structs (reference) */
@@ -533,6 +534,45 @@ tr_status tr_get_depth_slice(tr_context* ctx, const tr_light_cluster_coefficient
  * thresholds_out must hold TR_MAX_DEPTH_SLICES + 2 floats. */
 tr_status tr_depth_slice_thresholds(const tr_light_cluster_coefficients* coefficients, float* thresholds_out,
                                     uint32_t* max_slice_out);
+
+/* ------------------------------------------------- multi-GPU: row bands + composite */
+/*
+ * New surface (the reference is one VkQueue, src/main.rs:243): SURVEY.md section 8e.  Pixels of both passes are
+ * independent given replicated read-only inputs, so a frame is cut into contiguous ROW BANDS, one per rank (one
+ * process per GPU).  No collective while shading; the exchanges are in-place all-gathers of whole bands over
+ * RCCL / xGMI: the final composite (every rank ends with the whole frame) and, for the full opaque -> mips ->
+ * transmissive pipeline, level 0 of the opaque pyramid between the two passes (the transmissive pass samples the
+ * whole pyramid).
+ *
+ * RCCL is loaded at run time (dlopen "librccl.so.1") the first time one of these is called: the library has no
+ * link-time dependency on it, and a process that already holds an RCCL (a host framework's) shares that copy.
+ */
+typedef struct tr_comm tr_comm;   /* opaque: one RCCL communicator of this rank */
+#define TR_COMM_ID_BYTES 128u     /* = NCCL_UNIQUE_ID_BYTES */
+
+/* Host only, no device needed: the band of `rank`.  Bands are `*rows_per_rank` = ceil(height / nranks) rounded up to
+ * a multiple of 4 rows (the 16x4 wave tile; also keeps 2x2 quads whole), rows [*y0, *y1) clipped to the frame — the
+ * last bands of a frame whose height does not divide may be short or empty (y0 == y1).  A composite buffer must
+ * hold nranks * rows_per_rank rows (>= height): an all-gather moves equal counts. */
+tr_status tr_band_rows(uint32_t height, uint32_t nranks, uint32_t rank, uint32_t* rows_per_rank, uint32_t* y0,
+                       uint32_t* y1);
+/* One rank (conventionally 0) creates the id; the application hands its 128 bytes to the other ranks over any host
+ * channel; then EVERY rank calls tr_comm_create (collective, blocks until all nranks arrived) with its context's
+ * device current. */
+tr_status tr_comm_unique_id(uint8_t id_out[TR_COMM_ID_BYTES]);
+tr_status tr_comm_create(tr_context* ctx, const uint8_t id[TR_COMM_ID_BYTES], uint32_t nranks, uint32_t rank,
+                         tr_comm** out_comm);
+/* Wraps a communicator the host already has (ncclComm_t, borrowed: tr_comm_destroy leaves it alone). */
+tr_status tr_comm_from_nccl(void* nccl_comm, uint32_t nranks, uint32_t rank, tr_comm** out_comm);
+tr_status tr_comm_destroy(tr_comm* comm);
+/* ncclResult_t of the last failing RCCL call on this communicator (0 if none; -1: RCCL could not be loaded). */
+int32_t   tr_comm_last_error(const tr_comm* comm);
+/* The composite (and the mid-frame level-0 exchange): `frame_dev` holds nranks * rows_per_rank rows of `width`
+ * pixels of `format`; this rank has written band `rank` (rows rank * rows_per_rank ...); on return (stream order)
+ * every band is everywhere.  In place: ncclAllGather(sendbuff = recvbuff + rank * band_bytes).  Asynchronous on
+ * `stream`; call it on every rank. */
+tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame_dev, uint32_t width, uint32_t rows_per_rank,
+                             tr_format format, void* stream);
 
 /* ------------------------------------------------------------------ tonemap */
 

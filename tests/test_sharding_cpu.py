@@ -15,10 +15,21 @@ from transmission_renderer_amd import sharded, synthetic, wire
 
 
 def test_band_rows():
-    assert [sharded.band_rows(2160, 8, r) for r in (0, 7)] == [(0, 270), (1890, 2160)]
+    # (rows_per_rank, y0, y1): ceil(H / N) rounded up to the 4-row wave tile, clipped to the frame
+    assert [sharded.band_rows(2160, 8, r) for r in (0, 6, 7)] == [(272, 0, 272), (272, 1632, 1904), (272, 1904, 2160)]
+    assert sharded.band_rows(2160, 4, 1) == (540, 540, 1080) and sharded.band_rows(2160, 1, 0) == (2160, 0, 2160)
     assert sharded.band_rect(3840, 2160, 4, 1) == (0, 540, 3840, 1080)
+    assert sharded.padded_rows(2160, 8) == 2176 and sharded.padded_rows(2160, 2) == 2160
+    for h in (1, 3, 42, 130, 1080, 2160, 4320):
+        for n in (1, 2, 3, 4, 8):
+            bands = [sharded.band_rows(h, n, r) for r in range(n)]
+            rows = bands[0][0]
+            assert rows % 4 == 0 and rows * n >= h and all(b[0] == rows for b in bands)
+            assert bands[0][1] == 0 and bands[-1][2] == h                       # the bands tile the frame exactly
+            assert all(bands[r][2] == bands[r + 1][1] for r in range(n - 1))
+            assert all(b[1] == min(r * rows, h) for r, b in enumerate(bands))  # band r starts at its gather slot
     with pytest.raises(ValueError):
-        sharded.band_rows(2161, 8, 0)
+        sharded.band_rows(100, 4, 4)
 
 
 def test_synthetic_scene_is_deterministic_and_band_sliceable():
@@ -45,6 +56,48 @@ def _free_port():
     return p
 
 
+class _OraclePyramid:
+    """The pyramid as record_sharded sees it (level0_padded) over the oracle's packed texel array."""
+
+    def __init__(self, w, h, rows):
+        from oracle import oracle
+        self.w, self.h = w, h
+        self.level0 = torch.zeros((rows, w, 4), dtype=torch.float16)
+        self.tex = oracle.new_pyramid(w, h, np.zeros((h, w, 4), np.float16))
+
+    def level0_padded(self):
+        return self.level0
+
+
+class _OracleRenderer:
+    """Stands in for TransmissionRenderer in sharded.record_sharded: the same three calls, answered by the CPU
+    oracle on host tensors, so the REAL recorder (band arithmetic, exchange order, padded buffers) runs in the test."""
+
+    def __init__(self, binding):
+        self.binding = binding
+        self.calls = []
+
+    def shade_opaque(self, g, uniforms, push, hdr, pyramid, rect):
+        from oracle import oracle
+        self.calls.append(("opaque", rect))
+        hdr16, _, mip0 = oracle.shade_opaque(self.binding, g, rect=rect)
+        y0, y1 = rect[1], rect[3]
+        hdr[y0:y1] = torch.from_numpy(hdr16[y0:y1])
+        pyramid.level0[y0:y1] = torch.from_numpy(mip0[y0:y1])
+
+    def generate_mips(self, pyramid):
+        from oracle import oracle
+        self.calls.append(("mips", None))
+        pyramid.tex[:pyramid.w * pyramid.h] = pyramid.level0[:pyramid.h].numpy().reshape(-1, 4)
+        oracle.generate_mips(pyramid.w, pyramid.h, pyramid.tex)
+
+    def shade_transmission(self, g, uniforms, push, pyramid, hdr, rect):
+        from oracle import oracle
+        self.calls.append(("transmission", rect))
+        frame = hdr[:pyramid.h].numpy()                                   # shares memory: shaded in place (LOAD)
+        oracle.shade_transmission(self.binding, g, pyramid.tex, hdr_f16=frame, rect=rect)
+
+
 def _worker(rank, world, port, w, h, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -56,35 +109,37 @@ def _worker(rank, world, port, w, h, out_dir):
         lut = read_png_rgba8(os.path.join(root, "transmission_renderer_amd", "assets", "ggx_lut.png"))
         scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False)
         binding = oracle.SceneBinding(scene, lut)
-        y0, y1 = sharded.band_rows(h, world, rank)
+        rows, y0, y1 = sharded.band_rows(h, world, rank)
         band = synthetic.make_gbuffer(w, h, rows=(y0, y1))            # this rank's tile only
-
-        # "main opaque" on the band; both attachments whole-frame, only the band written
-        hdr16, _, mip0 = oracle.shade_opaque(binding, band)
-        assert (mip0[:y0] == 0).all() and (mip0[y1:] == 0).all()
-        mip0_t = torch.from_numpy(mip0)
-        sharded.allgather_mip0(mip0_t, world)                          # exchange 1
-        tex = oracle.new_pyramid(w, h, mip0_t.numpy())
-        oracle.generate_mips(w, h, tex)                                # replicated
-        oracle.shade_transmission(binding, band, tex, hdr_f16=hdr16)   # band, LOAD semantics
-        frame = torch.from_numpy(hdr16)
-        sharded.allgather_frame(frame, world)                          # exchange 2 (composite)
-        np.save(os.path.join(out_dir, f"frame_{rank}.npy"), frame.numpy())
+        hdr = torch.zeros((rows * world, w, 4), dtype=torch.float16)  # padded: equal bands for the gathers
+        pyr = _OraclePyramid(w, h, rows * world)
+        fake = _OracleRenderer(binding)
+        comp = sharded.Compositor(world, rank)                        # torch.distributed (gloo) on host tensors
+        assert comp.backend == "torch.distributed:gloo"
+        sharded.record_sharded(fake, band, band, scene["uniforms"], scene["push"], hdr, pyr, comp)
+        assert [c[0] for c in fake.calls] == ["opaque", "mips", "transmission"]
+        assert fake.calls[0][1] == (0, y0, w, y1) == fake.calls[2][1]
+        np.save(os.path.join(out_dir, f"frame_{rank}.npy"), hdr[:h].numpy())
+        np.save(os.path.join(out_dir, f"mip0_{rank}.npy"), pyr.level0[:h].numpy())
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_pipeline_matches_single_rank(tmp_path, ggx_lut):
+@pytest.mark.parametrize("w,h,world", [(64, 40, 2), (48, 42, 2), (40, 30, 3)])
+def test_record_sharded_over_gloo_matches_single_rank(tmp_path, ggx_lut, w, h, world):
+    """sharded.record_sharded ITSELF on `world` gloo ranks (oracle-backed renderer): every rank ends with the
+    single-rank frame, bit for bit; heights that do not divide into 4-row-aligned bands use the padded buffers."""
     from oracle import oracle
-    w, h, world = 64, 40, 2
     mp.spawn(_worker, args=(world, _free_port(), w, h, str(tmp_path)), nprocs=world, join=True)
     frames = [np.load(tmp_path / f"frame_{r}.npy") for r in range(world)]
-    np.testing.assert_array_equal(frames[0].view(np.uint16), frames[1].view(np.uint16))  # every rank has the frame
+    for f in frames[1:]:
+        np.testing.assert_array_equal(frames[0].view(np.uint16), f.view(np.uint16))      # every rank has the frame
 
     scene = synthetic.make_scene(w, h, num_point_lights=2)
     binding = oracle.SceneBinding(scene, ggx_lut)
     hdr16, _, mip0 = oracle.shade_opaque(binding, scene["gbuffer"])
+    np.testing.assert_array_equal(np.load(tmp_path / "mip0_0.npy").view(np.uint16), mip0.view(np.uint16))
     tex = oracle.new_pyramid(w, h, mip0)
     oracle.generate_mips(w, h, tex)
     oracle.shade_transmission(binding, scene["gbuffer"], tex, hdr_f16=hdr16)

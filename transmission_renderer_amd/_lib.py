@@ -23,6 +23,8 @@ SYMBOLS = (
     "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap", "tr_record_frame",
     "tr_basic_brdf", "tr_transmission_btdf", "tr_ibl_volume_refraction", "tr_light_direction_and_attenuation", "tr_d_ggx",
     "tr_v_smith_ggx_correlated", "tr_fresnel_schlick", "tr_compute_f0", "tr_get_depth_slice", "tr_depth_slice_thresholds",
+    "tr_band_rows", "tr_comm_unique_id", "tr_comm_create", "tr_comm_from_nccl", "tr_comm_destroy", "tr_comm_last_error",
+    "tr_allgather_frame",
 )
 
 _lib = None
@@ -121,6 +123,20 @@ def load() -> C.CDLL:
     lib.tr_get_depth_slice.argtypes = [vp, C.POINTER(wire.LightClusterCoefficients), vp, u32, vp, vp]
     lib.tr_depth_slice_thresholds.restype = i32
     lib.tr_depth_slice_thresholds.argtypes = [C.POINTER(wire.LightClusterCoefficients), C.POINTER(C.c_float), C.POINTER(u32)]
+    lib.tr_band_rows.restype = i32
+    lib.tr_band_rows.argtypes = [u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    lib.tr_comm_unique_id.restype = i32
+    lib.tr_comm_unique_id.argtypes = [C.POINTER(C.c_uint8 * 128)]
+    lib.tr_comm_create.restype = i32
+    lib.tr_comm_create.argtypes = [vp, C.POINTER(C.c_uint8 * 128), u32, u32, C.POINTER(vp)]
+    lib.tr_comm_from_nccl.restype = i32
+    lib.tr_comm_from_nccl.argtypes = [vp, u32, u32, C.POINTER(vp)]
+    lib.tr_comm_destroy.restype = i32
+    lib.tr_comm_destroy.argtypes = [vp]
+    lib.tr_comm_last_error.restype = i32
+    lib.tr_comm_last_error.argtypes = [vp]
+    lib.tr_allgather_frame.restype = i32
+    lib.tr_allgather_frame.argtypes = [vp, vp, vp, u32, u32, i32, vp]
     lib.tr_ibl_volume_refraction.restype = i32
     lib.tr_ibl_volume_refraction.argtypes = [vp, vp, u32, C.POINTER(wire.Pyramid), vp, vp]
     if lib.tr_abi_version() != 1:

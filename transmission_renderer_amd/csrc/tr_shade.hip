@@ -10,6 +10,9 @@
 #include "tr_raster_kernels.h"
 #include "tr_glam_pbr_kernels.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: RCCL is loaded with dlopen (tr_comm_*), never linked
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -460,6 +463,7 @@ const char* tr_status_string(tr_status status) {
         case TR_ERR_TABLES_MISSING: return "pass launched before its tables were uploaded";
         case TR_ERR_OUT_OF_MEMORY: return "out of memory";
         case TR_ERR_UNSUPPORTED: return "unsupported";
+        case TR_ERR_COMM: return "RCCL unavailable or a collective failed (see tr_comm_last_error)";
         default: return "unknown status";
     }
 }
@@ -1317,6 +1321,133 @@ tr_status tr_compute_f0(tr_context* ctx, const void* metallic, const void* ior, 
     hipLaunchKernelGGL(compute_f0_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_, (const float*)metallic,
                        (const float*)ior, (const float*)diffuse, count, (float*)out);
     TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+// ------------------------------------------------------------------------ multi-GPU: row bands + composite
+}  // extern "C"
+
+namespace {
+struct rccl_api {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    bool ok = false;
+};
+// Loaded once.  By soname first: a process that already mapped an RCCL (a framework's bundled copy has the same
+// soname) gets that copy, so there is one RCCL per process.
+const rccl_api& rccl() {
+    static const rccl_api api = [] {
+        rccl_api a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.handle) break;
+        }
+        if (!a.handle) return a;
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+        a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather;
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+
+struct tr_comm {
+    ncclComm_t comm = nullptr;
+    uint32_t nranks = 0, rank = 0;
+    bool owned = false;
+    int32_t last_error = 0;
+};
+
+extern "C" {
+
+tr_status tr_band_rows(uint32_t height, uint32_t nranks, uint32_t rank, uint32_t* rows_per_rank, uint32_t* y0, uint32_t* y1) {
+    if (!rows_per_rank || !y0 || !y1 || height == 0 || nranks == 0 || rank >= nranks) return TR_ERR_INVALID_ARGUMENT;
+    const uint32_t even = (height + nranks - 1u) / nranks;
+    const uint32_t rows = (even + kBlockTileH - 1u) / kBlockTileH * kBlockTileH;
+    *rows_per_rank = rows;
+    const uint64_t a = (uint64_t)rank * rows, b = a + rows;
+    *y0 = (uint32_t)(a < height ? a : height);
+    *y1 = (uint32_t)(b < height ? b : height);
+    return TR_OK;
+}
+
+tr_status tr_comm_unique_id(uint8_t id_out[TR_COMM_ID_BYTES]) {
+    static_assert(TR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!id_out) return TR_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return TR_ERR_COMM;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return TR_ERR_COMM;
+    std::memcpy(id_out, id.internal, TR_COMM_ID_BYTES);
+    return TR_OK;
+}
+
+tr_status tr_comm_create(tr_context* ctx, const uint8_t id_in[TR_COMM_ID_BYTES], uint32_t nranks, uint32_t rank, tr_comm** out) {
+    if (!ctx || !id_in || !out || nranks == 0 || rank >= nranks) return TR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!rccl().ok) return TR_ERR_COMM;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    tr_comm* c = new (std::nothrow) tr_comm();
+    if (!c) return TR_ERR_OUT_OF_MEMORY;
+    ncclUniqueId id;
+    std::memcpy(id.internal, id_in, TR_COMM_ID_BYTES);
+    const ncclResult_t r = rccl().CommInitRank(&c->comm, (int)nranks, id, (int)rank);
+    if (r != ncclSuccess) {
+        ctx->last_hip_error = (int32_t)r;   // (no communicator to hold it)
+        delete c;
+        return TR_ERR_COMM;
+    }
+    c->nranks = nranks;
+    c->rank = rank;
+    c->owned = true;
+    *out = c;
+    return TR_OK;
+}
+
+tr_status tr_comm_from_nccl(void* nccl_comm, uint32_t nranks, uint32_t rank, tr_comm** out) {
+    if (!nccl_comm || !out || nranks == 0 || rank >= nranks) return TR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!rccl().ok) return TR_ERR_COMM;
+    tr_comm* c = new (std::nothrow) tr_comm();
+    if (!c) return TR_ERR_OUT_OF_MEMORY;
+    c->comm = (ncclComm_t)nccl_comm;
+    c->nranks = nranks;
+    c->rank = rank;
+    c->owned = false;
+    *out = c;
+    return TR_OK;
+}
+
+tr_status tr_comm_destroy(tr_comm* comm) {
+    if (!comm) return TR_ERR_INVALID_ARGUMENT;
+    tr_status st = TR_OK;
+    if (comm->owned && comm->comm && rccl().ok && rccl().CommDestroy(comm->comm) != ncclSuccess) st = TR_ERR_COMM;
+    delete comm;
+    return st;
+}
+
+int32_t tr_comm_last_error(const tr_comm* comm) { return comm ? comm->last_error : (rccl().ok ? 0 : -1); }
+
+tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame, uint32_t width, uint32_t rows_per_rank,
+                             tr_format format, void* stream_) {
+    if (!ctx || !comm || !frame || width == 0 || rows_per_rank == 0) return TR_ERR_INVALID_ARGUMENT;
+    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F) return TR_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return TR_ERR_COMM;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t band_bytes = (size_t)width * rows_per_rank * (format == TR_FORMAT_RGBA16F ? 8u : 16u);
+    char* base = static_cast<char*>(frame);
+    // in place: this rank's band already sits at its slot of the receive buffer
+    const ncclResult_t r = rccl().AllGather(base + (size_t)comm->rank * band_bytes, base, band_bytes, ncclUint8, comm->comm,
+                                            (hipStream_t)stream_);
+    if (r != ncclSuccess) {
+        comm->last_error = (int32_t)r;
+        return TR_ERR_COMM;
+    }
     return TR_OK;
 }
 

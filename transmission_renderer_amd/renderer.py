@@ -67,7 +67,9 @@ class GBufferPlanes:
 class OpaquePyramid:
     """`opaque_sampled_hdr_framebuffer` (src/main.rs:383-402): RGBA16F, full mip chain, one allocation."""
 
-    def __init__(self, width: int, height: int, device):
+    def __init__(self, width: int, height: int, device, level0_rows: Optional[int] = None):
+        """level0_rows > height reserves extra rows behind level 0 (levels 1.. start later): a row-band sharded
+        frame all-gathers level 0 in equal bands of sharded.padded_rows(height, world) rows in all."""
         lib = _lib.load()
         self.desc = wire.Pyramid()
         nbytes = C.c_size_t()
@@ -75,15 +77,26 @@ class OpaquePyramid:
         if st != 0:
             raise _lib.TrError(st, "tr_pyramid_layout")
         self.width, self.height, self.levels = width, height, int(self.desc.levels)
+        self.level0_rows = max(int(level0_rows or height), height)
+        pad = (self.level0_rows - height) * width           # texels
+        if pad:
+            for l in range(1, self.levels):
+                self.desc.level_offset[l] += pad
+            if (nbytes.value // 8 + pad) * 8 > 0xFFFFFFFF:
+                raise _lib.TrError(6, "padded pyramid exceeds 4 GiB")
+        total = nbytes.value // 8 + pad
         # out_bytes includes one texel of tail padding (the sampler reads 16-byte texel pairs)
-        self._storage = torch.zeros((nbytes.value // 8, 4), dtype=torch.float16, device=device)
-        self.texels = self._storage[:nbytes.value // 8 - 1]
+        self._storage = torch.zeros((total, 4), dtype=torch.float16, device=device)
+        self.texels = self._storage[:total - 1]
         self.desc.texels = self._storage.data_ptr()
 
     def level(self, l: int) -> torch.Tensor:
         w, h = max(self.width >> l, 1), max(self.height >> l, 1)
         off = int(self.desc.level_offset[l])
         return self.texels[off:off + w * h].view(h, w, 4)
+
+    def level0_padded(self) -> torch.Tensor:
+        return self.texels[:self.width * self.level0_rows].view(self.level0_rows, self.width, 4)
 
 
 class TransmissionRenderer:
@@ -290,7 +303,9 @@ class TransmissionRenderer:
     @staticmethod
     def _check_target(hdr: torch.Tensor, push: wire.PushConstants):
         fw, fh = int(push.framebuffer_size[0]), int(push.framebuffer_size[1])
-        assert hdr.is_cuda and hdr.is_contiguous() and hdr.numel() == fw * fh * 4, "colour targets are whole-frame"
+        # whole-frame pitch; a sharded frame's buffer carries padding rows behind the frame (sharded.padded_rows)
+        assert hdr.is_cuda and hdr.is_contiguous() and hdr.numel() >= fw * fh * 4 and hdr.shape[-2] == fw, \
+            "colour targets are whole-frame"
 
     def shade_opaque(self, g: GBufferPlanes, uniforms: wire.Uniforms, push: wire.PushConstants, hdr: torch.Tensor,
                      pyramid: Optional[OpaquePyramid] = None, rect=None):

@@ -1,82 +1,129 @@
-"""Screen-tile sharding across the GPUs of one node (one process per GPU, torch.distributed).
+"""Screen-tile sharding across the GPUs of one node (one process per GPU).
 
 The reference is single-GPU (one VkQueue, src/main.rs:243); this is new surface.
 Pixels of both shading passes are independent given replicated read-only inputs (tables, LUT,
 opaque pyramid), so the frame is cut into contiguous row bands, one per rank, and no collective
-is needed while shading.  Two exchanges exist, both all-gathers of whole row bands over RCCL/xGMI
-("nccl" backend) — or gloo on CPU tensors in the tests:
+is needed while shading.  Two exchanges exist, both in-place all-gathers of whole row bands over RCCL/xGMI:
 
-  * `allgather_frame`: the final composite — every rank ends with the whole RGBA16F frame.
-  * `allgather_mip0`: for the full opaque -> mips -> transmissive pipeline the transmissive pass
-    samples the *whole* opaque pyramid at refracted coordinates, so level 0 has to be gathered
-    (and the 10.67 B/px pyramid built redundantly per rank) between the two passes.
+  * the composite: every rank ends with the whole RGBA16F frame;
+  * level 0 of the opaque pyramid between the two passes (the transmissive pass samples the *whole*
+    pyramid at refracted coordinates; the 10.67 B/px chain is then built redundantly per rank).
 
-Bands are contiguous in memory (row-major frame), so both are in-place all_gather_into_tensor
-calls with no packing kernel.
+Band arithmetic is the library's (`tr_band_rows`, include/tr_shade.h): bands of ceil(H / N) rows rounded up to the
+4-row wave tile, the last ones clipped to the frame; buffers that are gathered hold N * rows_per_rank rows (>= H).
+On a GPU the gathers go through `tr_allgather_frame` — the library's own RCCL communicator, the entry point a
+non-Python host calls too — and through torch.distributed otherwise (gloo on CPU tensors in the tests; also the
+fallback when the library's communicator cannot be created).
 """
 from __future__ import annotations
 
-from typing import Tuple
+import ctypes as C
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
+from . import _lib, wire
 
-def band_rows(height: int, world: int, rank: int) -> Tuple[int, int]:
-    """Rows [y0, y1) of `rank`.  Equal bands (height must divide): in-place all-gather needs equal counts.
-    With textured materials a band must also hold whole 2x2 pixel quads (height / world even): the shading
-    entry points refuse a rect that cuts quads (include/tr_shade.h tr_upload_textures)."""
-    if height % world:
-        raise ValueError(f"frame height {height} is not a multiple of world size {world}")
-    rows = height // world
-    return rank * rows, (rank + 1) * rows
+
+def band_rows(height: int, world: int, rank: int) -> Tuple[int, int, int]:
+    """(rows_per_rank, y0, y1) of `rank`: tr_band_rows."""
+    rows, y0, y1 = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    st = _lib.load().tr_band_rows(int(height), int(world), int(rank), C.byref(rows), C.byref(y0), C.byref(y1))
+    if st != 0:
+        raise ValueError(f"tr_band_rows({height}, {world}, {rank}): status {st}")
+    return rows.value, y0.value, y1.value
 
 
 def band_rect(width: int, height: int, world: int, rank: int) -> Tuple[int, int, int, int]:
-    y0, y1 = band_rows(height, world, rank)
+    _, y0, y1 = band_rows(height, world, rank)
     return 0, y0, width, y1
 
 
-def _allgather_rows_inplace(frame: torch.Tensor, world: int, group=None) -> None:
-    """frame: (H, W, C) contiguous, every rank has written its own band; afterwards all bands are everywhere."""
-    assert frame.is_contiguous()
-    rank = dist.get_rank(group)
-    flat = frame.view(-1)
-    if flat.numel() % world:
-        raise ValueError("frame does not split into equal bands")
-    n = flat.numel() // world
-    mine = flat[rank * n:(rank + 1) * n]
-    backend = dist.get_backend(group)
-    if backend == "gloo":  # gloo has no in-place variant on views of the output: gather into a list of views
-        outs = [flat[i * n:(i + 1) * n] for i in range(world)]
-        dist.all_gather(outs, mine.clone(), group=group)
-    else:
-        dist.all_gather_into_tensor(flat, mine, group=group)
+def padded_rows(height: int, world: int) -> int:
+    """Rows a gathered buffer must hold."""
+    return band_rows(height, world, 0)[0] * world
 
 
-def allgather_frame(hdr: torch.Tensor, world: int, group=None) -> None:
-    """Composite: all-gather the row bands of the RGBA16F/32F frame in place."""
-    _allgather_rows_inplace(hdr, world, group)
+class Compositor:
+    """In-place all-gather of equal row bands of a (rows_per_rank * world, W, C) device or host tensor."""
+
+    def __init__(self, world: int, rank: int, renderer=None, group=None, prefer_library: bool = True):
+        self.world, self.rank, self.group = world, rank, group
+        self.renderer = renderer
+        self._comm = C.c_void_p()
+        self.backend = "none" if world == 1 else "torch.distributed:" + dist.get_backend(group)
+        if world > 1 and renderer is not None and prefer_library:
+            self._try_library_comm()
+
+    def _try_library_comm(self):
+        """The library's RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes."""
+        lib = self.renderer.lib
+        ident = (C.c_uint8 * 128)()
+        ok = 1
+        if self.rank == 0:
+            ok = int(lib.tr_comm_unique_id(C.byref(ident)) == 0)
+        box = [bytes(ident) if ok else None]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        if box[0] is not None:
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            st = lib.tr_comm_create(self.renderer._ctx, C.byref(ident), self.world, self.rank, C.byref(self._comm))
+            ok = int(st == 0)
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.renderer.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)       # every rank or none
+        if int(flag.item()) == 1:
+            self.backend = "tr_allgather_frame (RCCL)"
+        else:
+            self.close()
+
+    def close(self):
+        if self._comm.value:
+            self.renderer.lib.tr_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def allgather_rows(self, frame: torch.Tensor) -> None:
+        """frame: (rows_per_rank * world, W, C) contiguous; every rank has written its own band."""
+        if self.world == 1:
+            return
+        assert frame.is_contiguous() and frame.shape[0] % self.world == 0, "gathered buffers hold world * rows_per_rank rows"
+        rows = frame.shape[0] // self.world
+        if self._comm.value:
+            fmt = wire.FORMAT_RGBA16F if frame.dtype == torch.float16 else wire.FORMAT_RGBA32F
+            assert frame.shape[2] == 4 and frame.dtype in (torch.float16, torch.float32)
+            st = self.renderer.lib.tr_allgather_frame(self.renderer._ctx, self._comm, frame.data_ptr(), int(frame.shape[1]),
+                                                      rows, fmt, torch.cuda.current_stream().cuda_stream)
+            if st != 0:
+                raise _lib.TrError(st, "tr_allgather_frame", self.renderer.lib.tr_comm_last_error(self._comm))
+            return
+        flat = frame.view(-1)
+        n = flat.numel() // self.world
+        mine = flat[self.rank * n:(self.rank + 1) * n]
+        if dist.get_backend(self.group) == "gloo":   # gloo has no in-place variant on views of the output
+            outs = [flat[i * n:(i + 1) * n] for i in range(self.world)]
+            dist.all_gather(outs, mine.clone(), group=self.group)
+        else:
+            dist.all_gather_into_tensor(flat, mine, group=self.group)
 
 
-def allgather_mip0(mip0: torch.Tensor, world: int, group=None) -> None:
-    """Mid-frame exchange of the opaque colour (pyramid level 0) before generate_mips."""
-    _allgather_rows_inplace(mip0, world, group)
-
-
-def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid, world: int, rank: int, group=None,
+def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid, compositor: Compositor,
                    composite: bool = True) -> None:
     """The hot-path slice of `record()` (src/main.rs:1969-2124) for one rank of a row-band sharded frame.
 
-    `opaque` / `transmissive` are this rank's G-buffer tiles (origin_y = its first row).  Order:
+    `opaque` / `transmissive` are this rank's G-buffer tiles (origin_y = its first row); `hdr` holds
+    padded_rows(H, world) rows and `pyramid` was made with level0_rows = the same.  Order:
     opaque band -> all-gather level 0 -> mip chain (replicated) -> transmissive band -> composite.
     """
+    world, rank = compositor.world, compositor.rank
     fw, fh = int(push.framebuffer_size[0]), int(push.framebuffer_size[1])
     rect = band_rect(fw, fh, world, rank)
-    renderer.shade_opaque(opaque, uniforms, push, hdr, pyramid, rect)
+    if rect[3] > rect[1]:       # (a band can be empty when the height is far from a multiple of world * 4)
+        renderer.shade_opaque(opaque, uniforms, push, hdr, pyramid, rect)
     if world > 1:
-        allgather_mip0(pyramid.level(0), world, group)
+        compositor.allgather_rows(pyramid.level0_padded())
     renderer.generate_mips(pyramid)
-    renderer.shade_transmission(transmissive, uniforms, push, pyramid, hdr, rect)
+    if rect[3] > rect[1]:
+        renderer.shade_transmission(transmissive, uniforms, push, pyramid, hdr, rect)
     if world > 1 and composite:
-        allgather_frame(hdr, world, group)
+        compositor.allgather_rows(hdr)
