@@ -252,7 +252,9 @@ struct pixel_frame {
     v2f g_nov;         // sqrt(n.v^2 (1 - a2) + a2) per lobe: the light-independent half of v_smith
 };
 
-template <bool TRANSMISSIVE, class Mat /* cdmat (scalar registers) or const lane_dmat (per lane) */>
+// FIRST: the pixel's first light (the sun) writes the accumulators instead of adding to zeros — `0 + x` is not `x`
+// for the compiler (signed zeros), so accumulating into zero-initialised registers costs a move and an add per sum.
+template <bool TRANSMISSIVE, bool FIRST = false, class Mat /* cdmat (scalar registers) or const lane_dmat (per lane) */>
 __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_frame& px, f3 l, f3 I, bool btdf) {
     const f3 n = px.n, v = px.v;
     const float nov_raw = px.nov_raw, nov = px.nov;
@@ -279,12 +281,17 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         const float Fx = fmaf(m.df[0], p, m.f0[0]), Fy = fmaf(m.df[1], p, m.f0[1]), Fz = fmaf(m.df[2], p, m.f0[2]);
         const float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));  // diffuse_brdf :356-360
         const float ws = nol * dv;                                 // specular_brdf :362-375 (weighted by n.l :414-421)
-        acc.d.x = fmaf(I.x, wd, acc.d.x);
-        acc.d.y = fmaf(I.y, wd, acc.d.y);
-        acc.d.z = fmaf(I.z, wd, acc.d.z);
-        acc.s.x = fmaf(I.x * ws, Fx, acc.s.x);
-        acc.s.y = fmaf(I.y * ws, Fy, acc.s.y);
-        acc.s.z = fmaf(I.z * ws, Fz, acc.s.z);
+        if constexpr (FIRST) {
+            acc.d = {I.x * wd, I.y * wd, I.z * wd};
+            acc.s = {I.x * ws * Fx, I.y * ws * Fy, I.z * ws * Fz};
+        } else {
+            acc.d.x = fmaf(I.x, wd, acc.d.x);
+            acc.d.y = fmaf(I.y, wd, acc.d.y);
+            acc.d.z = fmaf(I.z, wd, acc.d.z);
+            acc.s.x = fmaf(I.x * ws, Fx, acc.s.x);
+            acc.s.y = fmaf(I.y * ws, Fy, acc.s.y);
+            acc.s.z = fmaf(I.z * ws, Fz, acc.s.z);
+        }
     }
     // ---- lobe 1: transmission_btdf (:200-233): the light mirrored about the surface,
     //      n.l' = -(n.l), v.l' = v.l - 2 (n.l)(n.v); no vector is formed.  For the mirrored light |v+l'|^2
@@ -305,13 +312,22 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
             const float g = fmaf(nolm, px.g_nov.y, nov * fast_sqrt(fmaf(nolm * nolm, m.oma2[1], m.a2[1])));
             const float r = rcp(f * f * g);                          // D'V' / k[1]; not weighted by n.l (:232)
             const float tx = I.x * r, ty = I.y * r, tz = I.z * r;
-            acc.ta.x += tx;
-            acc.ta.y += ty;
-            acc.ta.z += tz;
-            acc.tb.x = fmaf(tx, p, acc.tb.x);
-            acc.tb.y = fmaf(ty, p, acc.tb.y);
-            acc.tb.z = fmaf(tz, p, acc.tb.z);
+            if constexpr (FIRST) {
+                acc.ta = {tx, ty, tz};
+                acc.tb = {tx * p, ty * p, tz * p};
+            } else {
+                acc.ta.x += tx;
+                acc.ta.y += ty;
+                acc.ta.z += tz;
+                acc.tb.x = fmaf(tx, p, acc.tb.x);
+                acc.tb.y = fmaf(ty, p, acc.tb.y);
+                acc.tb.z = fmaf(tz, p, acc.tb.z);
+            }
+        } else if constexpr (FIRST) {
+            acc.ta = acc.tb = {0.f, 0.f, 0.f};
         }
+    } else if constexpr (FIRST) {
+        acc.ta = acc.tb = {0.f, 0.f, 0.f};
     }
 }
 
@@ -332,7 +348,7 @@ __device__ __forceinline__ void eval_punctual(light_acc& acc, Mat& m, cdlight& L
         }
     }
     f3 I = {L.colour[0] * att, L.colour[1] * att, L.colour[2] * att};
-    eval_light<TRANSMISSIVE>(acc, m, px, l, I, btdf);
+    eval_light<TRANSMISSIVE, false>(acc, m, px, l, I, btdf);
 }
 
 // ------------------------------------------------------------------ opaque pyramid taps
@@ -760,7 +776,11 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     // Every lane walks its own cluster's list; at each step the lanes whose next light index equals that of the
     // first pending lane evaluate it together, with the light read through the scalar unit.  When the lists
     // agree (the normal case, also across cluster boundaries) that is one pass per light.
-    light_acc acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#ifndef TR_SUN_FIRST
+#define TR_SUN_FIRST 1   // the sun writes the accumulators (0: zero-initialised and accumulated, experiments only)
+#endif
+    light_acc acc;
+    if (!TR_SUN_FIRST || TR_ABLATION) acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto lights_phase = [&]() {
         claunch* L2 = launder(L);
         MatP m2 = launder(m);
@@ -770,12 +790,16 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         }
         // sun (lighting.rs:37-53 / 171-177)
         if (!TR_ABLATE(L2, 4u))
-            eval_light<TRANSMISSIVE>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
+            eval_light<TRANSMISSIVE, TR_SUN_FIRST && !TR_ABLATION>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
                                      {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, transmits);
-        // punctual lights (lighting.rs:55-92 / 179-217)
         tile_phase<1>();
+    };
+    // punctual lights (lighting.rs:55-92 / 179-217)
+    auto punctual_uniform = [&]() {   // one cluster for the whole tile: count, list and lights all through the scalar unit
+        claunch* L2 = launder(L);
+        MatP m2 = launder(m);
         cdlight* lights = as_constant(L2->lights);
-        if (cl.uniform) {   // one cluster for the whole tile: count, list and lights all through the scalar unit
+        {
             const uint32_t n = cl.s_num;
             const uint32_t sc = cl.s_cluster == 0xFFFFFFFFu ? 0u : opaque(cl.s_cluster);
             const TR_CONSTANT uint32_t* list = as_constant(L2->light_indices) + (size_t)sc * TR_MAX_LIGHTS_PER_CLUSTER;
@@ -784,8 +808,12 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
                 eval_punctual<TRANSMISSIVE>(acc, *m2, lights[idx], pos, px, transmits);
             }
             uniform_lights = n;
-            return;
         }
+    };
+    auto punctual_per_lane = [&]() {
+        claunch* L2 = launder(L);
+        MatP m2 = launder(m);
+        cdlight* lights = as_constant(L2->lights);
         constexpr uint32_t kDone = 0xFFFFFFFFu;   // a lane whose list is exhausted
         uint32_t i = 0;
         uint32_t head = num_lights ? cl.l0 : kDone;
@@ -799,11 +827,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
             if (head == h0) {
                 ++i;
                 uint32_t next = cl.l1;
-#ifdef TR_AB_TAIL_ALWAYS   // experiments only (tools/ab_kernel.py)
-                if (i >= 2u)
-#else
                 if (long_lists && i >= 2u)   // longer lists: the entry is in flight during the evaluation
-#endif
                     next = ld<uint32_t>(L2->light_indices, cl.list_offset + min(i, TR_MAX_LIGHTS_PER_CLUSTER - 1u) * 4u);
                 eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0s], pos, px, transmits);
                 head = i < num_lights ? next : kDone;
@@ -858,19 +882,26 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     // would hide their latency inside the wave, but holds 16 + 6 vector registers across the loop; without them
     // the kernel fits 64 VGPRs = 8 waves per SIMD, and the other seven waves hide the latency better (measured:
     // 129 -> 122 us on the 4K frame, profiles/r01).
-    lights_phase();
-    tile_phase<2>();
+    auto tail = [&]() -> f3 {
+        tile_phase<2>();
 #if TR_TIMING
-    tr_drain();
-    const unsigned long long t_taps = tr_now();
+        tr_drain();
+        const unsigned long long t_taps = tr_now();
 #endif
-    issue_taps();
+        issue_taps();
 #if TR_TIMING
-    tr_drain();
-    timer.wait[2] += tr_now() - t_taps;
+        tr_drain();
+        timer.wait[2] += tr_now() - t_taps;
 #endif
-    tile_phase<3>();
-    return finish();
+        tile_phase<3>();
+        return finish();
+    };
+    lights_phase();   // the sun
+    // (Instantiating the rest of the pixel behind each list walk, to save the ~10 register copies where the two walks
+    //  join, was tried: the scheduler then keeps 84 registers live — a lost wave costs more than the copies.)
+    if (cl.uniform) punctual_uniform();
+    else punctual_per_lane();
+    return tail();
 }
 
 // ------------------------------------------------------------------------ one pixel of a textured material
@@ -1073,6 +1104,10 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) void shade_kernel(const 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lx = lane & (kWaveTileW - 1u), ly = lane / kWaveTileW;   // position inside the wave's tile
 
+    // One contiguous band of the rect's block tiles (row-major) per XCD.  Dealing the tiles to the XCDs in k smaller
+    // chunks or in stripes of tile rows, to average the scene's cost variations over the XCDs (the most loaded XCD runs
+    // ~3 % longer than the mean on the 4K frame), measured equal or slower for every k: each L2 then serves k windows
+    // of the screen and of the pyramid behind it.
     const uint32_t ntiles = L->fp.tiles_x * L->fp.tiles_y;
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = ntiles >> 3, rem = ntiles & 7u;
