@@ -619,6 +619,22 @@ typedef struct tr_frame_desc {
 } tr_frame_desc;
 tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* frame, void* stream);
 
+/* The same frame with a GPU timestamp pair around every pass: the reference's Tracy GPU zones (Vulkan timestamp queries,
+ * src/profiling.rs:134-236) under the names it gives them in `record()` (src/main.rs:1643, 1653, 1831, 1902, 1989,
+ * 2048, 2094, 2227): "all commands", "frustum culling", "demultiplex draws compute shader", "depth pre pass" (here:
+ * the visibility-buffer rasteriser that stands for the three depth pre-passes and the EQUAL-tested draws), "main opaque",
+ * "opaque framebuffer mipchain", "opaque transmissive objects", "tonemapping"; plus "assign lights to clusters", which
+ * the reference records without a zone (:1765-1798).  A measuring call: it records HIP events on `stream`, WAITS for
+ * the frame, and writes up to `capacity` zones (host memory; `name` points to a static string) and their count. */
+typedef struct tr_frame_zone {
+    const char* name;
+    float milliseconds;
+    uint32_t _pad;
+} tr_frame_zone;
+#define TR_MAX_FRAME_ZONES 16u
+tr_status tr_record_frame_timed(tr_context* ctx, const tr_frame_desc* frame, void* stream, tr_frame_zone* zones_out,
+                                uint32_t capacity, uint32_t* num_zones_out);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

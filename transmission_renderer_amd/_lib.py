@@ -20,7 +20,7 @@ SYMBOLS = (
     "tr_upload_ggx_lut", "tr_upload_textures", "tr_texture_get_layout", "tr_download_texture", "tr_frustum_culling", "tr_demultiplex_draws",
     "tr_upload_geometry", "tr_rasterize", "tr_draw_scene",
     "tr_write_cluster_data", "tr_assign_lights_to_clusters", "tr_shade_opaque",
-    "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap", "tr_record_frame",
+    "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap", "tr_record_frame", "tr_record_frame_timed",
     "tr_basic_brdf", "tr_transmission_btdf", "tr_ibl_volume_refraction", "tr_light_direction_and_attenuation", "tr_d_ggx",
     "tr_v_smith_ggx_correlated", "tr_fresnel_schlick", "tr_compute_f0", "tr_get_depth_slice", "tr_depth_slice_thresholds",
     "tr_band_rows", "tr_comm_unique_id", "tr_comm_create", "tr_comm_from_nccl", "tr_comm_destroy", "tr_comm_last_error",
@@ -114,6 +114,8 @@ def load() -> C.CDLL:
     lib.tr_tonemap.argtypes = [vp, vp, u32, u32, C.POINTER(wire.TonemapParams), vp, i32, vp]
     lib.tr_record_frame.restype = i32
     lib.tr_record_frame.argtypes = [vp, C.POINTER(wire.FrameDesc), vp]
+    lib.tr_record_frame_timed.restype = i32
+    lib.tr_record_frame_timed.argtypes = [vp, C.POINTER(wire.FrameDesc), vp, C.POINTER(wire.FrameZone), u32, C.POINTER(u32)]
     for name, nptr in (("tr_basic_brdf", 1), ("tr_transmission_btdf", 1), ("tr_light_direction_and_attenuation", 2),
                        ("tr_d_ggx", 2), ("tr_v_smith_ggx_correlated", 3), ("tr_fresnel_schlick", 3), ("tr_compute_f0", 3)):
         fn = getattr(lib, name)   # (ctx, <nptr input arrays>, count, out, stream)

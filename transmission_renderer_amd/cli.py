@@ -5,7 +5,8 @@ The reference's CLI (`Opt`, src/main.rs:65-91) is
 and renders to a window.  Here the frame goes to a file.  Scene sources:
     <path>.gltf / <path>.glb   a glTF 2.0 file (what `--external-model` gives the reference; the Khronos sample-model
                                checkout the reference resolves bare names against is not in this image), placed like
-                               src/main.rs:364-368: translated to (0, 2, 0), scaled by --scale
+                               src/main.rs:364-368: translated to (0, 2, 0), scaled by --scale; `--backdrop other.glb`
+                               puts a second scene behind it the way the reference always loads Sponza (:342-351)
     meshes                     the procedural mesh scene (transmission_renderer_amd/meshes.py), same pipeline
     synthetic                  a ready-made TGB-v1 G-buffer (the benchmark's input), no geometry stage
 Pipeline (every stage on the GPU through libtr_shade.so):
@@ -33,6 +34,12 @@ def main(argv=None) -> int:
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=2, help="point lights (the reference hard-codes 2)")
+    ap.add_argument("--backdrop", default=None, metavar="GLTF",
+                    help="a .gltf / .glb scene loaded FIRST with the identity transform and no roughness override, behind "
+                         "the model — what the reference does with Sponza (src/main.rs:342-351); the refraction samples it")
+    ap.add_argument("--timings", action="store_true",
+                    help="render a second, timed frame and print the GPU time of every pass under the reference's "
+                         "profiling zone names (src/main.rs:1643-2227)")
     ap.add_argument("--out", default="frame.png", help="tonemapped 8-bit sRGB PNG")
     ap.add_argument("--hdr-out", default=None, help="also save the RGBA16F HDR frame as .npy")
     ap.add_argument("--device", type=int, default=0)
@@ -45,6 +52,9 @@ def main(argv=None) -> int:
         return 2
     if is_file and not os.path.exists(name):
         print(f"{name}: no such file", file=sys.stderr)
+        return 2
+    if args.backdrop is not None and (not is_file or not os.path.exists(args.backdrop)):
+        print("--backdrop needs an existing .gltf / .glb file and a .gltf / .glb model in front of it", file=sys.stderr)
         return 2
 
     import torch
@@ -69,7 +79,11 @@ def main(argv=None) -> int:
         scene["materials"][2].alpha_clipping_cutoff = 0.75
         scene["materials"][7].alpha_clipping_cutoff = 0.6
     else:
-        loaded = gltf.load_gltf(name, base_transform=meshes.Similarity(np.array([0.0, 2.0, 0.0], np.float32), args.scale),
+        # src/main.rs:342-368: the backdrop scene (Sponza there) first, identity transform, no override; then the
+        # model at (0, 2, 0) scaled by --scale into the same model buffers (materials and textures are appended)
+        backdrop = gltf.load_gltf(args.backdrop) if args.backdrop else None
+        loaded = gltf.load_gltf(name, scene=backdrop,
+                                base_transform=meshes.Similarity(np.array([0.0, 2.0, 0.0], np.float32), args.scale),
                                 roughness_override=args.roughness_override)
         geometry = loaded.geometry()
         scene["materials"] = loaded.materials or [wire.MaterialInfo.default()]
@@ -101,6 +115,13 @@ def main(argv=None) -> int:
         hdr, ldr = r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs, work)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.timings and geometry is not None:
+        for _ in range(20):   # warm clocks
+            r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs, work)
+        _, _, zones = r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs,
+                                     work, timed=True)
+        for zone, ms in zones.items():
+            print(f"  {zone:<36} {ms * 1e3:9.1f} us")
     write_png(args.out, ldr.cpu().numpy())
     if args.hdr_out:
         np.save(args.hdr_out, hdr.cpu().numpy())

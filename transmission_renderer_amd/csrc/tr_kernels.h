@@ -1091,8 +1091,12 @@ struct tile_regs {
     uint32_t mat, cluster_x, cluster_y_term, px, py;  // (the two table values are only added when used)
 };
 
+// Experiments only: an occupancy target for the register allocator, e.g. -DTR_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(TEXTURED ? 5 : 8)))'
+#ifndef TR_WAVES_ATTR
+#define TR_WAVES_ATTR
+#endif
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, bool TEXTURED = false>
-__global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) void shade_kernel(const tr_launch launch_by_value) {
+__global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
     const uint32_t block_waves = blockDim.x >> 6;   // 4, or 1 (TR_WAVE_BLOCKS: one wave per workgroup)
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());

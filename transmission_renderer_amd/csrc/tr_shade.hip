@@ -1529,7 +1529,42 @@ tr_status tr_tonemap(tr_context* ctx, const void* hdr, uint32_t width, uint32_t 
     return TR_OK;
 }
 
-tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream) {
+}  // extern "C"
+
+namespace {
+// Optional GPU timestamps around the passes of a frame (tr_record_frame_timed): one hipEvent pair per zone.
+struct zone_recorder {
+    struct zone { const char* name; hipEvent_t begin, end; };
+    std::vector<zone> zones;
+    hipStream_t stream;
+    bool failed = false;
+    int open(const char* name) {
+        zone z{name, nullptr, nullptr};
+        if (hipEventCreate(&z.begin) != hipSuccess || hipEventCreate(&z.end) != hipSuccess ||
+            hipEventRecord(z.begin, stream) != hipSuccess)
+            failed = true;
+        zones.push_back(z);
+        return (int)zones.size() - 1;
+    }
+    void close(int i) {
+        if (zones[(size_t)i].end && hipEventRecord(zones[(size_t)i].end, stream) != hipSuccess) failed = true;
+    }
+    ~zone_recorder() {
+        for (auto& z : zones) {
+            if (z.begin) (void)hipEventDestroy(z.begin);
+            if (z.end) (void)hipEventDestroy(z.end);
+        }
+    }
+};
+struct zone_scope {   // no-op without a recorder
+    zone_recorder* r;
+    int i = -1;
+    zone_scope(zone_recorder* rec, const char* name) : r(rec) { if (r) i = r->open(name); }
+    void close() { if (r && i >= 0) { r->close(i); i = -1; } }
+    ~zone_scope() { close(); }
+};
+
+tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zone_recorder* rec) {
     if (!ctx || !f || !f->push || !f->uniforms || !f->culling || !f->view_matrix || !f->view_rotation ||
         !f->cluster_aabbs || !f->cluster_light_counts || !f->light_indices || !f->hdr || !f->pyramid.texels ||
         f->num_clusters == 0 || ((f->tonemap == nullptr) != (f->ldr_out == nullptr)))
@@ -1538,20 +1573,33 @@ tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream)
     const uint32_t w = f->push->framebuffer_size[0], h = f->push->framebuffer_size[1];
     if (f->pyramid.width != w || f->pyramid.height != h) return TR_ERR_INVALID_ARGUMENT;
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
-    // "frustum culling compute shader" + "demultiplex draws compute shader" + the draws
-    tr_status st = tr_frustum_culling(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instances, ctx->num_instances,
-                                      f->culling, ctx->d_instance_counts, stream);
+    zone_scope all(rec, "all commands");
+    tr_status st;
+    {   // "frustum culling" (zeroing the counts + "frustum culling compute shader")
+        zone_scope z(rec, "frustum culling");
+        st = tr_frustum_culling(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instances, ctx->num_instances,
+                                f->culling, ctx->d_instance_counts, stream);
+    }
     if (st != TR_OK) return st;
-    st = tr_assign_lights_to_clusters(ctx, f->view_matrix, f->view_rotation, f->cluster_aabbs, f->num_clusters,
-                                      f->cluster_light_counts, f->light_indices, stream);
+    {
+        zone_scope z(rec, "assign lights to clusters");
+        st = tr_assign_lights_to_clusters(ctx, f->view_matrix, f->view_rotation, f->cluster_aabbs, f->num_clusters,
+                                          f->cluster_light_counts, f->light_indices, stream);
+    }
     if (st != TR_OK) return st;
     st = tr_set_cluster_tables(ctx, f->cluster_light_counts, f->light_indices, f->num_clusters);
     if (st != TR_OK) return st;
     void* draws[TR_NUM_DRAW_BUFFERS] = {ctx->d_draws[0], ctx->d_draws[1], ctx->d_draws[2], ctx->d_draws[3]};
-    st = tr_demultiplex_draws(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instance_counts, ctx->d_draw_counts, draws,
-                              stream);
+    {
+        zone_scope z(rec, "demultiplex draws compute shader");
+        st = tr_demultiplex_draws(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instance_counts, ctx->d_draw_counts,
+                                  draws, stream);
+    }
     if (st != TR_OK) return st;
-    st = tr_rasterize(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream);
+    {   // the visibility-buffer rasteriser: stands for the depth pre-passes and the EQUAL-tested colour-pass draws
+        zone_scope z(rec, "depth pre pass");
+        st = tr_rasterize(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream);
+    }
     if (st != TR_OK) return st;
     // "main opaque" -> "opaque framebuffer mipchain" -> "opaque transmissive objects"
     tr_gbuffer layers[2];
@@ -1566,19 +1614,60 @@ tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream)
         layers[k].origin_x = layers[k].origin_y = 0;
     }
     const tr_rect whole = {0u, 0u, w, h};
-    ctx->cover_hint = ctx->d_tile_cover[0];
-    st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
-    ctx->cover_hint = nullptr;
+    {
+        zone_scope z(rec, "main opaque");
+        ctx->cover_hint = ctx->d_tile_cover[0];
+        st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
+        ctx->cover_hint = nullptr;
+    }
     if (st != TR_OK) return st;
-    st = tr_generate_mips(ctx, &f->pyramid, stream);
+    {
+        zone_scope z(rec, "opaque framebuffer mipchain");
+        st = tr_generate_mips(ctx, &f->pyramid, stream);
+    }
     if (st != TR_OK) return st;
-    ctx->cover_hint = ctx->d_tile_cover[1];
-    st = tr_shade_transmission(ctx, &layers[1], f->uniforms, f->push, &f->pyramid, f->hdr, f->hdr_format, whole, stream);
-    ctx->cover_hint = nullptr;
+    {
+        zone_scope z(rec, "opaque transmissive objects");
+        ctx->cover_hint = ctx->d_tile_cover[1];
+        st = tr_shade_transmission(ctx, &layers[1], f->uniforms, f->push, &f->pyramid, f->hdr, f->hdr_format, whole, stream);
+        ctx->cover_hint = nullptr;
+    }
     if (st != TR_OK) return st;
-    // "tonemapping"
-    if (f->ldr_out) st = tr_tonemap(ctx, f->hdr, w, h, f->tonemap, f->ldr_out, f->bgra, stream);
+    if (f->ldr_out) {
+        zone_scope z(rec, "tonemapping");
+        st = tr_tonemap(ctx, f->hdr, w, h, f->tonemap, f->ldr_out, f->bgra, stream);
+    }
     return st;
+}
+}  // namespace
+
+extern "C" {
+
+tr_status tr_record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream) { return record_frame(ctx, f, stream, nullptr); }
+
+tr_status tr_record_frame_timed(tr_context* ctx, const tr_frame_desc* f, void* stream, tr_frame_zone* zones_out, uint32_t capacity,
+                                uint32_t* num_zones_out) {
+    if (!ctx || !zones_out || !num_zones_out) return TR_ERR_INVALID_ARGUMENT;
+    *num_zones_out = 0;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    zone_recorder rec;
+    rec.stream = (hipStream_t)stream;
+    const tr_status st = record_frame(ctx, f, stream, &rec);
+    if (st != TR_OK) return st;
+    if (rec.failed) return TR_ERR_HIP;
+    TR_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    uint32_t n = 0;
+    for (const auto& z : rec.zones) {
+        if (n >= capacity) break;
+        float ms = 0.0f;
+        TR_HIP(ctx, hipEventElapsedTime(&ms, z.begin, z.end));
+        zones_out[n].name = z.name;
+        zones_out[n].milliseconds = ms;
+        zones_out[n]._pad = 0;
+        ++n;
+    }
+    *num_zones_out = n;
+    return TR_OK;
 }
 
 }  // extern "C"

@@ -350,10 +350,12 @@ class TransmissionRenderer:
         return out
 
     def record_frame(self, uniforms: wire.Uniforms, push: wire.PushConstants, culling: wire.CullingPushConstants,
-                     view_matrix: np.ndarray, view_rotation: np.ndarray, aabbs: torch.Tensor, work: dict, tonemap=True):
+                     view_matrix: np.ndarray, view_rotation: np.ndarray, aabbs: torch.Tensor, work: dict, tonemap=True,
+                     timed: bool = False):
         """One frame of the uploaded scene through tr_record_frame (the native recorder: culling, light assignment,
         demultiplex, rasteriser, opaque, mips, transmissive, tonemap).  `work` = new_frame_buffers(); returns
-        (hdr, ldr or None)."""
+        (hdr, ldr or None) — and, with timed=True (tr_record_frame_timed, blocks), a dict {zone name: ms} under the
+        reference's profiling zone names (src/main.rs:1643-2227)."""
         vm = (C.c_float * 16)(*[float(x) for x in np.asarray(view_matrix, dtype=np.float32).reshape(-1)])
         q = (C.c_float * 4)(*[float(x) for x in np.asarray(view_rotation, dtype=np.float32).reshape(-1)])
         params = self.baked_tonemap_params() if tonemap else None
@@ -369,6 +371,13 @@ class TransmissionRenderer:
         d.bgra = 0
         if tonemap:
             d.tonemap, d.ldr_out = C.pointer(params), work["ldr"].data_ptr()
+        if timed:
+            zones = (wire.FrameZone * 16)()
+            n = C.c_uint32()
+            self._check(self.lib.tr_record_frame_timed(self._ctx, C.byref(d), self._stream(), zones, 16, C.byref(n)),
+                        "tr_record_frame_timed")
+            times = {zones[i].name.decode(): float(zones[i].milliseconds) for i in range(n.value)}
+            return work["hdr"], (work["ldr"] if tonemap else None), times
         self._check(self.lib.tr_record_frame(self._ctx, C.byref(d), self._stream()), "tr_record_frame")
         return work["hdr"], (work["ldr"] if tonemap else None)
 

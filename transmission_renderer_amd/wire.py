@@ -264,6 +264,10 @@ class GBufferTarget(C.Structure):  # include/tr_shade.h tr_gbuffer_target
     _fields_ = [("pos_depth", C.c_void_p), ("nrm_scale", C.c_void_p), ("uv", C.c_void_p), ("material_id", C.c_void_p)]
 
 
+class FrameZone(C.Structure):  # include/tr_shade.h tr_frame_zone
+    _fields_ = [("name", C.c_char_p), ("milliseconds", C.c_float), ("_pad", C.c_uint32)]
+
+
 class FrameDesc(C.Structure):  # include/tr_shade.h tr_frame_desc
     _fields_ = [("push", C.POINTER(PushConstants)), ("uniforms", C.POINTER(Uniforms)),
                 ("culling", C.POINTER(CullingPushConstants)), ("view_matrix", C.POINTER(C.c_float)),
