@@ -46,9 +46,9 @@ def test_cli_renders_a_model_in_front_of_a_backdrop(tmp_path):
     from transmission_renderer_amd.png import read_png_rgba8
     model, out_a, out_b = str(tmp_path / "demo.glb"), str(tmp_path / "a.png"), str(tmp_path / "b.png")
     make_demo_gltf.main(model)
-    assert cli.main([model, "--width", "320", "--height", "180", "--scale", "0.5", "--out", out_a]) == 0
-    assert cli.main([model, "--backdrop", model, "--width", "320", "--height", "180", "--scale", "0.5", "--out", out_b]) == 0
+    assert cli.main([model, "--width", "320", "--height", "180", "--scale", "0.15", "--out", out_a]) == 0
+    assert cli.main([model, "--backdrop", model, "--width", "320", "--height", "180", "--scale", "0.15", "--out", out_b]) == 0
     a, b = read_png_rgba8(out_a), read_png_rgba8(out_b)
     assert a.shape == b.shape == (180, 320, 4)
     changed = (a[..., :3] != b[..., :3]).any(axis=2).mean()
-    assert changed > 0.2, changed            # the backdrop fills pixels the model alone leaves to the clear colour
+    assert changed > 0.1, changed            # the backdrop fills pixels the model alone leaves to the clear colour

@@ -108,13 +108,12 @@ __global__ __launch_bounds__(64) void write_cluster_data_kernel(const tr_cluster
 
 // shader/src/lib.rs:596-645 + ClusterAabb::{distance_sq, cull_spotlight} shared-structs/src/lib.rs:290-319.
 // One wave per cluster; block = 4 waves = 4 clusters.
-__global__ __launch_bounds__(256) void assign_lights_kernel(const tr_assign_params p, const tr_alight* __restrict__ lights,
-                                                            const tr_cluster_aabb* __restrict__ clusters,
-                                                            uint32_t* __restrict__ counts,
-                                                            uint32_t* __restrict__ indices) {
+__device__ __forceinline__ void assign_lights_body(const tr_assign_params& p, const tr_alight* __restrict__ lights,
+                                                   const tr_cluster_aabb* __restrict__ clusters, uint32_t* __restrict__ counts,
+                                                   uint32_t* __restrict__ indices, uint32_t block) {
 #pragma clang fp contract(off)
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t cluster = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t cluster = block * 4u + (threadIdx.x >> 6);
     if (cluster >= p.num_clusters) return;
     const tr_cluster_aabb box = clusters[cluster];
     // per-cluster constants of cull_spotlight
@@ -166,6 +165,12 @@ __global__ __launch_bounds__(256) void assign_lights_kernel(const tr_assign_para
         count += (uint32_t)__popcll(mask);
     }
     if (lane == 0) counts[cluster] = count < TR_MAX_LIGHTS_PER_CLUSTER ? count : TR_MAX_LIGHTS_PER_CLUSTER;
+}
+__global__ __launch_bounds__(256) void assign_lights_kernel(const tr_assign_params p, const tr_alight* __restrict__ lights,
+                                                            const tr_cluster_aabb* __restrict__ clusters,
+                                                            uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ indices) {
+    assign_lights_body(p, lights, clusters, counts, indices, blockIdx.x);
 }
 
 }  // namespace tr

@@ -56,12 +56,11 @@ struct tr_cull_params {
 
 // One thread per instance; the only shared state is one counter per primitive, and only its final value is
 // observable, so the atomic order does not matter.
-__global__ __launch_bounds__(256) void frustum_culling_kernel(const tr_cull_params p,
-                                                              const tr_primitive_info* __restrict__ primitives,
-                                                              const tr_instance* __restrict__ instances,
-                                                              uint32_t* __restrict__ instance_counts) {
+__device__ __forceinline__ void frustum_culling_body(const tr_cull_params& p, const tr_primitive_info* __restrict__ primitives,
+                                                     const tr_instance* __restrict__ instances,
+                                                     uint32_t* __restrict__ instance_counts, uint32_t block) {
 #pragma clang fp contract(off)
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = block * 256u + threadIdx.x;
     if (i >= p.num_instances) return;
     const tr_instance inst = instances[i];
     if (inst.primitive_id >= p.num_primitives) return;   // unchecked in the reference
@@ -76,6 +75,12 @@ __global__ __launch_bounds__(256) void frustum_culling_kernel(const tr_cull_para
     visible &= cz * p.pc.frustum_y_yz[1] - fabsf(cy) * p.pc.frustum_y_yz[0] < radius;
     if (visible) atomicAdd(&instance_counts[inst.primitive_id], 1u);
 }
+__global__ __launch_bounds__(256) void frustum_culling_kernel(const tr_cull_params p,
+                                                              const tr_primitive_info* __restrict__ primitives,
+                                                              const tr_instance* __restrict__ instances,
+                                                              uint32_t* __restrict__ instance_counts) {
+    frustum_culling_body(p, primitives, instances, instance_counts, blockIdx.x);
+}
 
 struct tr_draw_buffers {
     tr_draw_command* draws[TR_NUM_DRAW_BUFFERS];
@@ -85,11 +90,12 @@ struct tr_draw_buffers {
 // the primitives with a non-zero instance count IN ASCENDING PRIMITIVE ORDER (ballot + mbcnt inside a wave, LDS
 // across the 16 waves): the reference's atomic append is order-free, this one is reproducible.  The work is a few
 // bytes per primitive; one workgroup is latency-, not throughput-bound, up to ~1e6 primitives.
-__global__ __launch_bounds__(1024) void demultiplex_draws_kernel(const tr_primitive_info* __restrict__ primitives,
-                                                                 const uint32_t* __restrict__ instance_counts,
-                                                                 uint32_t num_primitives,
-                                                                 uint32_t* __restrict__ draw_counts,
-                                                                 const tr_draw_buffers out) {
+// ZERO_COUNTS (the frame recorder's own buffer): every count is zeroed once it has been read, so the next frame's
+// culling finds the buffer clear without a fill launch of its own (src/main.rs:1668-1674 zeroes it per frame).
+template <bool ZERO_COUNTS>
+__device__ __forceinline__ void demultiplex_draws_body(const tr_primitive_info* __restrict__ primitives,
+                                                       uint32_t* __restrict__ instance_counts, uint32_t num_primitives,
+                                                       uint32_t* __restrict__ draw_counts, const tr_draw_buffers& out) {
     __shared__ uint32_t wave_totals[16][TR_NUM_DRAW_BUFFERS];
     __shared__ uint32_t running[TR_NUM_DRAW_BUFFERS];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(1024) void demultiplex_draws_kernel(const tr_primit
         tr_primitive_info prim;
         if (d < num_primitives) {
             n = instance_counts[d];
+            if constexpr (ZERO_COUNTS) instance_counts[d] = 0u;
             prim = primitives[d];
             buffer = prim.draw_buffer_index < 3u ? prim.draw_buffer_index : 3u;   // the `_ =>` arm
         }
@@ -133,6 +140,13 @@ __global__ __launch_bounds__(1024) void demultiplex_draws_kernel(const tr_primit
         __syncthreads();
     }
     if (threadIdx.x < TR_NUM_DRAW_BUFFERS) draw_counts[threadIdx.x] = running[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void demultiplex_draws_kernel(const tr_primitive_info* __restrict__ primitives,
+                                                                 const uint32_t* __restrict__ instance_counts,
+                                                                 uint32_t num_primitives,
+                                                                 uint32_t* __restrict__ draw_counts,
+                                                                 const tr_draw_buffers out) {
+    demultiplex_draws_body<false>(primitives, const_cast<uint32_t*>(instance_counts), num_primitives, draw_counts, out);
 }
 
 }  // namespace tr

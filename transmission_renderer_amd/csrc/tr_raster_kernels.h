@@ -416,7 +416,7 @@ struct tr_layer_planes {
 // perspective-correct), or "no fragment".
 __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, const tr_raster_frame f,
                                                              const tr_tri_record* __restrict__ records,
-                                                             const unsigned long long* __restrict__ vis,
+                                                             unsigned long long* __restrict__ vis,
                                                              const tr_layer_planes out, const uint32_t* __restrict__ tile_cover) {
 #pragma clang fp contract(off)
     const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
@@ -433,6 +433,9 @@ __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, co
         out.material_id[pix] = TR_NOT_COVERED;
         return;
     }
+    // The resolve is the last reader of a visibility word: it leaves the buffer zeroed for the next frame, so a frame
+    // clears only the words it set instead of filling both whole-frame buffers (133 MB at 4K, 21 us) up front.
+    vis[pix] = 0ull;
     const tr_tri_record rec = records[(uint32_t)key];
     const tr_instance inst = g.instances[rec.instance];
     float lam[3], depth;
@@ -471,14 +474,57 @@ struct tr_layer_work {
     uint32_t* item_counts;
     uint32_t* chunk_sums;
     uint32_t* item_base;
-    const unsigned long long* vis;
+    unsigned long long* vis;
     tr_layer_planes planes;
-    uint32_t* tile_cover;                      // [ceil(h/4)][ceil(w/64)]: zeroed with the visibility buffers, set by raster_kernel
+    uint32_t* tile_cover;                      // [ceil(h/4)][ceil(w/64)]: zeroed per frame, set by raster_kernel
 };
 struct tr_two_layers {
     tr_layer_work l[2];
 };
 #define TR_PICK_LAYER(two, which) const tr_layer_work W = (which) ? (two).l[1] : (two).l[0]
+
+// The frame recorder's fused launches (tr_record_frame / tr_draw_scene): every step of the front end is a tiny,
+// launch-latency-bound kernel (~4.5 us each back to back), so steps that run in ONE workgroup anyway share a launch.
+//   demultiplex_draws, then the draw scan of both layers: the same 1024 threads; the draw commands and counts the first
+//   step wrote are made visible to the whole device (fence) before the block barrier.
+__global__ __launch_bounds__(1024) void frame_demux_scan_kernel(const tr_primitive_info* __restrict__ primitives,
+                                                                uint32_t* __restrict__ instance_counts, uint32_t num_primitives,
+                                                                uint32_t* __restrict__ draw_counts, const tr_draw_buffers out,
+                                                                const tr_two_layers two) {
+    demultiplex_draws_body<true>(primitives, instance_counts, num_primitives, draw_counts, out);
+    __threadfence();
+    __syncthreads();
+    const volatile uint32_t* counts_now = draw_counts;   // (written above by this workgroup)
+    for (uint32_t layer = 0; layer < 2u; ++layer) {
+        TR_PICK_LAYER(two, layer);
+        if (W.capacity_triangles != 0u)
+            raster_scan_draws_body(W.draws_a, W.draws_b, const_cast<const uint32_t*>(counts_now), W.buffer_a, num_primitives,
+                                   W.capacity_triangles, W.tri_base, W.counts);
+        __syncthreads();
+    }
+}
+//   the prefix over the work items of a small layer (up to kSmallScanChunks chunks of 4096 triangles): one workgroup per
+//   layer walks the chunks with a running total instead of the three launches of the chunked scan.
+constexpr uint32_t kSmallScanChunks = 4u;
+__global__ __launch_bounds__(1024) void raster_scan_items_small_kernel(const tr_two_layers two) {
+    TR_PICK_LAYER(two, blockIdx.y);
+    if (W.capacity_triangles == 0u) return;
+    __shared__ uint32_t lds[17];
+    const uint32_t n = W.counts->num_triangles;
+    uint32_t running = 0;
+    for (uint32_t first = 0; first < n; first += 1024u) {
+        const uint32_t t = first + threadIdx.x;
+        const uint32_t v = t < n ? W.item_counts[t] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, lds, total);
+        if (t < n) W.item_base[t] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) {
+        W.item_base[n] = running;
+        W.counts->num_items = running;
+    }
+}
 
 __global__ __launch_bounds__(1024) void raster_scan_draws_kernel(const tr_two_layers two, const uint32_t* __restrict__ draw_counts,
                                                                  uint32_t capacity_draws) {

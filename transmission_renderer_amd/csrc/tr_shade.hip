@@ -23,6 +23,20 @@
 
 using namespace tr;
 
+namespace tr {
+// The frame recorder's first launch: frustum culling and light assignment are independent of each other, and each is
+// a few microseconds of launch latency on its own.  Blocks [0, cull_blocks) cull, the rest assign lights.
+__global__ __launch_bounds__(256) void frame_front_kernel(const tr_cull_params cp, const tr_primitive_info* __restrict__ primitives,
+                                                          const tr_instance* __restrict__ instances,
+                                                          uint32_t* __restrict__ instance_counts, uint32_t cull_blocks,
+                                                          const tr_assign_params ap, const tr_alight* __restrict__ lights,
+                                                          const tr_cluster_aabb* __restrict__ clusters,
+                                                          uint32_t* __restrict__ cluster_counts, uint32_t* __restrict__ light_indices) {
+    if (blockIdx.x < cull_blocks) frustum_culling_body(cp, primitives, instances, instance_counts, blockIdx.x);
+    else assign_lights_body(ap, lights, clusters, cluster_counts, light_indices, blockIdx.x - cull_blocks);
+}
+}  // namespace tr
+
 struct tr_context {
     int device = 0;
     int32_t last_hip_error = 0;
@@ -68,6 +82,9 @@ struct tr_context {
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
     size_t vis_pixels = 0;
+    bool vis_clean = false;                            // both visibility buffers are all zero (stream order)
+    uint32_t vis_w = 0, vis_h = 0;                     // the frame size they are laid out for
+    bool counts_clean = false;                         // d_instance_counts is all zero (stream order): the fused frame path
     uint32_t num_cus = 256;
     bool occupancy_fallback = false;     // the occupancy query failed: the grid was sized for 8 waves per SIMD
     bool mip_tail_attr_set = false;      // hipFuncSetAttribute(mip_tail_kernel, 160 KiB of LDS) done on this context's device
@@ -799,6 +816,7 @@ tr_status tr_frustum_culling(tr_context* ctx, const void* primitives, uint32_t n
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     TR_HIP(ctx, hipMemsetAsync(instance_counts, 0, sizeof(uint32_t) * num_primitives, stream));   // src/main.rs:1668-1674
+    if (instance_counts == ctx->d_instance_counts) ctx->counts_clean = false;   // (left holding this frame's counts)
     if (num_instances == 0) return TR_OK;
     tr_cull_params p;
     p.pc = *push;
@@ -885,12 +903,18 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
     ctx->num_instances = g->num_instances;
     ctx->max_triangles[0] = (uint32_t)max_tris[0];
     ctx->max_triangles[1] = (uint32_t)max_tris[1];
+    ctx->counts_clean = false;
     return TR_OK;
 }
 
-tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
-                       const tr_push_constants* push, const tr_gbuffer_target* opaque,
-                       const tr_gbuffer_target* transmissive, void* stream_) {
+}  // extern "C"
+
+namespace {
+// fused_demux: the caller has NOT demultiplexed: the first launch does it (from the context's own instance counts,
+// which it leaves zeroed) together with the draw scans of both layers.
+tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
+                         const tr_push_constants* push, const tr_gbuffer_target* opaque,
+                         const tr_gbuffer_target* transmissive, void* stream_, bool fused_demux) {
     if (!ctx || !draw_counts || !draws || !push || !opaque || !transmissive) return TR_ERR_INVALID_ARGUMENT;
     for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k)
         if (!draws[k]) return TR_ERR_INVALID_ARGUMENT;
@@ -913,6 +937,12 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
         // both layers' visibility buffers and, behind them, their tile coverage maps: cleared by one fill
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 2u * (npix / 64u + 65536u + 16384u) * 4u));
         ctx->vis_pixels = npix;
+        ctx->vis_clean = false;
+    }
+    if (ctx->vis_w != w || ctx->vis_h != h) {   // another frame size lays the buffers out differently: the previous
+        ctx->vis_clean = false;                  // size's coverage words may lie where this size's visibility words do
+        ctx->vis_w = w;
+        ctx->vis_h = h;
     }
     ctx->d_vis[1] = ctx->d_vis[0] + npix;
     const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
@@ -954,16 +984,31 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
         W.planes.material_id = (uint32_t*)targets[layer]->material_id;
         W.tile_cover = ctx->d_tile_cover[layer];
     }
-    TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u + 2u * cover_tiles * 4u, stream));
+    // The visibility buffers are zero on entry: filled once after (re)allocation, and every resolve zeroes the words its
+    // frame set (raster_resolve_body).  Per frame only the two tile coverage maps are cleared (260 KB at 4K).
+    if (!ctx->vis_clean) TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u, stream));
+    ctx->vis_clean = false;   // (until this frame's resolve is enqueued)
+    TR_HIP(ctx, hipMemsetAsync(ctx->d_tile_cover[0], 0, 2u * cover_tiles * 4u, stream));
     const uint32_t max_cap = std::max(ctx->max_triangles[0], ctx->max_triangles[1]);
+    if (fused_demux) {
+        tr_draw_buffers out;
+        for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k) out.draws[k] = (tr_draw_command*)draws[k];
+        hipLaunchKernelGGL(frame_demux_scan_kernel, dim3(1), dim3(1024), 0, stream, (const tr_primitive_info*)ctx->d_primitives,
+                           ctx->d_instance_counts, ctx->num_primitives, (uint32_t*)draw_counts, out, two);
+    }
     if (max_cap > 0u) {
         const uint32_t chunks = (max_cap + kScanChunk - 1u) / kScanChunk;
-        hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1, 2), dim3(1024), 0, stream, two, (const uint32_t*)draw_counts,
-                           ctx->num_primitives);
+        if (!fused_demux)
+            hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1, 2), dim3(1024), 0, stream, two, (const uint32_t*)draw_counts,
+                               ctx->num_primitives);
         hipLaunchKernelGGL(raster_setup_kernel, dim3((max_cap + 255u) / 256u, 2), dim3(256), 0, stream, gv, fr, two);
-        hipLaunchKernelGGL(raster_scan_items_reduce_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
-        hipLaunchKernelGGL(raster_scan_items_chunks_kernel, dim3(1, 2), dim3(1024), 0, stream, two);
-        hipLaunchKernelGGL(raster_scan_items_apply_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
+        if (chunks <= kSmallScanChunks) {   // small layers: one launch for the work-item prefix
+            hipLaunchKernelGGL(raster_scan_items_small_kernel, dim3(1, 2), dim3(1024), 0, stream, two);
+        } else {
+            hipLaunchKernelGGL(raster_scan_items_reduce_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
+            hipLaunchKernelGGL(raster_scan_items_chunks_kernel, dim3(1, 2), dim3(1024), 0, stream, two);
+            hipLaunchKernelGGL(raster_scan_items_apply_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
+        }
         for (uint32_t layer = 0; layer < 2u; ++layer) {
             if (ctx->max_triangles[layer] == 0u) continue;
             const tr_layer_work& W = two.l[layer];
@@ -975,7 +1020,17 @@ tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* con
     }
     hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two, 0u);
     TR_HIP(ctx, hipGetLastError());
+    ctx->vis_clean = true;
     return TR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
+                       const tr_push_constants* push, const tr_gbuffer_target* opaque,
+                       const tr_gbuffer_target* transmissive, void* stream) {
+    return rasterize_impl(ctx, draw_counts, draws, push, opaque, transmissive, stream, false);
 }
 
 tr_status tr_draw_scene(tr_context* ctx, const tr_culling_push_constants* culling, const tr_push_constants* push,
@@ -1575,6 +1630,36 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
     zone_scope all(rec, "all commands");
     tr_status st;
+    void* draws[TR_NUM_DRAW_BUFFERS] = {ctx->d_draws[0], ctx->d_draws[1], ctx->d_draws[2], ctx->d_draws[3]};
+    if (!rec) {
+        // The untimed frame fuses its launch-latency-bound front end: [culling | light assignment] in one launch,
+        // [demultiplex + both layers' draw scans] in the next (inside rasterize_impl); the instance counts are zeroed
+        // by their last reader instead of a fill.  (The timed frame launches every pass on its own, below.)
+        hipStream_t s_ = (hipStream_t)stream;
+        TR_HIP(ctx, hipSetDevice(ctx->device));
+        if (!ctx->counts_clean) TR_HIP(ctx, hipMemsetAsync(ctx->d_instance_counts, 0, sizeof(uint32_t) * ctx->num_primitives, s_));
+        ctx->counts_clean = false;
+        tr_cull_params cp;
+        cp.pc = *f->culling;
+        cp.num_instances = ctx->num_instances;
+        cp.num_primitives = ctx->num_primitives;
+        tr_assign_params ap;
+        std::memcpy(ap.view_matrix, f->view_matrix, sizeof(ap.view_matrix));
+        std::memcpy(ap.view_rotation, f->view_rotation, sizeof(ap.view_rotation));
+        ap.num_lights = ctx->num_lights;
+        ap.num_clusters = f->num_clusters;
+        const uint32_t cull_blocks = (ctx->num_instances + 255u) / 256u, assign_blocks = (f->num_clusters + 3u) / 4u;
+        hipLaunchKernelGGL(frame_front_kernel, dim3(cull_blocks + assign_blocks), dim3(256), 0, s_, cp,
+                           (const tr_primitive_info*)ctx->d_primitives, (const tr_instance*)ctx->d_instances,
+                           ctx->d_instance_counts, cull_blocks, ap, (const tr_alight*)ctx->d_alights,
+                           (const tr_cluster_aabb*)f->cluster_aabbs, (uint32_t*)f->cluster_light_counts, (uint32_t*)f->light_indices);
+        TR_HIP(ctx, hipGetLastError());
+        st = tr_set_cluster_tables(ctx, f->cluster_light_counts, f->light_indices, f->num_clusters);
+        if (st != TR_OK) return st;
+        st = rasterize_impl(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream, true);
+        if (st != TR_OK) return st;
+        ctx->counts_clean = true;   // (the fused demultiplex zeroed what it read)
+    } else {
     {   // "frustum culling" (zeroing the counts + "frustum culling compute shader")
         zone_scope z(rec, "frustum culling");
         st = tr_frustum_culling(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instances, ctx->num_instances,
@@ -1589,7 +1674,6 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (st != TR_OK) return st;
     st = tr_set_cluster_tables(ctx, f->cluster_light_counts, f->light_indices, f->num_clusters);
     if (st != TR_OK) return st;
-    void* draws[TR_NUM_DRAW_BUFFERS] = {ctx->d_draws[0], ctx->d_draws[1], ctx->d_draws[2], ctx->d_draws[3]};
     {
         zone_scope z(rec, "demultiplex draws compute shader");
         st = tr_demultiplex_draws(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instance_counts, ctx->d_draw_counts,
@@ -1601,6 +1685,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         st = tr_rasterize(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream);
     }
     if (st != TR_OK) return st;
+    }
     // "main opaque" -> "opaque framebuffer mipchain" -> "opaque transmissive objects"
     tr_gbuffer layers[2];
     const tr_gbuffer_target* targets[2] = {&f->opaque_layer, &f->transmissive_layer};
