@@ -388,6 +388,120 @@ def test_4k_properties(renderer, ggx_lut):
     assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (_rmse(e), np.abs(e).max())
 
 
+def _oracle_rows(bind, scene_size, rows, tex, fp64=True, opaque=False):
+    """The oracle on single rows of a big frame: {y: (row of the un-rounded plane)}."""
+    w, h = scene_size
+    out = {}
+    for y in rows:
+        band = synthetic.make_gbuffer(w, h, rows=(int(y), int(y) + 1))
+        if opaque:
+            _, ref, _ = oracle.shade_opaque(bind, band, fp64=fp64, want_mip0=False)
+        else:
+            ref = np.zeros((h, w, 4), dtype=np.float64 if fp64 else np.float32)
+            oracle.shade_transmission(bind, band, tex, hdr_f32=ref, fp64=fp64)
+        out[int(y)] = ref[int(y)]
+    return out
+
+
+def test_config2_1080p_opaque_mips_transmissive_end_to_end(renderer, ggx_lut):
+    """BASELINE config 2 at its full size: 1920x1080, one punctual light, opaque -> mip chain -> transmissive through
+    record(): the mip chain bit-exact against the oracle's from the GPU's own level 0, both passes against the oracle on
+    rows spread over the frame, determinism, and 4 row bands == the whole frame."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    w, h = 1920, 1080
+    scene = synthetic.make_scene(w, h, num_point_lights=1, coverage="holes")
+    _upload_scene(r, scene)
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    pyr = OpaquePyramid(w, h, r.device)
+    assert pyr.levels == 11
+    hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+    r.record(g, g, scene["uniforms"], scene["push"], hdr, pyr)
+    torch.cuda.synchronize()
+    frame = hdr.cpu().numpy()
+    # (1) the chain from the GPU's level 0, bit for bit
+    tex = oracle.new_pyramid(w, h, pyr.level(0).cpu().numpy())
+    oracle.generate_mips(w, h, tex)
+    np.testing.assert_array_equal(pyr.texels.cpu().numpy().view(np.uint16), tex.view(np.uint16))
+    # (2) the opaque pass and (3) the transmissive pass (over the GPU's own pyramid) against the oracle on 10 rows
+    bind = oracle.SceneBinding(scene, ggx_lut)
+    rows = np.linspace(0, h - 1, 10).astype(int)
+    o32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    t32 = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    r.shade_opaque(g, scene["uniforms"], scene["push"], o32, None)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
+    torch.cuda.synchronize()
+    for got, refs, what in ((o32.cpu().numpy(), _oracle_rows(bind, (w, h), rows, tex, opaque=True), "opaque"),
+                            (t32.cpu().numpy(), _oracle_rows(bind, (w, h), rows, tex), "transmissive")):
+        covered = scene["gbuffer"]["material_id"][rows] != wire.NOT_COVERED
+        e = np.stack([_norm_err(got[y], refs[int(y)]) for y in rows])
+        e = np.where(covered[..., None], e, 0.0)
+        assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (what, _rmse(e), np.abs(e).max())
+    # (4) deterministic, and 4 row bands of 270 rows reproduce the frame
+    hdr2 = torch.zeros_like(hdr)
+    pyr2 = OpaquePyramid(w, h, r.device)
+    for k in range(4):
+        r.shade_opaque(g, scene["uniforms"], scene["push"], hdr2, pyr2, rect=(0, k * 272, w, min((k + 1) * 272, h)))
+    r.generate_mips(pyr2)
+    for k in range(4):
+        r.shade_transmission(g, scene["uniforms"], scene["push"], pyr2, hdr2, rect=(0, k * 272, w, min((k + 1) * 272, h)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(hdr2.cpu().numpy().view(np.uint16), frame.view(np.uint16))
+
+
+def test_config3_4k_four_lights_roughness_override(renderer, ggx_lut):
+    """BASELINE config 3 at its full size: 3840x2160, sun + 4 punctual lights, --roughness-override 0.25, the full
+    12-level chain: the oracle on rows spread over the frame, determinism, 8 band == whole frame, and linearity in
+    the light intensities."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    w, h = 3840, 2160
+    scene = synthetic.make_scene(w, h, num_point_lights=4, roughness_override=0.25)
+    assert all(m.roughness_factor == 0.25 for m in scene["materials"]) and len(scene["lights"]) == 4
+    _upload_scene(r, scene)
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    pyr = OpaquePyramid(w, h, r.device)
+    assert pyr.levels == 12
+    pyr.level(0).copy_(torch.from_numpy(synthetic.make_opaque_mip0(w, h)).to(r.device))
+    r.generate_mips(pyr)
+    a = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+    b_ = torch.zeros_like(a)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, a)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, b_)
+    assert torch.equal(a, b_)
+    c = torch.zeros_like(a)
+    for k in range(8):
+        r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, c, rect=(0, k * 272, w, min((k + 1) * 272, h)))
+    assert torch.equal(a, c)
+    bind = oracle.SceneBinding(scene, ggx_lut)
+    tex = pyr.texels.cpu().numpy()
+    rows = np.linspace(0, h - 1, 8).astype(int)
+    refs = _oracle_rows(bind, (w, h), rows, tex)
+    got = a.cpu().numpy()
+    e = np.stack([_norm_err(got[y], refs[int(y)]) for y in rows])
+    assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (_rmse(e), np.abs(e).max())
+    refs32 = _oracle_rows(bind, (w, h), rows, tex, fp64=False)                      # the pinned fp32 oracle, all pixels
+    e32 = np.stack([_norm_err(got[y], refs32[int(y)]) for y in rows])
+    assert _rmse(e32).max() <= 1e-4, _rmse(e32)
+    # lights x 2 (the sun off): the punctual-light part of the frame doubles
+    scene["uniforms"].sun_intensity = (C.c_float * 3)(0.0, 0.0, 0.0)
+    dark = OpaquePyramid(w, h, r.device)      # a black backdrop and no emission: only the lights are left
+    for m in scene["materials"]:
+        m.emissive_factor = (C.c_float * 3)(0.0, 0.0, 0.0)
+    _upload_scene(r, scene)
+    one = torch.zeros_like(a)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], dark, one)
+    for l in scene["lights"]:
+        for k in range(3):
+            l.colour_emission_and_falloff_distance_sq[k] *= 2
+    _upload_scene(r, scene)
+    two = torch.zeros_like(a)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], dark, two)
+    torch.cuda.synchronize()
+    rel = ((two[..., :3] - 2 * one[..., :3]).abs() / (2 * one[..., :3].abs() + 1e-6)).max().item()
+    assert rel <= 2e-5, rel
+
+
 def test_frame_recorded_into_a_hip_graph_replays_bit_exact(renderer, ggx_lut):
     """The launch-bound part of a frame (opaque -> 2 mip launches -> transmissive -> tonemap) captured once into a
     HIP graph and replayed: every entry point only enqueues on the caller's stream once its tables are warm, so
