@@ -12,6 +12,15 @@ import numpy as np, torch
 sys.path.insert(0, os.environ["TR_ROOT"])
 from transmission_renderer_amd import _lib
 _lib.LIB_PATH = os.environ["TR_AB_LIB"]
+class _Tolerant(C.CDLL):   # builds of older commits lack the newer entry points: bind what exists (experiments only)
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if name.startswith("tr_") and name != "tr_debug_read_timing":
+                return type("missing", (), {})()
+            raise
+C.CDLL = _Tolerant
 from transmission_renderer_amd import synthetic, wire
 from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer
 w, h, nl = 3840, 2160, int(os.environ.get("TR_AB_LIGHTS", "1"))

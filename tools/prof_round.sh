@@ -5,7 +5,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-round}
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_default -o t -- python3 $R/bench.py > $OUT/bench_default.log 2>&1
 python3 $R/tools/make_demo_gltf.py $OUT/demo.glb > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pipeline_gltf -o t -- python3 -m transmission_renderer_amd.cli $OUT/demo.glb --width 3840 --height 2160 --out $OUT/demo_4k.png > $OUT/pipeline_gltf.log 2>&1
