@@ -248,7 +248,7 @@ def run_rank(args) -> int:
     r.upload_ggx_lut(lut)
     r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(dev),
                          torch.from_numpy(scene["light_indices"].view(np.int32)).to(dev))
-    g = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh, rows=(y0, y1)), dev)   # this rank's screen tile only
+    g = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh, rows=(y0, y1) if y1 > y0 else (0, 1)), dev)   # this rank's screen tile only
     pyr = OpaquePyramid(fw, fh, dev)                                                  # replicated read-only input
     pyr.level(0).copy_(make_mip0_torch(fw, fh, dev))
     r.generate_mips(pyr)
@@ -265,7 +265,8 @@ def run_rank(args) -> int:
     launches = {"count": 0}
 
     def shade(buf):
-        r.shade_transmission(g, uniforms, push, pyr, buf, rect)
+        if y1 > y0:     # (a band can be empty when the height is far from a multiple of 4 N; it still joins the gathers)
+            r.shade_transmission(g, uniforms, push, pyr, buf, rect)
         launches["count"] += 1
 
     def step(k):
