@@ -110,7 +110,8 @@ struct alignas(16) tr_dmat {
     uint32_t lut_row0;     // GGX LUT row offsets into the pair table (entries)
     uint32_t lut_row1;
     uint32_t flags;        // bit0: finite attenuation distance; bit1: transmission_factor != 0;
-                           // bit2: the material has texture slots (shaded by the per-pixel material path)
+                           // bit2: the material has texture slots (shaded by the per-pixel material path);
+                           // bit3: ... of the lite class (lite_dmat)
     float ior_clamp;       // clamp(2 ior - 2, 0, 1)
     float f0_dielectric;   // ((ior - 1) / (ior + 1))^2
     float bt_a[3];         // k[1] * (1 - f0): the btdf lobe is accumulated as sum(I D'V') and sum(I D'V' p') and
@@ -161,6 +162,8 @@ struct tr_frame_params {
     uint32_t lut_width, lut_stride;  // pair-table stride in entries (= lut_width + 2)
     uint32_t lut_height;
     uint32_t pyr_levels;
+    uint32_t solo_full;          // TEX = 2 launch only: every uploaded material is of the full class, there is no TEX = 1
+                                 // launch beside this one: it sweeps the whole rect and writes the clear colour itself
     uint32_t ablate;             // profiling only (TR_ABLATE env): bit0 no pyramid taps, bit1 no LUT, bit2 no sun,
                                  // bit3 no punctual lights, bit4 no refraction math
 };
@@ -198,6 +201,8 @@ struct tr_launch {
     const uint32_t* tex_arena;          // RGBA8 texels of every chain
     const float* srgb_to_linear;        // 256 entries
     const float* slice_thr;             // [slice_max + 2] depth thresholds of get_depth_slice, see depth_slice()
+    const uint32_t* tile_list;          // optional (TEX = 2 launches inside the frame recorder): the block tiles that hold
+    const uint32_t* tile_list_count;    // fragments of a full-class material, and their number (raster_resolve_body)
     const uint32_t* tile_cover;         // optional: one word per 64x4 block tile of the frame, 0 = the layer has no fragment there
     uint32_t* tile_counters;            // per XCD kSubCounters tile counters + one count of finished waves, 256 bytes apart
 };
@@ -223,6 +228,28 @@ __device__ __forceinline__ float mat_c_diff(const lane_dmat* m, int k) {
 }
 __device__ __forceinline__ float mat_bt_a(const lane_dmat* m, int k) { return m->k[1] * (1.0f - m->f0[k]); }
 __device__ __forceinline__ float mat_bt_b(const lane_dmat* m, int k) { return m->k[1] * m->df[k]; }
+
+// The "lite" material class: a dielectric (metallic_factor == 0) whose only bound texture is the base colour — the most
+// common textured glTF material.  Everything the specular lobes read stays what the material table holds (f0 does not
+// depend on the base colour when metallic is 0), so the pixel keeps the scalar record and carries just the sampled base
+// colour per lane: three registers instead of the per-lane record's thirty.
+struct lite_dmat {
+    cdmat* m;
+    float diffuse[3];      // diffuse_factor.rgb * sample (lib.rs:65-69)
+};
+__device__ __forceinline__ const lite_dmat* launder(const lite_dmat* p) { return p; }
+// the record the material-constant reads go to
+__device__ __forceinline__ cdmat* mat_base(cdmat* m) { return m; }
+__device__ __forceinline__ const lane_dmat* mat_base(const lane_dmat* m) { return m; }
+__device__ __forceinline__ cdmat* mat_base(const lite_dmat* m) { return launder(m->m); }
+// the values a base-colour texture changes
+__device__ __forceinline__ float mat_diffuse(const TR_CONSTANT tr_dmat* m, int k) { return m->diffuse[k]; }
+__device__ __forceinline__ float mat_diffuse(const lane_dmat* m, int k) { return m->diffuse[k]; }
+__device__ __forceinline__ float mat_diffuse(const lite_dmat* m, int k) { return m->diffuse[k]; }
+__device__ __forceinline__ float mat_c_diff(const lite_dmat* m, int k) {
+    const float diff = m->diffuse[k];
+    return (diff + (0.0f - diff) * 0.0f) * kFrac1Pi;                 // lerp(diffuse, 0, metallic = 0) / pi
+}
 
 // ------------------------------------------------------------------------ one light
 // Accumulators of one pixel over its lights.
@@ -709,7 +736,8 @@ __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, 
 template <bool TRANSMISSIVE, class MatP>
 __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 ns, uint32_t lane,
                                           const cluster_list& cl TR_TIMER_PARAM) {
-    constexpr bool SCALAR_MATERIAL = std::is_same<MatP, cdmat*>::value;
+    // (roughness, ior and the LUT line are the table's: one level pair and one LUT line per wave)
+    constexpr bool SCALAR_MATERIAL = std::is_same<MatP, cdmat*>::value || std::is_same<MatP, const lite_dmat*>::value;
     // ================= phase 1: frame of the pixel, cluster list request, refraction taps =================
     L = launder(L);
     m = launder(m);
@@ -741,14 +769,15 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     float len = 0.0f;
     // transmission_factor == 0 (scalar): lib.rs:157-159 multiplies the whole transmission term by zero, so the
     // refraction taps, the LUT and the btdf lobes are skipped for such materials
-    const bool transmits = TRANSMISSIVE && (m->flags & 2u);
+    const bool transmits = TRANSMISSIVE && (mat_base(m)->flags & 2u);
     auto issue_taps = [&]() {
     if (transmits) {
+        const auto mb = mat_base(m);
         // refract(-v, n, ior) :248-256 ; unit length by construction (Snell), so no re-normalise
-        float eta = m->eta;
+        float eta = mb->eta;
         float k = fmaf(-eta * eta, fmaf(-nov_raw, nov_raw, 1.0f), 1.0f);
         float cn = fmaf(-eta, nov_raw, fast_sqrt(k));   // eta * n.i + sqrt(k), n.i = -n.v
-        len = m->thickness * ns.w;                      // thickness * model_scale :264
+        len = mb->thickness * ns.w;                      // thickness * model_scale :264
         float ex = fmaf(fmaf(-eta, v.x, -cn * n.x), len, pos.x);
         float ey = fmaf(fmaf(-eta, v.y, -cn * n.y), len, pos.y);
         float ez = fmaf(fmaf(-eta, v.z, -cn * n.z), len, pos.z);
@@ -759,14 +788,14 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         float hw = 0.5f * rcp(cw);                      // (clip.xy / clip.w + 1) / 2  :330-332
         float tu = fmaf(cx, hw, 0.5f);
         float tv = fmaf(cy, hw, 0.5f);
-        float lod = L->fp.log2_fb_width * m->rough_ior; // :334-335
+        float lod = L->fp.log2_fb_width * mb->rough_ior; // :334-335
         if (!TR_ABLATE(L, 1u)) pyramid_issue<SCALAR_MATERIAL>(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane);
         else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
         if constexpr (SCALAR_MATERIAL) {
-            lut_line_issue(lf, L->lut_lines, (float)L->fp.lut_width, m->lut_line, nov_raw);
+            lut_line_issue(lf, L->lut_lines, (float)L->fp.lut_width, mb->lut_line, nov_raw);
         } else {   // per-pixel roughness: the row pair is found here, not carried through the light loop
             uint32_t row0, row1;
-            lut_rows(m->rough, L->fp.lut_height, L->fp.lut_stride, lf.fy, row0, row1);
+            lut_rows(mb->rough, L->fp.lut_height, L->fp.lut_stride, lf.fy, row0, row1);
             lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, row0, row1, nov_raw);
         }
     }
@@ -783,7 +812,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     if (!TR_SUN_FIRST || TR_ABLATION) acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto lights_phase = [&]() {
         claunch* L2 = launder(L);
-        MatP m2 = launder(m);
+        const auto m2 = mat_base(launder(m));
         {
             const v2f ra = pk_fma(splat(nov * nov), v2f{m2->oma2[0], m2->oma2[1]}, v2f{m2->a2[0], m2->a2[1]});
             px.g_nov = v2f{fast_sqrt(ra.x), TRANSMISSIVE ? fast_sqrt(ra.y) : 0.0f};
@@ -797,7 +826,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     // punctual lights (lighting.rs:55-92 / 179-217)
     auto punctual_uniform = [&]() {   // one cluster for the whole tile: count, list and lights all through the scalar unit
         claunch* L2 = launder(L);
-        MatP m2 = launder(m);
+        const auto m2 = mat_base(launder(m));
         cdlight* lights = as_constant(L2->lights);
         {
             const uint32_t n = cl.s_num;
@@ -812,7 +841,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     };
     auto punctual_per_lane = [&]() {
         claunch* L2 = launder(L);
-        MatP m2 = launder(m);
+        const auto m2 = mat_base(launder(m));
         cdlight* lights = as_constant(L2->lights);
         constexpr uint32_t kDone = 0xFFFFFFFFu;   // a lane whose list is exhausted
         uint32_t i = 0;
@@ -838,8 +867,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     // ================= phase 4: resolve the taps, composite =================
     auto finish = [&]() -> f3 {
         claunch* L4 = launder(L);
-        MatP m4 = launder(m);
-        f3 diffuse = {acc.d.x * mat_c_diff(m4, 0), acc.d.y * mat_c_diff(m4, 1), acc.d.z * mat_c_diff(m4, 2)};
+        MatP mo = launder(m);                  // what a base-colour texture changes is read through `mo`,
+        const auto m4 = mat_base(mo);          // every other constant from the record
+        f3 diffuse = {acc.d.x * mat_c_diff(mo, 0), acc.d.y * mat_c_diff(mo, 1), acc.d.z * mat_c_diff(mo, 2)};
 
         if (transmits) {
             // ---- ibl_volume_refraction, part 2 (:337-353)
@@ -857,9 +887,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
             const float bx = fmaf(-mat_bt_b(m4, 0), acc.tb.x, mat_bt_a(m4, 0) * acc.ta.x);   // sum over lights of transmission_btdf
             const float by = fmaf(-mat_bt_b(m4, 1), acc.tb.y, mat_bt_a(m4, 1) * acc.ta.y);
             const float bz = fmaf(-mat_bt_b(m4, 2), acc.tb.z, mat_bt_a(m4, 2) * acc.ta.z);
-            float tx = fmaf(1.0f - fmaf(m4->f0[0], AB.x, fb), T.x, bx) * m4->diffuse[0];
-            float ty = fmaf(1.0f - fmaf(m4->f0[1], AB.x, fb), T.y, by) * m4->diffuse[1];
-            float tz = fmaf(1.0f - fmaf(m4->f0[2], AB.x, fb), T.z, bz) * m4->diffuse[2];
+            float tx = fmaf(1.0f - fmaf(m4->f0[0], AB.x, fb), T.x, bx) * mat_diffuse(mo, 0);
+            float ty = fmaf(1.0f - fmaf(m4->f0[1], AB.x, fb), T.y, by) * mat_diffuse(mo, 1);
+            float tz = fmaf(1.0f - fmaf(m4->f0[2], AB.x, fb), T.z, bz) * mat_diffuse(mo, 2);
             // lib.rs:157-159: real = tf * transmission; diffuse = lerp(diffuse, real, tf)
             float tf = m4->transmission_factor;
             diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
@@ -1042,6 +1072,32 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd, ns, lane, cl TR_TIMER_ARG);
 }
 
+// ------------------------------------------------------------------------ one pixel of a "lite" textured material
+// The front end for a material of the lite class (lite_dmat): one implicit-LOD tap set of the base-colour texture
+// (lib.rs:65-69, 190-194), then the untextured pixel with the sampled colour.
+template <bool TRANSMISSIVE>
+__device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cdmat* dm, float4 pd, float4 ns, float2 uv,
+                                               const uv_derivs& duv, uint32_t lane, const cluster_list& cl,
+                                               const float* __restrict__ lds_srgb TR_TIMER_PARAM) {
+    L = launder(L);
+    const TR_CONSTANT tr_material_info* mi = as_constant(L->materials) + material;
+    cdtex* t = as_constant(L->textures) + mi->textures.diffuse;
+    tex_geom g;
+    tex_taps taps;
+    tex_geom_compute(g, t, uv.x, uv.y, duv);
+    texture_issue_shared(taps, L->tex_arena, t, g);
+    const bool srgb = t->srgb != 0u;
+    lite_dmat lm;
+    lm.m = dm;
+    lm.diffuse[0] = mi->diffuse_factor[0] * texture_resolve_shared<0>(taps, g, srgb, lds_srgb);
+    lm.diffuse[1] = mi->diffuse_factor[1] * texture_resolve_shared<1>(taps, g, srgb, lds_srgb);
+    lm.diffuse[2] = mi->diffuse_factor[2] * texture_resolve_shared<2>(taps, g, srgb, lds_srgb);
+    // The colour is first USED at the end of the pixel; left to itself the optimiser sinks the whole filter down there
+    // and keeps the eight taps, their weights and the decode look-ups alive across the light loop (+40 registers).
+    asm volatile("" : "+v"(lm.diffuse[0]), "+v"(lm.diffuse[1]), "+v"(lm.diffuse[2]));
+    return shade_pixel<TRANSMISSIVE, const lite_dmat*>(L, &lm, pd, ns, lane, cl TR_TIMER_ARG);
+}
+
 // ------------------------------------------------------------------------ the shading kernel
 // Grid: 8 * k workgroups, k per XCD (hardware workgroup b runs on XCD b % 8), of one wave each (TR_WAVE_BLOCKS),
 // kGridRounds times what is resident.  The 64x4-pixel block tiles of the rect are cut into 8
@@ -1095,8 +1151,18 @@ struct tile_regs {
 #ifndef TR_WAVES_ATTR
 #define TR_WAVES_ATTR
 #endif
-template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, bool TEXTURED = false>
+// TEX: which material classes the launch shades (the host launches what the uploaded materials need, see tr_shade.hip):
+//   0  no uploaded material has a texture slot: every material through the scalar record;
+//   1  untextured materials and the LITE class (lite_dmat: only a base-colour texture, dielectric); pixels of FULL-class
+//      materials are left alone (their target texels too);
+//   2  the FULL class only (any other combination of texture slots: shade_pixel_textured), everything else left alone.
+// A frame with textured materials is one launch of TEX = 1 (which also writes the opaque pass's clear colour) plus, when
+// a full-class material is uploaded, one of TEX = 2: the common materials do not pay for the registers of the eight-slot
+// sampling front end (120 VGPRs = 4 waves per SIMD; TEX = 1 holds 7-8).
+constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2;
+template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, int TEX = kTexNone>
 __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
+    constexpr bool TEXTURED = TEX != kTexNone;
     const uint32_t block_waves = blockDim.x >> 6;   // 4, or 1 (TR_WAVE_BLOCKS: one wave per workgroup)
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
@@ -1115,8 +1181,13 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     const uint32_t ntiles = L->fp.tiles_x * L->fp.tiles_y;
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = ntiles >> 3, rem = ntiles & 7u;
-    const uint32_t band_start = xcd * per + min(xcd, rem);
-    const uint32_t band_len = per + (xcd < rem ? 1u : 0u);
+    // A TEX = 2 launch inside the frame recorder walks the resolve's list of the block tiles that hold fragments of its
+    // class instead of the rect: a whole-frame sweep that skips nearly every tile still pays the scalar round trips of
+    // each (75 us at 4K for the demo frame's one small full-class object at 4 waves per SIMD).
+    const bool listed = TEX == kTexFull && L->tile_list != nullptr;
+    const uint32_t listed_tiles = listed ? as_constant(L->tile_list_count)[0] : 0u;
+    const uint32_t band_start = listed ? 0u : xcd * per + min(xcd, rem);
+    const uint32_t band_len = listed ? listed_tiles : per + (xcd < rem ? 1u : 0u);
 
     // Out-of-rect lanes read a clamped (valid) pixel and are masked later.  There is no software prefetch of the
     // next tile: its 13 registers cost two of the eight resident waves per SIMD, and even scheduled so that nothing
@@ -1124,7 +1195,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
     auto fetch = [&](uint32_t j, tile_regs& t) {
         claunch* F = launder(L);
-        const uint32_t tile = band_start + (j >> 2);
+        const uint32_t tile = listed ? as_constant(F->tile_list)[j >> 2] : band_start + (j >> 2);
         // tile / tiles_x without the vector unit: q = mulhi(tile, floor(2^32 / d)) is the quotient or one less
         uint32_t tyi = __umulhi(tile, F->fp.tiles_x_magic);
         uint32_t txi = tile - tyi * F->fp.tiles_x;
@@ -1135,13 +1206,18 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         txi = txi * 4u + (j & 3u);
         t.px = F->fp.rect_x0 + txi * kWaveTileW + lx;
         t.py = F->fp.rect_y0 + tyi * kWaveTileH + ly;
-        if (!TR_TILE_8X8 && F->tile_cover && as_constant(F->tile_cover)[tile] == 0u) {   // (scalar) nothing rasterised into this block tile
+        // (scalar) the coverage word of the block tile, when the frame recorder rasterised the layer itself: 0 = nothing
+        // landed there; bit 1 / bit 2 = fragments of a full-class material / of any other (raster_resolve_body): a
+        // launch skips the tiles that hold nothing of the classes it shades without touching their planes
+        const uint32_t cover = (!TR_TILE_8X8 && F->tile_cover) ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
+        if (cover == 0u || (TEX == kTexFull && !(cover & 2u))) {
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
             t.uv = float2{0.f, 0.f};
             t.cluster_x = t.cluster_y_term = 0u;
             return;
         }
+        const uint32_t px_ = t.px, py_ = t.py;
         const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
         const uint32_t gpix = mad24(cy - F->fp.g_origin_y, F->fp.g_width, cx - F->fp.g_origin_x);
         if (TR_ABLATE(F, 64u)) {  // profiling only: no G-buffer traffic (synthetic per-lane inputs)
@@ -1155,7 +1231,26 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         // lists the kernel keeps re-reading from L2 (measured 115 -> 111 us)
         typedef float f4v __attribute__((ext_vector_type(4)));
         typedef float f2v __attribute__((ext_vector_type(2)));
-        t.mat = ld_stream<uint32_t>(F->material_id, gpix * 4u);
+        if (TEX == kTexFull && !listed && !F->fp.solo_full) {
+            // (a FULL-class launch beside a TEX = 1 launch without a tile list — the host always provides one, this is
+            //  the safety net: material ids (4 B per pixel) and their class first, the other planes (40 B per pixel)
+            //  only where one of the tile's pixels is this launch's to shade)
+            const uint32_t id = ld<uint32_t>(F->material_id, gpix * 4u);
+            const bool in_rect = px_ < F->fp.rect_x1 && py_ < F->fp.rect_y1;
+            uint32_t cls = 0u;
+            if (id != TR_NOT_COVERED && in_rect)
+                cls = ld<uint32_t>(F->dmats, id * (uint32_t)sizeof(tr_dmat) + (uint32_t)offsetof(tr_dmat, flags)) & 12u;
+            if (ballot(cls == 4u) == 0ull) {
+                t.mat = TR_NOT_COVERED;
+                t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
+                t.uv = float2{0.f, 0.f};
+                t.cluster_x = t.cluster_y_term = 0u;
+                return;
+            }
+            t.mat = id;
+        } else {
+            t.mat = ld_stream<uint32_t>(F->material_id, gpix * 4u);
+        }
         { const f4v a = ld_stream<f4v>(F->pos_depth, gpix * 16u); t.pd = float4{a.x, a.y, a.z, a.w}; }
         { const f4v a = ld_stream<f4v>(F->nrm_scale, gpix * 16u); t.ns = float4{a.x, a.y, a.z, a.w}; }
         if constexpr (TEXTURED) { const f2v a = ld_stream<f2v>(F->uv, gpix * 8u); t.uv = float2{a.x, a.y}; }
@@ -1179,7 +1274,8 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     // longer than the mean) but measured slower (135 vs 100 us): a tile then takes 16.6k instead of 11.7k cycles,
     // the waves of a block no longer touching neighbouring memory at the same time.
     const uint32_t wave_tiles = band_len * 4u;
-    const uint32_t slot = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * block_waves + (threadIdx.x >> 6));
+    const uint32_t slot = listed ? __builtin_amdgcn_readfirstlane(blockIdx.x * block_waves + (threadIdx.x >> 6))
+                                 : __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * block_waves + (threadIdx.x >> 6));
 #if TR_DYNAMIC_TILES
     // mode 1: every wave takes 16x4 tiles on its own; mode 2: the block's first wave takes a 64x4 block tile for the four
     // waves (shared through LDS behind the block's barrier), which keeps them on neighbouring memory at the same time
@@ -1243,9 +1339,11 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         claunch* S = launder(L);
         const bool inside = cur.px < S->fp.rect_x1 && cur.py < S->fp.rect_y1;
         const bool active = inside && cur.mat != TR_NOT_COVERED;
+        const bool cur_mat_uncovered = cur.mat == TR_NOT_COVERED;
         const uint32_t key = inside ? cur.mat : TR_NOT_COVERED;   // the material of a lane that has work
         f3 out = {0.f, 0.f, 0.f};  // clear colour of the opaque pass (src/main.rs:1592-1601)
         uint64_t todo = ballot(key != TR_NOT_COVERED);
+        uint64_t shaded = 0ull;   // TEX != 0: the lanes whose material class this launch shades
 #if TR_DYNAMIC_TILES
         request = __builtin_amdgcn_readfirstlane(request);   // (older than the plane loads: it is here) into a scalar register
 #endif
@@ -1281,19 +1379,29 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
                             nvz = -(S->fp.view_position[2] - cur.pd.z);
                 auto ddx = [&](float v) { const float d = (swz_x(v) - v) * sgn_x; return cov_x ? d : 0.0f; };
                 auto ddy = [&](float v) { const float d = (swz_y(v) - v) * sgn_y; return cov_y ? d : 0.0f; };
-                qd.dp_dx = {ddx(nvx), ddx(nvy), ddx(nvz)};
-                qd.dp_dy = {ddy(nvx), ddy(nvy), ddy(nvz)};
+                if constexpr (TEX == kTexFull) {   // (only normal mapping differentiates the view vector)
+                    qd.dp_dx = {ddx(nvx), ddx(nvy), ddx(nvz)};
+                    qd.dp_dy = {ddy(nvx), ddy(nvy), ddy(nvz)};
+                }
                 qd.uv = {ddx(cur.uv.x), ddx(cur.uv.y), ddy(cur.uv.x), ddy(cur.uv.y)};
             }
             while (todo) {
                 const int l0 = __ffsll((unsigned long long)todo) - 1;
                 const uint32_t mk = (uint32_t)__builtin_amdgcn_readlane((int)key, l0);
                 const uint32_t m0 = opaque(mk);   // tables are indexed with m0, the branch compares mk (see opaque())
-                todo &= ~ballot(key == mk);
+                const uint64_t group = ballot(key == mk);
+                todo &= ~group;
+                if constexpr (TEXTURED) {   // (scalar) is this material's class shaded by this launch?
+                    const uint32_t cls = dmats[m0].flags & 12u;   // 0 untextured, 12 lite, 4 full
+                    if (TEX == kTexLite ? cls == 4u : cls != 4u) continue;
+                    shaded |= group;
+                }
                 if (key == mk) {
-                    if constexpr (TEXTURED) {
-                        if (dmats[m0].flags & 4u)
-                            out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb TR_TIMER_ARG);
+                    if constexpr (TEX == kTexFull) {
+                        out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb TR_TIMER_ARG);
+                    } else if constexpr (TEX == kTexLite) {
+                        if (dmats[m0].flags & 8u)
+                            out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane, cl, lds_srgb TR_TIMER_ARG);
                         else
                             out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
                     } else {
@@ -1308,13 +1416,21 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
 #if TR_DYNAMIC_TILES
         j = tile_of(share(grabber ? resolve(request) : 0u));
 #else
-        j += (gridDim.x >> 3) * block_waves;
+        j += (listed ? gridDim.x : (gridDim.x >> 3)) * block_waves;
 #endif
 #if TR_LOAD_BEFORE_STORE
         if (j < wave_tiles) fetch(j, cur);
 #endif
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
-        if ((TRANSMISSIVE ? active : inside) && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
+        // (with textured materials uploaded: a launch writes the pixels of the classes it shades; the TEX = 1 launch
+        //  also writes the opaque pass's clear colour)
+        bool write = TRANSMISSIVE ? active : inside;
+        if constexpr (TEXTURED) {
+            const bool mine = ((shaded >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+            const bool clears = TEX == kTexLite || S->fp.solo_full != 0u;   // (the launch that writes the opaque pass's clear colour)
+            write = TRANSMISSIVE ? mine : (clears ? (inside && (mine || cur_mat_uncovered)) : mine);
+        }
+        if (write && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
             claunch* W = launder(L);
             const uint32_t pix = mad24(out_py, W->fp.width, out_px);
             if constexpr (sizeof(OutT) == 8) {
@@ -1370,6 +1486,28 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
 #endif
 }
 
+// The block tiles (64x4 pixels, numbered like shade_kernel numbers the rect's) that hold a pixel of a full-class material,
+// for TEX = 2 launches outside the frame recorder (there the resolve makes the list): one workgroup per block tile.
+struct tr_classify_params {
+    uint32_t g_width, g_origin_x, g_origin_y;
+    uint32_t rect_x0, rect_y0, rect_x1, rect_y1, tiles_x;
+};
+__global__ __launch_bounds__(256) void classify_tiles_kernel(const uint32_t* __restrict__ material_id, const tr_classify_params p,
+                                                             const uint32_t* __restrict__ material_flags, uint32_t flags_stride,
+                                                             uint32_t num_materials, uint32_t* __restrict__ list,
+                                                             uint32_t* __restrict__ count) {
+    __shared__ uint32_t any;
+    if (threadIdx.x == 0) any = 0u;
+    __syncthreads();
+    const uint32_t px = p.rect_x0 + blockIdx.x * 64u + (threadIdx.x & 63u), py = p.rect_y0 + blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (px < p.rect_x1 && py < p.rect_y1) {
+        const uint32_t id = material_id[(size_t)(py - p.g_origin_y) * p.g_width + (px - p.g_origin_x)];
+        if (id != TR_NOT_COVERED && id < num_materials && (material_flags[(size_t)id * flags_stride] & 12u) == 4u) any = 1u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && any) list[atomicAdd(count, 1u)] = blockIdx.y * p.tiles_x + blockIdx.x;
+}
+
 // LightClusterCoefficients::get_depth_slice over an array (tr_get_depth_slice): the passes' own device function.
 __global__ __launch_bounds__(256) void depth_slice_kernel(const float* __restrict__ depth, uint32_t count, const slice_params sp,
                                                           uint32_t* __restrict__ out) {
@@ -1405,7 +1543,11 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
     const tr_textures& t = mi.textures;
     const bool textured = t.diffuse != -1 || t.metallic_roughness != -1 || t.normal_map != -1 || t.emissive != -1 ||
                           t.transmission != -1 || t.thickness != -1 || t.specular != -1 || t.specular_colour != -1;
-    d.flags = (has_atten ? 1u : 0u) | (mi.transmission_factor != 0.0f ? 2u : 0u) | (textured ? 4u : 0u);
+    // the lite class (bit 3, always with bit 2): only the base-colour slot is bound and the material is a dielectric
+    const bool lite = t.diffuse != -1 && t.metallic_roughness == -1 && t.normal_map == -1 && t.emissive == -1 &&
+                      t.transmission == -1 && t.thickness == -1 && t.specular == -1 && t.specular_colour == -1 &&
+                      mi.metallic_factor == 0.0f;
+    d.flags = (has_atten ? 1u : 0u) | (mi.transmission_factor != 0.0f ? 2u : 0u) | (textured ? 4u : 0u) | (lite ? 8u : 0u);
     for (int k = 0; k < 3; ++k) {
         float coeff = -logf(mi.attenuation_colour[k]) / mi.attenuation_distance;  // :284
         d.neg_atten_log2[k] = has_atten ? (-coeff) * kLog2e : 0.0f;

@@ -417,18 +417,38 @@ struct tr_layer_planes {
 __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, const tr_raster_frame f,
                                                              const tr_tri_record* __restrict__ records,
                                                              unsigned long long* __restrict__ vis,
-                                                             const tr_layer_planes out, const uint32_t* __restrict__ tile_cover) {
+                                                             const tr_layer_planes out, uint32_t* __restrict__ tile_cover,
+                                                             uint32_t* __restrict__ tile_list, uint32_t* __restrict__ tile_list_count,
+                                                             const uint32_t* __restrict__ material_flags /* tr_dmat::flags, stride in words */,
+                                                             uint32_t flags_stride) {
 #pragma clang fp contract(off)
     const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (px >= f.width || py >= f.height) return;
     const size_t pix = (size_t)py * f.width + px;
     // one word per 64x4 block tile (this workgroup), set by raster_kernel when a fragment landed in it: an untouched tile
     // has no fragment, its visibility words need not be read
-    if (as_constant(tile_cover)[blockIdx.y * gridDim.x + blockIdx.x] == 0u) {
+    const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (as_constant(tile_cover)[tile] == 0u) {
         out.material_id[pix] = TR_NOT_COVERED;
         return;
     }
     const unsigned long long key = vis[pix];
+    // The tile's word also tells the shading launches which material CLASSES its fragments belong to (shade_kernel's
+    // TEX launches): bit 1 = a full-class textured material, bit 2 = anything else.  One atomic per wave.
+    {
+        uint32_t cls = 0u;
+        if (key != 0ull) {
+            const uint32_t mat = g.instances[records[(uint32_t)key].instance].material_id;
+            const uint32_t fl = material_flags ? material_flags[(size_t)mat * flags_stride] & 12u : 0xFFFFFFFFu;
+            cls = fl == 0xFFFFFFFFu ? 6u : (fl == 4u ? 2u : 4u);
+        }
+        const uint32_t bits = (__builtin_amdgcn_ballot_w64((cls & 2u) != 0u) ? 2u : 0u) | (__builtin_amdgcn_ballot_w64((cls & 4u) != 0u) ? 4u : 0u);
+        if (bits && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(true)) - 1)) {
+            const uint32_t before = atomicOr(&tile_cover[tile], bits);
+            // the first wave to tag the tile as holding full-class fragments also lists it for the TEX = 2 launch
+            if ((bits & 2u) && !(before & 2u)) tile_list[atomicAdd(tile_list_count, 1u)] = tile;
+        }
+    }
     if (key == 0ull) {   // no fragment: only the id plane is defined there (the shading passes look at nothing else)
         out.material_id[pix] = TR_NOT_COVERED;
         return;
@@ -477,6 +497,8 @@ struct tr_layer_work {
     unsigned long long* vis;
     tr_layer_planes planes;
     uint32_t* tile_cover;                      // [ceil(h/4)][ceil(w/64)]: zeroed per frame, set by raster_kernel
+    uint32_t* tile_list;                       // the tiles with full-class fragments ...
+    uint32_t* tile_list_count;                 // ... and their number (zeroed per frame with the coverage maps)
 };
 struct tr_two_layers {
     tr_layer_work l[2];
@@ -553,9 +575,10 @@ __global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const tr_
     raster_scan_items_apply_body(W.item_counts, W.chunk_sums, W.counts, W.item_base);
 }
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two,
-                                                             uint32_t first_layer) {
+                                                             uint32_t first_layer, const uint32_t* __restrict__ material_flags,
+                                                             uint32_t flags_stride) {
     TR_PICK_LAYER(two, blockIdx.z + first_layer);
-    raster_resolve_body(g, f, W.records, W.vis, W.planes, W.tile_cover);
+    raster_resolve_body(g, f, W.records, W.vis, W.planes, W.tile_cover, W.tile_list, W.tile_list_count, material_flags, flags_stride);
 }
 
 }  // namespace tr

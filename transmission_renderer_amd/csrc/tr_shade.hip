@@ -49,7 +49,11 @@ struct tr_context {
     bool dmats_dirty = false;
     std::vector<tr_material_info> stage_materials;
 
-    bool any_textured = false;      // some material has a texture slot: the TEXTURED kernels are launched
+    bool any_textured = false;      // some material has a texture slot: the TEX = 1 launch (untextured + lite class) runs
+    bool any_full_textured = false; // ... outside the lite class: the TEX = 2 launch runs as well
+    bool any_plain_or_lite = false; // some material is untextured or of the lite class (else the TEX = 2 launch runs alone)
+    uint32_t* d_class_list = nullptr;   // TEX = 2 launches outside the frame recorder: [0] count, [1..] block tiles
+    size_t class_list_cap = 0;
     int32_t max_texture_id = -1;    // largest texture id a material refers to
 
     // material textures: one arena of RGBA8 mip chains + a descriptor table
@@ -81,6 +85,10 @@ struct tr_context {
     unsigned long long* d_vis[2] = {nullptr, nullptr};
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
+    const uint32_t* list_hint = nullptr;               // ... with it: the layer's list of full-class tiles
+    const uint32_t* list_count_hint = nullptr;
+    uint32_t* d_tile_list_counts = nullptr;            // (inside the d_vis allocation, cleared with the coverage maps)
+    uint32_t* d_tile_list[2] = {nullptr, nullptr};     // per layer: the tiles
     size_t vis_pixels = 0;
     bool vis_clean = false;                            // both visibility buffers are all zero (stream order)
     uint32_t vis_w = 0, vis_h = 0;                     // the frame size they are laid out for
@@ -444,6 +452,8 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.tile_cover = (ctx->cover_hint && fp.rect_x0 == 0u && fp.rect_y0 == 0u && fp.g_origin_x == 0u && fp.g_origin_y == 0u &&
                     fp.rect_x1 == fp.width && fp.rect_y1 == fp.height && fp.g_width == fp.width)
                        ? ctx->cover_hint : nullptr;
+    L.tile_list = L.tile_cover ? ctx->list_hint : nullptr;
+    L.tile_list_count = L.tile_list ? ctx->list_count_hint : nullptr;
     L.slice_thr = ctx->d_slice_thr;
     L.cluster_x = ctx->d_cluster_x;
     L.cluster_y_term = ctx->d_cluster_y_term;
@@ -458,6 +468,58 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.textures = ctx->d_textures;
     L.tex_arena = ctx->d_tex_arena;
     L.srgb_to_linear = ctx->d_colour_tables ? ctx->d_colour_tables->srgb_to_linear : nullptr;
+}
+
+// The launches of a shading pass when textured materials are uploaded (shade_kernel's TEX classes):
+//   untextured + lite materials present: one TEX = 1 launch over the rect (it also writes the opaque pass's clear colour),
+//   full-class materials present: one TEX = 2 launch over the block tiles that hold their pixels — the frame recorder's
+//   resolve has listed them; otherwise a classification launch over the material-id plane lists them first —,
+//   only full-class materials: the TEX = 2 launch alone, sweeping the rect like an untextured pass.
+template <bool TRANSMISSIVE>
+tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bool half, dim3 grid, dim3 block, bool wave_blocks,
+                          hipStream_t stream) {
+    if (ctx->any_plain_or_lite) {
+        if (half) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, kTexLite>), grid, block, 0, stream, L);
+        else hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, float4, kTexLite>), grid, block, 0, stream, L);
+        if (!ctx->any_full_textured) return TR_OK;
+        if (!L.tile_list) {
+            const size_t tiles = (size_t)L.fp.tiles_x * L.fp.tiles_y;
+            if (tiles + 1u > ctx->class_list_cap) {
+                TR_HIP(ctx, hipStreamSynchronize(stream));
+                (void)hipFree(ctx->d_class_list);
+                ctx->d_class_list = nullptr;
+                ctx->class_list_cap = 0;
+                TR_HIP(ctx, hipMalloc((void**)&ctx->d_class_list, (tiles + 1u) * 4u));
+                ctx->class_list_cap = tiles + 1u;
+            }
+            TR_HIP(ctx, hipMemsetAsync(ctx->d_class_list, 0, 4u, stream));
+            tr_classify_params cp;
+            cp.g_width = L.fp.g_width;
+            cp.g_origin_x = L.fp.g_origin_x;
+            cp.g_origin_y = L.fp.g_origin_y;
+            cp.rect_x0 = L.fp.rect_x0;
+            cp.rect_y0 = L.fp.rect_y0;
+            cp.rect_x1 = L.fp.rect_x1;
+            cp.rect_y1 = L.fp.rect_y1;
+            cp.tiles_x = L.fp.tiles_x;
+            hipLaunchKernelGGL(classify_tiles_kernel, dim3(L.fp.tiles_x, L.fp.tiles_y), dim3(256), 0, stream,
+                               (const uint32_t*)g->material_id, cp,
+                               reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctx->d_dmats) + offsetof(tr_dmat, flags)),
+                               (uint32_t)(sizeof(tr_dmat) / 4u), ctx->num_materials, ctx->d_class_list + 1, ctx->d_class_list);
+            L.tile_list = ctx->d_class_list + 1;
+            L.tile_list_count = ctx->d_class_list;
+        }
+        // as many waves as the chip holds of this kernel (4 per SIMD), each striding over the list
+        const dim3 grid2(wave_blocks ? ctx->num_cus * 16u : ctx->num_cus * 4u);
+        if (half) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, kTexFull>), grid2, block, 0, stream, L);
+        else hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, float4, kTexFull>), grid2, block, 0, stream, L);
+        return TR_OK;
+    }
+    L.fp.solo_full = 1u;
+    L.tile_list = L.tile_list_count = nullptr;
+    if (half) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, kTexFull>), grid, block, 0, stream, L);
+    else hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, float4, kTexFull>), grid, block, 0, stream, L);
+    return TR_OK;
 }
 
 bool tables_ready(const tr_context* ctx, bool need_lut) {
@@ -560,6 +622,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_lut_lines);
     (void)hipFree(ctx->d_levels);
     (void)hipFree(ctx->d_slice_thr);
+    (void)hipFree(ctx->d_class_list);
     (void)hipFree(ctx->d_tile_counters);
     (void)hipFree(ctx->d_cluster_x);
     (void)hipFree(ctx->d_cluster_y_term);
@@ -596,20 +659,32 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
     if (!ctx || !materials_host || count == 0) return TR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
-    bool any_textured = false;
+    bool any_textured = false, any_full = false, any_other = false;
     int32_t max_id = -1;
     for (uint32_t i = 0; i < count; ++i) {
         const tr_textures& t = materials_host[i].textures;
         // the slots the shaders read (shader/src/lib.rs:65-76, 120-124; lighting.rs:222-313); occlusion is never sampled
         const int32_t ids[8] = {t.diffuse, t.metallic_roughness, t.normal_map, t.emissive,
                                 t.transmission, t.thickness, t.specular, t.specular_colour};
-        for (int32_t id : ids) {
+        bool textured = false, only_diffuse = true;
+        for (int k = 0; k < 8; ++k) {
+            const int32_t id = ids[k];
             if (id < -1) return TR_ERR_INVALID_ARGUMENT;
-            if (id != -1) any_textured = true;
+            if (id != -1) {
+                textured = true;
+                if (k != 0) only_diffuse = false;
+            }
             if (id > max_id) max_id = id;
         }
+        any_textured |= textured;
+        // the same rule as digest_materials_kernel's lite class (flags bit 3)
+        const bool full = textured && !(only_diffuse && materials_host[i].metallic_factor == 0.0f);
+        any_full |= full;
+        any_other |= !full;
     }
     ctx->any_textured = any_textured;
+    ctx->any_full_textured = any_full;
+    ctx->any_plain_or_lite = any_other;
     ctx->max_texture_id = max_id;
     if (count > ctx->cap_materials) {
         (void)hipFree(ctx->d_materials_raw);
@@ -935,7 +1010,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
         ctx->vis_pixels = 0;
         ctx->d_tile_cover[0] = ctx->d_tile_cover[1] = nullptr;
         // both layers' visibility buffers and, behind them, their tile coverage maps: cleared by one fill
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 2u * (npix / 64u + 65536u + 16384u) * 4u));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 4u * (npix / 64u + 65536u + 16384u) * 4u + 64u));
         ctx->vis_pixels = npix;
         ctx->vis_clean = false;
     }
@@ -948,6 +1023,10 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
     ctx->d_tile_cover[0] = (uint32_t*)(ctx->d_vis[0] + 2u * npix);
     ctx->d_tile_cover[1] = ctx->d_tile_cover[0] + cover_tiles;
+    // behind the two maps: the two counters of the full-class tile lists (cleared with the maps), then the lists
+    ctx->d_tile_list_counts = ctx->d_tile_cover[1] + cover_tiles;
+    ctx->d_tile_list[0] = ctx->d_tile_list_counts + 2u;
+    ctx->d_tile_list[1] = ctx->d_tile_list[0] + cover_tiles;
     tr_geometry_view gv;
     gv.position = ctx->d_position;
     gv.normal = ctx->d_normal;
@@ -983,12 +1062,14 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
         W.planes.uv = (float2*)targets[layer]->uv;
         W.planes.material_id = (uint32_t*)targets[layer]->material_id;
         W.tile_cover = ctx->d_tile_cover[layer];
+        W.tile_list = ctx->d_tile_list[layer];
+        W.tile_list_count = ctx->d_tile_list_counts + layer;
     }
     // The visibility buffers are zero on entry: filled once after (re)allocation, and every resolve zeroes the words its
     // frame set (raster_resolve_body).  Per frame only the two tile coverage maps are cleared (260 KB at 4K).
     if (!ctx->vis_clean) TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u, stream));
     ctx->vis_clean = false;   // (until this frame's resolve is enqueued)
-    TR_HIP(ctx, hipMemsetAsync(ctx->d_tile_cover[0], 0, 2u * cover_tiles * 4u, stream));
+    TR_HIP(ctx, hipMemsetAsync(ctx->d_tile_cover[0], 0, (2u * cover_tiles + 2u) * 4u, stream));
     const uint32_t max_cap = std::max(ctx->max_triangles[0], ctx->max_triangles[1]);
     if (fused_demux) {
         tr_draw_buffers out;
@@ -1018,7 +1099,13 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
                                ctx->d_vis[layer], ctx->d_tile_cover[layer]);
         }
     }
-    hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two, 0u);
+    // (the resolve tags every tile with the material classes of its fragments for the shading launches: needs the
+    //  digested material table; without a GGX LUT there is none yet and every covered tile is tagged with both classes)
+    const uint32_t* mat_flags = nullptr;
+    if (ensure_digested(ctx, stream) == TR_OK)
+        mat_flags = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctx->d_dmats) + offsetof(tr_dmat, flags));
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two, 0u,
+                       mat_flags, (uint32_t)(sizeof(tr_dmat) / 4u));
     TR_HIP(ctx, hipGetLastError());
     ctx->vis_clean = true;
     return TR_OK;
@@ -1153,9 +1240,9 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
         L.hdr = hdr_out;
         L.mip0 = (uint2*)opaque_mip0_out;
         const bool half = format == TR_FORMAT_RGBA16F;
-        if (ctx->any_textured) {
-            if (half) hipLaunchKernelGGL((shade_kernel<false, uint2, true>), grid, block, 0, stream, L);
-            else hipLaunchKernelGGL((shade_kernel<false, float4, true>), grid, block, 0, stream, L);
+        if (ctx->any_textured) {   // one launch per material class (see launch_textured)
+            const tr_status ls = launch_textured<false>(ctx, L, g, half, grid, block, wave_blocks, stream);
+            if (ls != TR_OK) return ls;
         } else {
             if (half) hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, L);
             else hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, L);
@@ -1256,9 +1343,9 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
         L.pyramid = (const uint2*)p->texels;
         L.hdr = hdr_inout;
         const bool half = format == TR_FORMAT_RGBA16F;
-        if (ctx->any_textured) {
-            if (half) hipLaunchKernelGGL((shade_kernel<true, uint2, true>), grid, block, 0, stream, L);
-            else hipLaunchKernelGGL((shade_kernel<true, float4, true>), grid, block, 0, stream, L);
+        if (ctx->any_textured) {   // one launch per material class (see launch_textured)
+            const tr_status ls = launch_textured<true>(ctx, L, g, half, grid, block, wave_blocks, stream);
+            if (ls != TR_OK) return ls;
         } else {
             if (half) hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, L);
             else hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, L);
@@ -1702,8 +1789,10 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     {
         zone_scope z(rec, "main opaque");
         ctx->cover_hint = ctx->d_tile_cover[0];
+        ctx->list_hint = ctx->d_tile_list[0];
+        ctx->list_count_hint = ctx->d_tile_list_counts;
         st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
-        ctx->cover_hint = nullptr;
+        ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
     }
     if (st != TR_OK) return st;
     {
@@ -1714,8 +1803,10 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     {
         zone_scope z(rec, "opaque transmissive objects");
         ctx->cover_hint = ctx->d_tile_cover[1];
+        ctx->list_hint = ctx->d_tile_list[1];
+        ctx->list_count_hint = ctx->d_tile_list_counts + 1;
         st = tr_shade_transmission(ctx, &layers[1], f->uniforms, f->push, &f->pyramid, f->hdr, f->hdr_format, whole, stream);
-        ctx->cover_hint = nullptr;
+        ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
     }
     if (st != TR_OK) return st;
     if (f->ldr_out) {
