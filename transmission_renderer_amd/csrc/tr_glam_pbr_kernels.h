@@ -39,7 +39,7 @@ __device__ __forceinline__ void frame_of(pixel_frame& px, const lane_dmat& lm, c
     px.nvz = v2f{n[2], v[2]};
     px.nov_raw = dot3(n[0], n[1], n[2], v[0], v[1], v[2]);
     px.nov = fmaxf(px.nov_raw, kEpsilon);
-    const v2f ra = pk_fma(splat(px.nov * px.nov), v2f{lm.oma2[0], lm.oma2[1]}, v2f{lm.a2[0], lm.a2[1]});
+    const v2f ra = pk_fma(splat(px.nov * px.nov), v2f{m_oma2(lm, 0), m_oma2(lm, 1)}, v2f{lm.a2[0], lm.a2[1]});
     px.g_nov = v2f{fast_sqrt(ra.x), fast_sqrt(ra.y)};
 }
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void ibl_volume_refraction_kernel(const tr_ibl
     const float cw = fmaf(P[11], ez, fmaf(P[7], ey, fmaf(P[3], ex, P[15])));
     const float hw = 0.5f * rcp(cw);
     const float tu = fmaf(cx, hw, 0.5f), tv = fmaf(cy, hw, 0.5f);
-    const float lod = fast_log2((float)p.framebuffer_size_x) * lm.rough_ior;   // :334-335
+    const float lod = fast_log2((float)p.framebuffer_size_x) * m_rough_ior(lm);   // :334-335
     pyramid_fetch pf;
     pyramid_issue<false>(pf, t.pyramid, as_constant(t.levels), t.pyr_levels, tu, tv, lod, lane);
     lut_fetch lf;

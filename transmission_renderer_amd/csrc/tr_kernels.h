@@ -211,8 +211,10 @@ typedef const TR_CONSTANT tr_launch claunch;
 // The material as the per-pixel code reads it when it has texture slots: the same fields as tr_dmat, but
 // per lane (vector registers), digested per pixel from the sampled factors.
 struct lane_dmat {
-    float diffuse[3], f90, eta, f0[3], transmission_factor, df[3], thickness, emission[3], rough_ior;
-    float neg_atten_log2[3], a2[2], oma2[2], k[2];
+    float diffuse[3], f90, eta, f0[3], transmission_factor, thickness, emission[3], ior_clamp;
+    float neg_atten_log2[3], a2[2];
+    // (1 - a2, a2 / 2 pi, f90 - f0 and roughness * ior_clamp are one instruction each where they are used: keeping them
+    //  would cost eight more registers across the whole pixel — the difference between four and five waves per SIMD)
     float metallic, rough;   // what the end of the pixel derives c_diff, the btdf coefficients and the LUT row from
     uint32_t flags;          // (kept instead of those values: they are needed only after the light loop)
 };
@@ -226,8 +228,23 @@ __device__ __forceinline__ float mat_c_diff(const lane_dmat* m, int k) {
     const float diff = m->diffuse[k];
     return (diff + (0.0f - diff) * m->metallic) * kFrac1Pi;          // lerp(diffuse, 0, metallic) / pi
 }
-__device__ __forceinline__ float mat_bt_a(const lane_dmat* m, int k) { return m->k[1] * (1.0f - m->f0[k]); }
-__device__ __forceinline__ float mat_bt_b(const lane_dmat* m, int k) { return m->k[1] * m->df[k]; }
+// the derived constants: table fields of a scalar record, recomputed for a per-lane one
+__device__ __forceinline__ float m_oma2(const TR_CONSTANT tr_dmat& m, int k) { return m.oma2[k]; }
+__device__ __forceinline__ float m_k(const TR_CONSTANT tr_dmat& m, int k) { return m.k[k]; }
+__device__ __forceinline__ float m_df(const TR_CONSTANT tr_dmat& m, int k) { return m.df[k]; }
+__device__ __forceinline__ float m_rough_ior(const TR_CONSTANT tr_dmat& m) { return m.rough_ior; }
+// (the operand goes through an empty volatile asm: the recomputation stays where it is used instead of being hoisted
+//  out of the light loop back into a register of its own)
+__device__ __forceinline__ float here(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float m_oma2(const lane_dmat& m, int k) { return 1.0f - here(m.a2[k]); }
+__device__ __forceinline__ float m_k(const lane_dmat& m, int k) { return here(m.a2[k]) * (0.5f * kFrac1Pi); }
+__device__ __forceinline__ float m_df(const lane_dmat& m, int k) { return m.f90 - here(m.f0[k]); }
+__device__ __forceinline__ float m_rough_ior(const lane_dmat& m) { return m.rough * m.ior_clamp; }
+__device__ __forceinline__ float mat_bt_a(const lane_dmat* m, int k) { return m_k(*m, 1) * (1.0f - m->f0[k]); }
+__device__ __forceinline__ float mat_bt_b(const lane_dmat* m, int k) { return m_k(*m, 1) * m_df(*m, k); }
 
 // The "lite" material class: a dielectric (metallic_factor == 0) whose only bound texture is the base colour — the most
 // common textured glTF material.  Everything the specular lobes read stays what the material table holds (f0 does not
@@ -301,11 +318,11 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         const float sin2 = c2 * (inv_h * inv_h);                   // 1 - (n.h)^2
         const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
         // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal
-        const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(nol * nol, m.oma2[0], m.a2[0])));
+        const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(nol * nol, m_oma2(m, 0), m.a2[0])));
         // (g > 0 always: n.l, n.v are clamped to EPSILON and the roots are positive, so v_smith's `denom <= 0`
         //  guard, :125-131, cannot trigger; a NaN propagates like in the reference)
-        const float dv = m.k[0] * rcp(f * f * g);
-        const float Fx = fmaf(m.df[0], p, m.f0[0]), Fy = fmaf(m.df[1], p, m.f0[1]), Fz = fmaf(m.df[2], p, m.f0[2]);
+        const float dv = m_k(m, 0) * rcp(f * f * g);
+        const float Fx = fmaf(m_df(m, 0), p, m.f0[0]), Fy = fmaf(m_df(m, 1), p, m.f0[1]), Fz = fmaf(m_df(m, 2), p, m.f0[2]);
         const float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));  // diffuse_brdf :356-360
         const float ws = nol * dv;                                 // specular_brdf :362-375 (weighted by n.l :414-421)
         if constexpr (FIRST) {
@@ -336,7 +353,7 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
             const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
             const float sin2 = c2 * (inv_h * inv_h);
             const float f = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - sin2, sin2) : 1.0f;
-            const float g = fmaf(nolm, px.g_nov.y, nov * fast_sqrt(fmaf(nolm * nolm, m.oma2[1], m.a2[1])));
+            const float g = fmaf(nolm, px.g_nov.y, nov * fast_sqrt(fmaf(nolm * nolm, m_oma2(m, 1), m.a2[1])));
             const float r = rcp(f * f * g);                          // D'V' / k[1]; not weighted by n.l (:232)
             const float tx = I.x * r, ty = I.y * r, tz = I.z * r;
             if constexpr (FIRST) {
@@ -605,9 +622,11 @@ __device__ __forceinline__ void digest_factors(D& d, float metallic, float rough
     const float alpha_t = alpha * ior_clamp;                         // ActualRoughness::apply_ior :144-146
     d.a2[0] = alpha * alpha;
     d.a2[1] = alpha_t * alpha_t;
-    for (int k = 0; k < 2; ++k) {
-        d.oma2[k] = 1.0f - d.a2[k];
-        d.k[k] = d.a2[k] * (0.5f * kFrac1Pi);
+    if constexpr (FULL) {
+        for (int k = 0; k < 2; ++k) {
+            d.oma2[k] = 1.0f - d.a2[k];
+            d.k[k] = d.a2[k] * (0.5f * kFrac1Pi);
+        }
     }
     d.f90 = specular_factor + (1.0f - specular_factor) * metallic;  // calculate_combined_f90
     const float diffuse[3] = {dx, dy, dz}, spec_colour[3] = {scx, scy, scz};
@@ -616,15 +635,16 @@ __device__ __forceinline__ void digest_factors(D& d, float metallic, float rough
         d.diffuse[k] = diff;
         const float ds = f0d * spec_colour[k] * specular_factor;
         d.f0[k] = ds + (diff - ds) * metallic;                       // calculate_combined_f0
-        d.df[k] = d.f90 - d.f0[k];
         if constexpr (FULL) {
+            d.df[k] = d.f90 - d.f0[k];
             const float cd = diff + (0.0f - diff) * metallic;        // c_diff = lerp(diffuse, 0, metallic)
             d.c_diff[k] = cd * kFrac1Pi;
             d.bt_a[k] = d.k[1] * (1.0f - d.f0[k]);
             d.bt_b[k] = d.k[1] * d.df[k];
         }
     }
-    d.rough_ior = rough * ior_clamp;                                 // PerceptualRoughness::apply_ior :157-159
+    if constexpr (FULL) d.rough_ior = rough * ior_clamp;             // PerceptualRoughness::apply_ior :157-159
+    else d.ior_clamp = ior_clamp;
     if constexpr (FULL) lut_rows(rough, lut_height, lut_stride, d.lut_fy, d.lut_row0, d.lut_row1);
 }
 
@@ -788,7 +808,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         float hw = 0.5f * rcp(cw);                      // (clip.xy / clip.w + 1) / 2  :330-332
         float tu = fmaf(cx, hw, 0.5f);
         float tv = fmaf(cy, hw, 0.5f);
-        float lod = L->fp.log2_fb_width * mb->rough_ior; // :334-335
+        float lod = L->fp.log2_fb_width * m_rough_ior(*mb); // :334-335
         if (!TR_ABLATE(L, 1u)) pyramid_issue<SCALAR_MATERIAL>(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane);
         else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
         if constexpr (SCALAR_MATERIAL) {
@@ -814,7 +834,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         claunch* L2 = launder(L);
         const auto m2 = mat_base(launder(m));
         {
-            const v2f ra = pk_fma(splat(nov * nov), v2f{m2->oma2[0], m2->oma2[1]}, v2f{m2->a2[0], m2->a2[1]});
+            const v2f ra = pk_fma(splat(nov * nov), v2f{m_oma2(*m2, 0), m_oma2(*m2, 1)}, v2f{m2->a2[0], m2->a2[1]});
             px.g_nov = v2f{fast_sqrt(ra.x), TRANSMISSIVE ? fast_sqrt(ra.y) : 0.0f};
         }
         // sun (lighting.rs:37-53 / 171-177)
@@ -962,86 +982,88 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     const int32_t id_specular = mi->textures.specular, id_spec_colour = mi->textures.specular_colour;
 
     // Sampling geometry (LOD, level pair, wrapped tap coordinates, weights) depends on the texture's size only, and a
-    // material's textures usually share one size: it is computed once, for the first bound slot, and every slot of
-    // that size only issues its eight taps (scalar chain base + the shared per-lane offsets).  A slot of another size
-    // is sampled on its own afterwards.  All the conditions are scalar (ids and sizes come from the material record).
+    // material's textures usually share one size: it is computed for the first bound slot and kept while the following
+    // slots have that size (they only issue their eight taps: scalar chain base + the shared per-lane offsets); a slot of
+    // another size recomputes it in place.  All the conditions are scalar (ids and sizes come from the material record).
     const int32_t ids[8] = {id_diffuse, id_mr, id_normal, id_emissive, id_transmission, id_thickness, id_specular, id_spec_colour};
-    int32_t first = -1;
-#pragma unroll
-    for (int k = 7; k >= 0; --k) first = ids[k] != -1 ? ids[k] : first;
     tex_geom g0;
-    uint32_t w0 = 0u, h0 = 0u;
-    if (first != -1) {
-        w0 = tex[first].width;
-        h0 = tex[first].height;
-        tex_geom_compute(g0, tex + first, uv.x, uv.y, qd.uv);
-    }
-    // Two groups, so that at most four slots' taps are live at a time: first the slots the material digest needs
-    // (base colour, metallic-roughness, specular, specular colour), then normal, emissive, transmission, thickness.
-    bool shared[8];
-    tex_taps taps[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) shared[k] = ids[k] != -1 && tex[ids[k]].width == w0 && tex[ids[k]].height == h0;
-    if (shared[0]) texture_issue_shared(taps[0], arena, tex + ids[0], g0);
-    if (shared[1]) texture_issue_shared(taps[1], arena, tex + ids[1], g0);
-    if (shared[6]) texture_issue_shared(taps[6], arena, tex + ids[6], g0);
-    if (shared[7]) texture_issue_shared(taps[7], arena, tex + ids[7], g0);
-    // channel c of slot k (call only when the slot is bound)
-    auto sample = [&](auto slot, auto channel) -> float {
-        constexpr int k = decltype(slot)::value, c = decltype(channel)::value;
-        const bool srgb = tex[ids[k]].srgb != 0u;
-        if (shared[k]) return texture_resolve_shared<c>(taps[k], g0, srgb, lds_srgb);
-        tex_geom g1;
-        tex_taps t1;
-        tex_geom_compute(g1, tex + ids[k], uv.x, uv.y, qd.uv);
-        texture_issue_shared(t1, arena, tex + ids[k], g1);
-        return texture_resolve_shared<c>(t1, g1, srgb, lds_srgb);
+    uint32_t w0 = 0u, h0 = 0u;   // (scalar) the size g0 was computed for
+    // ONE slot at a time: its eight taps are issued, filtered and dropped before the next slot's are requested (a
+    // compiler barrier between slots), and what a slot yields is materialised on the spot.  With the slots' taps in
+    // flight together — or their filters sunk down to the late uses of emission, thickness, the transmission factor —
+    // the kernel needed 122 registers = 4 waves per SIMD; the memory-level parallelism given up inside a wave comes back
+    // as resident waves.
+    // use(S): S(channel) filters one channel of the slot's taps (call only when the slot is bound)
+    auto with_slot = [&](auto slot, auto&& use) {
+        constexpr int k = decltype(slot)::value;
+        cdtex* t = tex + ids[k];
+        const bool srgb = t->srgb != 0u;
+        if (t->width != w0 || t->height != h0) {
+            w0 = t->width;
+            h0 = t->height;
+            tex_geom_compute(g0, t, uv.x, uv.y, qd.uv);
+        }
+        tex_taps taps;
+        texture_issue_shared(taps, arena, t, g0);
+        use([&](auto ch) { return texture_resolve_shared<decltype(ch)::value>(taps, g0, srgb, lds_srgb); });
     };
-#define TR_SAMPLE(slot, channel) sample(std::integral_constant<int, slot>{}, std::integral_constant<int, channel>{})
+    auto slot_done = []() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> c0;
+    typedef std::integral_constant<int, 1> c1;
+    typedef std::integral_constant<int, 2> c2;
+    typedef std::integral_constant<int, 3> c3;
 
     lane_dmat lm;
     // diffuse = diffuse_factor * sample (lib.rs:65-69)
     float dr = mi->diffuse_factor[0], dg = mi->diffuse_factor[1], db = mi->diffuse_factor[2];
     if (id_diffuse != -1) {
-        dr *= TR_SAMPLE(0, 0);
-        dg *= TR_SAMPLE(0, 1);
-        db *= TR_SAMPLE(0, 2);
+        with_slot(std::integral_constant<int, 0>{}, [&](auto S) { dr *= S(c0{}); dg *= S(c1{}); db *= S(c2{}); });
+        asm volatile("" : "+v"(dr), "+v"(dg), "+v"(db));
+        slot_done();
     }
     // get_material_params (lighting.rs:261-301)
     float metallic = mi->metallic_factor, rough = mi->roughness_factor;
     if (id_mr != -1) {
-        metallic *= TR_SAMPLE(1, 2);   // "These two are switched!"
-        rough *= TR_SAMPLE(1, 1);
+        with_slot(std::integral_constant<int, 1>{}, [&](auto S) { metallic *= S(c2{}); rough *= S(c1{}); });   // "These two are switched!"
+        asm volatile("" : "+v"(metallic), "+v"(rough));
+        slot_done();
     }
     float scx = mi->specular_colour_factor[0], scy = mi->specular_colour_factor[1], scz = mi->specular_colour_factor[2];
     if (id_spec_colour != -1) {
-        scx *= TR_SAMPLE(7, 0);
-        scy *= TR_SAMPLE(7, 1);
-        scz *= TR_SAMPLE(7, 2);
+        with_slot(std::integral_constant<int, 7>{}, [&](auto S) { scx *= S(c0{}); scy *= S(c1{}); scz *= S(c2{}); });
+        asm volatile("" : "+v"(scx), "+v"(scy), "+v"(scz));
+        slot_done();
     }
     float specular_factor = mi->specular_factor;
-    if (id_specular != -1) specular_factor *= TR_SAMPLE(6, 3);
-    digest_factors<false>(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
-                          L->fp.lut_height, L->fp.lut_stride);
-    lm.metallic = metallic;
-    lm.rough = rough;
-    if (shared[2]) texture_issue_shared(taps[2], arena, tex + ids[2], g0);
-    if (shared[3]) texture_issue_shared(taps[3], arena, tex + ids[3], g0);
-    if (shared[4]) texture_issue_shared(taps[4], arena, tex + ids[4], g0);
-    if (shared[5]) texture_issue_shared(taps[5], arena, tex + ids[5], g0);
+    if (id_specular != -1) {
+        with_slot(std::integral_constant<int, 6>{}, [&](auto S) { specular_factor *= S(c3{}); });
+        asm volatile("" : "+v"(specular_factor));
+        slot_done();
+    }
     // get_emission (lighting.rs:303-313)
     lm.emission[0] = mi->emissive_factor[0];
     lm.emission[1] = mi->emissive_factor[1];
     lm.emission[2] = mi->emissive_factor[2];
     if (id_emissive != -1) {
-        lm.emission[0] *= TR_SAMPLE(3, 0);
-        lm.emission[1] *= TR_SAMPLE(3, 1);
-        lm.emission[2] *= TR_SAMPLE(3, 2);
+        with_slot(std::integral_constant<int, 3>{}, [&](auto S) { lm.emission[0] *= S(c0{}); lm.emission[1] *= S(c1{}); lm.emission[2] *= S(c2{}); });
+        asm volatile("" : "+v"(lm.emission[0]), "+v"(lm.emission[1]), "+v"(lm.emission[2]));
+        slot_done();
     }
     lm.transmission_factor = mi->transmission_factor;               // lib.rs:71-77
-    if (id_transmission != -1) lm.transmission_factor *= TR_SAMPLE(4, 0);
+    if (id_transmission != -1) {
+        with_slot(std::integral_constant<int, 4>{}, [&](auto S) { lm.transmission_factor *= S(c0{}); });
+        asm volatile("" : "+v"(lm.transmission_factor));
+        slot_done();
+    }
     lm.thickness = mi->thickness_factor;                            // lib.rs:120-124
-    if (id_thickness != -1) lm.thickness *= TR_SAMPLE(5, 1);
+    if (id_thickness != -1) {
+        with_slot(std::integral_constant<int, 5>{}, [&](auto S) { lm.thickness *= S(c1{}); });
+        asm volatile("" : "+v"(lm.thickness));
+        slot_done();
+    }
     lm.eta = dm->eta;
     lm.neg_atten_log2[0] = dm->neg_atten_log2[0];
     lm.neg_atten_log2[1] = dm->neg_atten_log2[1];
@@ -1053,9 +1075,14 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         const float inv_n = rsq(dot3(ns.x, ns.y, ns.z, ns.x, ns.y, ns.z));
         const f3 n = {ns.x * inv_n, ns.y * inv_n, ns.z * inv_n};
         // map_normal * 255/127 - 128/127 (the compiled shader folds 255/127 into one multiply)
-        const float mx = fmaf(TR_SAMPLE(2, 0), 255.0f / 127.0f, -128.0f / 127.0f);
-        const float my = fmaf(TR_SAMPLE(2, 1), 255.0f / 127.0f, -128.0f / 127.0f);
-        const float mz = fmaf(TR_SAMPLE(2, 2), 255.0f / 127.0f, -128.0f / 127.0f);
+        float mx = 0.0f, my = 0.0f, mz = 0.0f;
+        with_slot(std::integral_constant<int, 2>{}, [&](auto S) {
+            mx = fmaf(S(c0{}), 255.0f / 127.0f, -128.0f / 127.0f);
+            my = fmaf(S(c1{}), 255.0f / 127.0f, -128.0f / 127.0f);
+            mz = fmaf(S(c2{}), 255.0f / 127.0f, -128.0f / 127.0f);
+        });
+        asm volatile("" : "+v"(mx), "+v"(my), "+v"(mz));
+        slot_done();
         auto cross = [](f3 a, f3 b) { return f3{fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y))}; };
         const f3 dp2perp = cross(qd.dp_dy, n), dp1perp = cross(n, qd.dp_dx);
         const f3 t = {fmaf(dp2perp.x, qd.uv.dudx, dp1perp.x * qd.uv.dudy), fmaf(dp2perp.y, qd.uv.dudx, dp1perp.y * qd.uv.dudy),
@@ -1067,8 +1094,14 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         ns.x = fmaf(n.x, mz, fmaf(b.x, by_, t.x * tx));
         ns.y = fmaf(n.y, mz, fmaf(b.y, by_, t.y * tx));
         ns.z = fmaf(n.z, mz, fmaf(b.z, by_, t.z * tx));             // shade_pixel normalises
+        asm volatile("" : "+v"(ns.x), "+v"(ns.y), "+v"(ns.z));
     }
-#undef TR_SAMPLE
+    // The per-lane record is digested only now, when every slot has been sampled and the sampling geometry, the quad
+    // differences and the taps are dead: the digest's twenty values and the sampling state are never live together.
+    digest_factors<false>(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
+                          L->fp.lut_height, L->fp.lut_stride);
+    lm.metallic = metallic;
+    lm.rough = rough;
     return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd, ns, lane, cl TR_TIMER_ARG);
 }
 
