@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from transmission_renderer_amd import _lib
+if len(sys.argv) > 2:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])   # python tools/gpu_bench_passes.py <lights> [lib.so]
 from transmission_renderer_amd import synthetic, wire
 from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer
 
