@@ -347,6 +347,13 @@ def run_rank(args) -> int:
         t = torch.tensor([composite_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         composite_ms = float(t.item())
+        # the same composite of the frame as it is presented: bands tonemapped to RGBA8 first (half the bytes per link)
+        ldr = torch.zeros((padded, fw, 4), dtype=torch.uint8, device=dev)
+        dist.barrier()
+        composite_ldr_ms = timed_launches(max(10, K // 4), lambda: comp.allgather_rows(ldr))
+        t = torch.tensor([composite_ldr_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        composite_ldr_ms = float(t.item())
     # per-launch events for the frame-time percentiles of the metric
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
@@ -453,6 +460,7 @@ def run_rank(args) -> int:
                                   "Mpixels_per_s": round(pixels_step / kernel_ms_max / 1e3, 1),
                                   "note": "the band kernels alone, max over ranks, no composite"}
             out["composite_allgather_ms"] = round(composite_ms, 4)
+            out["composite_rgba8_allgather_ms"] = round(composite_ldr_ms, 4)
             if single_gpu_ms is not None:
                 out["single_gpu_ms"] = round(single_gpu_ms, 4)
                 out["speedup_vs_1gpu"] = {"kernel_only": round(single_gpu_ms / kernel_ms_max, 3),

@@ -220,7 +220,8 @@ typedef struct tr_rect {
  * that want to see the value before the half rounding. */
 typedef enum tr_format {
     TR_FORMAT_RGBA16F = 0,
-    TR_FORMAT_RGBA32F = 1
+    TR_FORMAT_RGBA32F = 1,
+    TR_FORMAT_RGBA8 = 2     /* tr_allgather_frame only: the tonemapped 8-bit frame (tr_tonemap's output) */
 } tr_format;
 
 /*
@@ -570,7 +571,8 @@ int32_t   tr_comm_last_error(const tr_comm* comm);
 /* The composite (and the mid-frame level-0 exchange): `frame_dev` holds nranks * rows_per_rank rows of `width`
  * pixels of `format`; this rank has written band `rank` (rows rank * rows_per_rank ...); on return (stream order)
  * every band is everywhere.  In place: ncclAllGather(sendbuff = recvbuff + rank * band_bytes).  Asynchronous on
- * `stream`; call it on every rank. */
+ * `stream`; call it on every rank.  `format` may also be TR_FORMAT_RGBA8: the composite of the frame as it is presented
+ * (each rank tonemaps its band first) moves half the bytes of the RGBA16F one. */
 tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame_dev, uint32_t width, uint32_t rows_per_rank,
                              tr_format format, void* stream);
 

@@ -30,6 +30,11 @@ def test_one_rank_communicator_and_inplace_allgather():
         assert lib.tr_allgather_frame(r._ctx, comm, frame.data_ptr(), 40, 24, fmt, torch.cuda.current_stream().cuda_stream) == 0
         torch.cuda.synchronize()
         assert torch.equal(frame, want)                               # one rank: its band is the frame
+    ldr = torch.from_numpy(rng.integers(0, 256, (24, 40, 4), dtype=np.uint8)).to(r.device)      # the tonemapped frame
+    want = ldr.clone()
+    assert lib.tr_allgather_frame(r._ctx, comm, ldr.data_ptr(), 40, 24, wire.FORMAT_RGBA8, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ldr, want)
     # argument checks
     assert lib.tr_allgather_frame(r._ctx, comm, None, 40, 24, wire.FORMAT_RGBA16F, None) == 1
     assert lib.tr_allgather_frame(r._ctx, comm, frame.data_ptr(), 0, 24, wire.FORMAT_RGBA16F, None) == 1

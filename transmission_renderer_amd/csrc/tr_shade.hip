@@ -1578,10 +1578,10 @@ int32_t tr_comm_last_error(const tr_comm* comm) { return comm ? comm->last_error
 tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame, uint32_t width, uint32_t rows_per_rank,
                              tr_format format, void* stream_) {
     if (!ctx || !comm || !frame || width == 0 || rows_per_rank == 0) return TR_ERR_INVALID_ARGUMENT;
-    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F) return TR_ERR_INVALID_ARGUMENT;
+    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F && format != TR_FORMAT_RGBA8) return TR_ERR_INVALID_ARGUMENT;
     if (!rccl().ok) return TR_ERR_COMM;
     TR_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t band_bytes = (size_t)width * rows_per_rank * (format == TR_FORMAT_RGBA16F ? 8u : 16u);
+    const size_t band_bytes = (size_t)width * rows_per_rank * (format == TR_FORMAT_RGBA16F ? 8u : format == TR_FORMAT_RGBA32F ? 16u : 4u);
     char* base = static_cast<char*>(frame);
     // in place: this rank's band already sits at its slot of the receive buffer
     const ncclResult_t r = rccl().AllGather(base + (size_t)comm->rank * band_bytes, base, band_bytes, ncclUint8, comm->comm,

@@ -90,8 +90,8 @@ class Compositor:
         assert frame.is_contiguous() and frame.shape[0] % self.world == 0, "gathered buffers hold world * rows_per_rank rows"
         rows = frame.shape[0] // self.world
         if self._comm.value:
-            fmt = wire.FORMAT_RGBA16F if frame.dtype == torch.float16 else wire.FORMAT_RGBA32F
-            assert frame.shape[2] == 4 and frame.dtype in (torch.float16, torch.float32)
+            fmt = {torch.float16: wire.FORMAT_RGBA16F, torch.float32: wire.FORMAT_RGBA32F, torch.uint8: wire.FORMAT_RGBA8}[frame.dtype]
+            assert frame.shape[2] == 4
             st = self.renderer.lib.tr_allgather_frame(self.renderer._ctx, self._comm, frame.data_ptr(), int(frame.shape[1]),
                                                       rows, fmt, torch.cuda.current_stream().cuda_stream)
             if st != 0:

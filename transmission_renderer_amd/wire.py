@@ -26,6 +26,7 @@ MAX_LIGHTS_PER_CLUSTER = 128  # shared-structs/src/lib.rs:322
 NOT_COVERED = 0xFFFFFFFF
 FORMAT_RGBA16F = 0
 FORMAT_RGBA32F = 1
+FORMAT_RGBA8 = 2        # tr_allgather_frame only
 MAX_MIP_LEVELS = 16
 
 
