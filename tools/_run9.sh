@@ -1,10 +1,10 @@
 R=$PWD
-OUT=$R/gpurun_out/r02a
-mkdir -p $OUT
-python3 tools/make_demo_gltf.py $OUT/demo.glb > /dev/null
+python -m pytest tests -q -m gpu > gpurun_out/r02q_tests.txt 2>&1; grep -n "passed\|failed" gpurun_out/r02q_tests.txt | tail -2
+bash tools/prof_round.sh r02b > gpurun_out/r02b_round.log 2>&1
+OUT=$R/gpurun_out/r02b
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pipeline_gltf -o t -- python3 -m transmission_renderer_amd.cli $OUT/demo.glb --width 3840 --height 2160 --out $OUT/demo_4k.png > $OUT/pipeline_gltf.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/frame_loop -o t -- python3 $R/tools/gpu_bench_frame.py $OUT/demo.glb > $OUT/frame_loop.log 2>&1
 grep "us per frame" $OUT/frame_loop.log
-f=$(find $OUT/frame_loop -name '*kernel_stats.csv' | head -1); head -22 "$f" | cut -c1-150
-rm -f $OUT/demo_4k.png
+cd $R
+bash tools/prof_pmc.sh r02b_pmc > gpurun_out/r02b_pmc.log 2>&1; grep -A3 "FETCH_SIZE\|WRITE_SIZE" gpurun_out/r02b_pmc.log | head -8
+grep "^{" gpurun_out/r02b/bench_default.log | cut -c1-300
