@@ -338,10 +338,14 @@ def run_rank(args) -> int:
     kernel_ms = region_ms if not distributed else timed_launches(K, lambda: shade(frames[0]))
     kernel_ms_max = kernel_ms
     composite_ms = None
+    per_rank_kernel_ms = [kernel_ms]
     if distributed:
-        t = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kernel_ms_max = float(t.item())
+        mine = torch.tensor([kernel_ms, float((y1 - y0) * fw)], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_kernel_ms = [float(e[0].item()) for e in every]
+        per_rank_pixels = [float(e[1].item()) for e in every]
+        kernel_ms_max = max(per_rank_kernel_ms)
         dist.barrier()
         composite_ms = timed_launches(max(10, K // 4), lambda: comp.allgather_rows(frames[0]))
         t = torch.tensor([composite_ms], dtype=torch.float64, device=dev)
@@ -458,6 +462,9 @@ def run_rank(args) -> int:
         if distributed:
             out["kernel_only"] = {"ms_per_step": round(kernel_ms_max, 4),
                                   "Mpixels_per_s": round(pixels_step / kernel_ms_max / 1e3, 1),
+                                  "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
+                                  "per_rank_roofline_frac": [round(px_ * ALGORITHMIC_BYTES_PER_PIXEL / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                             if ms > 0 else None for ms, px_ in zip(per_rank_kernel_ms, per_rank_pixels)],
                                   "note": "the band kernels alone, max over ranks, no composite"}
             out["composite_allgather_ms"] = round(composite_ms, 4)
             out["composite_rgba8_allgather_ms"] = round(composite_ldr_ms, 4)
