@@ -63,6 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-single-gpu-reference", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--launch-timeout-s", type=float, default=1500.0)
+    ap.add_argument("--rehearse-distributed", action="store_true",
+                    help="N = 1 only: run the N > 1 code path on one GPU (process group of one rank, the library's RCCL "
+                         "communicator, comm stream, composite in the timed step) — every line of the multi-GPU path that "
+                         "one GPU can execute")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="no GPU: the ranks rendezvous over gloo, cut the frame into bands and composite a host frame "
                          "(covers the launcher and the band arithmetic; tests/test_bench_launch.py)")
@@ -217,9 +221,12 @@ def run_rank(args) -> int:
         return selftest_cpu(args, world, rank)
     import numpy as np
     import torch
-    distributed = world > 1
+    distributed = world > 1 or args.rehearse_distributed
     dist = None
     if distributed:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -255,7 +262,7 @@ def run_rank(args) -> int:
     frames = [torch.zeros((padded, fw, 4), dtype=torch.float16, device=dev) for _ in range(2 if composite == "overlap" else 1)]
     uniforms, push = scene["uniforms"], scene["push"]
     rect = (0, y0, fw, y1)
-    comp = sharded.Compositor(world, rank, renderer=r) if distributed else None
+    comp = sharded.Compositor(world, rank, renderer=r, single_rank_comm=args.rehearse_distributed) if distributed else None
     torch.cuda.synchronize()
 
     compute = torch.cuda.current_stream()
@@ -392,7 +399,9 @@ def run_rank(args) -> int:
             gw = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh), dev)
             whole = torch.zeros((fh, fw, 4), dtype=torch.float16, device=dev)
             fn = lambda: r.shade_transmission(gw, uniforms, push, pyr, whole)   # noqa: E731
-            timed_launches(64, fn)
+            t_r = time.perf_counter()      # (the GPU idled while the host made the planes: ramp its clocks again)
+            while time.perf_counter() - t_r < 0.05:
+                timed_launches(16, fn)
             single_gpu_ms = timed_launches(K, fn)
             del gw, whole
         dist.barrier()

@@ -48,12 +48,15 @@ def padded_rows(height: int, world: int) -> int:
 class Compositor:
     """In-place all-gather of equal row bands of a (rows_per_rank * world, W, C) device or host tensor."""
 
-    def __init__(self, world: int, rank: int, renderer=None, group=None, prefer_library: bool = True):
+    def __init__(self, world: int, rank: int, renderer=None, group=None, prefer_library: bool = True,
+                 single_rank_comm: bool = False):
+        """single_rank_comm: make the library's communicator for world == 1 as well (the one-GPU rehearsal of the
+        multi-GPU path: bench.py --rehearse-distributed)."""
         self.world, self.rank, self.group = world, rank, group
         self.renderer = renderer
         self._comm = C.c_void_p()
         self.backend = "none" if world == 1 else "torch.distributed:" + dist.get_backend(group)
-        if world > 1 and renderer is not None and prefer_library:
+        if (world > 1 or single_rank_comm) and renderer is not None and prefer_library:
             self._try_library_comm()
 
     def _try_library_comm(self):
@@ -85,7 +88,7 @@ class Compositor:
 
     def allgather_rows(self, frame: torch.Tensor) -> None:
         """frame: (rows_per_rank * world, W, C) contiguous; every rank has written its own band."""
-        if self.world == 1:
+        if self.world == 1 and not self._comm.value:
             return
         assert frame.is_contiguous() and frame.shape[0] % self.world == 0, "gathered buffers hold world * rows_per_rank rows"
         rows = frame.shape[0] // self.world
