@@ -420,7 +420,7 @@ __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, co
                                                              const tr_layer_planes out, uint32_t* __restrict__ tile_cover,
                                                              uint32_t* __restrict__ tile_list, uint32_t* __restrict__ tile_list_count,
                                                              const uint32_t* __restrict__ material_flags /* tr_dmat::flags, stride in words */,
-                                                             uint32_t flags_stride) {
+                                                             uint32_t flags_stride, bool ids_of_untouched_tiles) {
 #pragma clang fp contract(off)
     const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (px >= f.width || py >= f.height) return;
@@ -429,7 +429,9 @@ __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, co
     // has no fragment, its visibility words need not be read
     const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
     if (as_constant(tile_cover)[tile] == 0u) {
-        out.material_id[pix] = TR_NOT_COVERED;
+        // (inside the frame recorder the shading launches skip untouched tiles by this very word and never read their
+        //  ids: 4 B per pixel of mostly empty layers saved)
+        if (ids_of_untouched_tiles) out.material_id[pix] = TR_NOT_COVERED;
         return;
     }
     const unsigned long long key = vis[pix];
@@ -576,9 +578,10 @@ __global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const tr_
 }
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two,
                                                              uint32_t first_layer, const uint32_t* __restrict__ material_flags,
-                                                             uint32_t flags_stride) {
+                                                             uint32_t flags_stride, uint32_t ids_of_untouched_tiles) {
     TR_PICK_LAYER(two, blockIdx.z + first_layer);
-    raster_resolve_body(g, f, W.records, W.vis, W.planes, W.tile_cover, W.tile_list, W.tile_list_count, material_flags, flags_stride);
+    raster_resolve_body(g, f, W.records, W.vis, W.planes, W.tile_cover, W.tile_list, W.tile_list_count, material_flags, flags_stride,
+                        ids_of_untouched_tiles != 0u);
 }
 
 }  // namespace tr

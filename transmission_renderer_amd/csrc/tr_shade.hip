@@ -1105,7 +1105,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     if (ensure_digested(ctx, stream) == TR_OK)
         mat_flags = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctx->d_dmats) + offsetof(tr_dmat, flags));
     hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two, 0u,
-                       mat_flags, (uint32_t)(sizeof(tr_dmat) / 4u));
+                       mat_flags, (uint32_t)(sizeof(tr_dmat) / 4u), fused_demux ? 0u : 1u);   // (fused = the frame recorder's call)
     TR_HIP(ctx, hipGetLastError());
     ctx->vis_clean = true;
     return TR_OK;
