@@ -40,9 +40,13 @@ struct alignas(16) tr_tri_record {
     uint32_t v[3];            // vertex indices
     uint32_t instance;
     uint32_t flags;           // bit0: alpha clipped draw
-    uint32_t _pad[2];
+    uint32_t material_id;     // of the instance
+    float scale;              // of the instance (translation_and_scale.w)
+    // the vertex stage's outputs per corner (vertex_instanced_with_scale: world position, rotated normal, uv), so the
+    // resolve interpolates without redoing three vertex stages per PIXEL
+    float P[3][3], N[3][3], T[3][2];
 };
-static_assert(sizeof(tr_tri_record) == 96, "tr_tri_record is 96 B");
+static_assert(sizeof(tr_tri_record) == 192, "tr_tri_record is 192 B");
 
 struct tr_layer_counts {      // written by scan_draws / scan_items, read by the later kernels of the layer
     uint32_t num_draws_first;  // draws taken from the layer's first buffer
@@ -161,8 +165,11 @@ __device__ __forceinline__ void raster_setup_body(const tr_geometry_view g, cons
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         r.v[k] = g.index[c.first_index + tri * 3u + (uint32_t)k] + (uint32_t)c.vertex_offset;
-        float world[3], clip[4];
-        vertex_stage(g, inst, f.proj_view, r.v[k], world, clip);
+        float clip[4];
+        vertex_stage(g, inst, f.proj_view, r.v[k], r.P[k], clip);
+        quat_rotate(inst.rotation, g.normal[r.v[k] * 3u], g.normal[r.v[k] * 3u + 1u], g.normal[r.v[k] * 3u + 2u], r.N[k]);
+        r.T[k][0] = g.uv[r.v[k] * 2u];
+        r.T[k][1] = g.uv[r.v[k] * 2u + 1u];
         X[k] = (clip[0] + clip[3]) * hw;
         Y[k] = (clip[1] + clip[3]) * hh;
         W[k] = clip[3];
@@ -201,7 +208,8 @@ __device__ __forceinline__ void raster_setup_body(const tr_geometry_view g, cons
     }
     r.instance = inst_id;
     r.flags = (second && alpha_buffer_b) ? 1u : 0u;
-    r._pad[0] = r._pad[1] = 0u;
+    r.material_id = inst.material_id;
+    r.scale = inst.translation_and_scale[3];
     records[t] = r;
     item_counts[t] = items;
 }
@@ -360,18 +368,11 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             if (hit && alpha_clip) {
                 // implicit-LOD fetch of the diffuse texture: uv at the two quad partners from the same triangle
                 // (what helper invocations compute), differences oriented like dFdx / dFdy
-                const tr_instance& inst = g.instances[rec.instance];
-                const tr_material_info& m = alpha.materials[inst.material_id];
+                const tr_material_info& m = alpha.materials[rec.material_id];
                 float alpha_v = m.diffuse_factor[3];
                 const int32_t tex_id = m.textures.diffuse;
                 if (tex_id >= 0 && (uint32_t)tex_id < alpha.num_textures) {
-                    float uvv[3][2];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        uvv[k][0] = g.uv[rec.v[k] * 2u];
-                        uvv[k][1] = g.uv[rec.v[k] * 2u + 1u];
-                    }
-                    auto uv_at = [&](const float l[3], int c) { return (l[0] * uvv[0][c] + l[1] * uvv[1][c]) + l[2] * uvv[2][c]; };
+                    auto uv_at = [&](const float l[3], int c) { return (l[0] * rec.T[0][c] + l[1] * rec.T[1][c]) + l[2] * rec.T[2][c]; };
                     float lx[3], ly[3], dd;
                     tri_pixel(rec, (float)(px ^ 1u) + 0.5f, (float)py + 0.5f, lx, dd);
                     tri_pixel(rec, (float)px + 0.5f, (float)(py ^ 1u) + 0.5f, ly, dd);
@@ -440,7 +441,7 @@ __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, co
     {
         uint32_t cls = 0u;
         if (key != 0ull) {
-            const uint32_t mat = g.instances[records[(uint32_t)key].instance].material_id;
+            const uint32_t mat = records[(uint32_t)key].material_id;
             const uint32_t fl = material_flags ? material_flags[(size_t)mat * flags_stride] & 12u : 0xFFFFFFFFu;
             cls = fl == 0xFFFFFFFFu ? 6u : (fl == 4u ? 2u : 4u);
         }
@@ -458,26 +459,19 @@ __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, co
     // The resolve is the last reader of a visibility word: it leaves the buffer zeroed for the next frame, so a frame
     // clears only the words it set instead of filling both whole-frame buffers (133 MB at 4K, 21 us) up front.
     vis[pix] = 0ull;
-    const tr_tri_record rec = records[(uint32_t)key];
-    const tr_instance inst = g.instances[rec.instance];
+    const tr_tri_record& rec = records[(uint32_t)key];
     float lam[3], depth;
     tri_pixel(rec, (float)px + 0.5f, (float)py + 0.5f, lam, depth);
-    float P[3][3], N[3][3], T[3][2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const uint32_t vi = rec.v[k];
-        similarity_apply(inst, g.position[vi * 3u], g.position[vi * 3u + 1u], g.position[vi * 3u + 2u], P[k]);
-        quat_rotate(inst.rotation, g.normal[vi * 3u], g.normal[vi * 3u + 1u], g.normal[vi * 3u + 2u], N[k]);
-        T[k][0] = g.uv[vi * 2u];
-        T[k][1] = g.uv[vi * 2u + 1u];
-    }
+    const auto& P = rec.P;
+    const auto& N = rec.N;
+    const auto& T = rec.T;
     auto mix = [&](float a, float b, float c) { return (lam[0] * a + lam[1] * b) + lam[2] * c; };
     out.pos_depth[pix] = float4{mix(P[0][0], P[1][0], P[2][0]), mix(P[0][1], P[1][1], P[2][1]), mix(P[0][2], P[1][2], P[2][2]),
                                 __uint_as_float((uint32_t)(key >> 32))};
     out.nrm_scale[pix] = float4{mix(N[0][0], N[1][0], N[2][0]), mix(N[0][1], N[1][1], N[2][1]), mix(N[0][2], N[1][2], N[2][2]),
-                                inst.translation_and_scale[3]};
+                                rec.scale};
     out.uv[pix] = float2{mix(T[0][0], T[1][0], T[2][0]), mix(T[0][1], T[1][1], T[2][1])};
-    out.material_id[pix] = inst.material_id;
+    out.material_id[pix] = rec.material_id;
 }
 
 
