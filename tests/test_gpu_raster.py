@@ -264,3 +264,89 @@ def test_record_frame_equals_the_stepwise_sequence(renderer, ggx_lut):
         torch.cuda.synchronize()
         assert torch.equal(got_hdr.view(torch.int16), hdr2.view(torch.int16)) and torch.equal(got_ldr, ldr2)
         assert (got_hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
+
+
+def _stepwise_frame(r, sc, culling, view, q, aabbs, w, h, dtype=torch.float16):
+    from transmission_renderer_amd.renderer import OpaquePyramid
+    r.assign_lights_to_clusters(view, q, aabbs)
+    o, t = r.new_layer(w, h), r.new_layer(w, h)
+    r.draw_scene(culling, sc["push"], o, t)
+    pyr = OpaquePyramid(w, h, r.device)
+    hdr = torch.zeros((h, w, 4), dtype=dtype, device=r.device)
+    r.record(o, t, sc["uniforms"], sc["push"], hdr, pyr)
+    torch.cuda.synchronize()
+    return hdr
+
+
+def test_record_frame_shades_from_visibility_words_mixed_classes(renderer, ggx_lut, tmp_path):
+    """The frame recorder shades RGBA16F frames straight from the rasteriser's visibility words (no resolve, no planes):
+    bit for bit the stepwise sequence through the TGB-v1 planes, on a glTF scene that mixes untextured, lite-class,
+    full-class and transmissive materials; frame sizes change between frames (the visibility buffers are re-laid out
+    and must come back clean), the camera moves, and an RGBA32F frame goes through the planes."""
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1] / "tools"))
+    import make_demo_gltf
+    from transmission_renderer_amd import gltf
+    r = renderer
+    glb = str(tmp_path / "demo.glb")
+    make_demo_gltf.main(glb)
+    loaded = gltf.load_gltf(glb, base_transform=meshes.Similarity(np.array([0.0, 2.0, 0.0], np.float32), 1.0))
+    geo = loaded.geometry()
+    flags = []
+    cams = (wire.default_camera()[1], wire.look_at_rh((3.5, 2.5, -7.0), (0.0, 1.5, -3.0), (0.0, 1.0, 0.0)),
+            wire.look_at_rh((-2.5, 3.0, -6.5), (0.5, 1.8, -3.0), (0.0, 1.0, 0.0)))
+    work = {}
+    for k, (view, (w, h), dtype) in enumerate(zip(cams + cams[:1], ((640, 360), (482, 274), (640, 360), (640, 360)),
+                                                  (torch.float16, torch.float16, torch.float16, torch.float32))):
+        sc = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False)
+        sc["materials"] = loaded.materials
+        sc["textures"] = loaded.textures
+        eye = np.linalg.inv(np.asarray(view, np.float64).T)[:3, 3]
+        sc["push"] = wire.make_push_constants(w, h, eye=eye.astype(np.float32), view=view)
+        q = wire.view_rotation_inverse(view)
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+        r.upload_materials(sc["materials"])
+        r.upload_textures(sc["textures"])
+        r.upload_lights(sc["lights"])
+        r.upload_geometry(geo)
+        aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+        if (w, h) not in work:
+            work[(w, h)] = r.new_frame_buffers(w, h)
+        wk = dict(work[(w, h)])
+        if dtype == torch.float32:
+            wk["hdr"] = torch.zeros((h, w, 4), dtype=torch.float32, device=r.device)
+        for _ in range(2):   # (the second frame of each pair starts from what the first left behind)
+            hdr, _ldr = r.record_frame(sc["uniforms"], sc["push"], culling, view, q, aabbs, wk, tonemap=dtype == torch.float16)
+            torch.cuda.synchronize()
+        want = _stepwise_frame(r, sc, culling, view, q, aabbs, w, h, dtype)
+        bits = torch.int16 if dtype == torch.float16 else torch.int32
+        assert torch.equal(hdr.view(bits), want.view(bits)), f"frame {k} ({w}x{h}, {dtype})"
+        assert (hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
+        flags.append(k)
+    assert len(flags) == 4
+
+
+def test_record_frame_from_visibility_words_untextured(ggx_lut):
+    """The same for a scene without a single texture slot (the kernels the headline bench runs, fed from visibility words)."""
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    r = TransmissionRenderer(0)
+    r.upload_ggx_lut(ggx_lut)
+    w, h = 514, 290
+    geo = meshes.make_mesh_scene(extra_instances=True)
+    for view in (wire.default_camera()[1], wire.look_at_rh((3.5, 2.0, -6.0), (0.0, 1.2, -3.0), (0.0, 1.0, 0.0))):
+        sc = synthetic.make_scene(w, h, num_point_lights=3, textured=False, with_gbuffer=False)
+        eye = np.linalg.inv(np.asarray(view, np.float64).T)[:3, 3]
+        sc["push"] = wire.make_push_constants(w, h, eye=eye.astype(np.float32), view=view)
+        q = wire.view_rotation_inverse(view)
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+        r.upload_materials(sc["materials"])
+        r.upload_lights(sc["lights"])
+        r.upload_geometry(geo)
+        aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+        work = r.new_frame_buffers(w, h)
+        for _ in range(2):
+            hdr, _ldr = r.record_frame(sc["uniforms"], sc["push"], culling, view, q, aabbs, work)
+            torch.cuda.synchronize()
+        want = _stepwise_frame(r, sc, culling, view, q, aabbs, w, h)
+        assert torch.equal(hdr.view(torch.int16), want.view(torch.int16))
+        assert (hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2

@@ -40,6 +40,7 @@
 
 #include "tr_common.h"
 #include "tr_texture_kernels.h"
+#include "tr_visibility.h"
 
 namespace tr {
 
@@ -202,8 +203,14 @@ struct tr_launch {
     const float* srgb_to_linear;        // 256 entries
     const float* slice_thr;             // [slice_max + 2] depth thresholds of get_depth_slice, see depth_slice()
     const uint32_t* tile_list;          // optional (TEX = 2 launches inside the frame recorder): the block tiles that hold
-    const uint32_t* tile_list_count;    // fragments of a full-class material, and their number (raster_resolve_body)
+    const uint32_t* tile_list_count;    // fragments of a full-class material, and their number
     const uint32_t* tile_cover;         // optional: one word per 64x4 block tile of the frame, 0 = the layer has no fragment there
+                                        // (bit 1 / bit 2: fragments of a full-class material / of any other, raster_kernel)
+    uint32_t* list_build;               // optional (TEX = 1 launches inside the frame recorder): where this launch lists the
+    uint32_t* list_build_count;         // tiles whose coverage word has bit 1 set, for the TEX = 2 launch behind it
+    // VIS launches (the frame recorder): the layer's visibility words and triangle records instead of the planes
+    unsigned long long* vis;
+    const tr_tri_record* records;
     uint32_t* tile_counters;            // per XCD kSubCounters tile counters + one count of finished waves, 256 bytes apart
 };
 typedef const TR_CONSTANT tr_launch claunch;
@@ -1178,6 +1185,7 @@ struct tile_regs {
     float4 pd, ns;
     float2 uv;                                        // TEXTURED only
     uint32_t mat, cluster_x, cluster_y_term, px, py;  // (the two table values are only added when used)
+    uint32_t cover;                                   // (scalar) the block tile's coverage word
 };
 
 // Experiments only: an occupancy target for the register allocator, e.g. -DTR_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(TEXTURED ? 5 : 8)))'
@@ -1193,7 +1201,12 @@ struct tile_regs {
 // a full-class material is uploaded, one of TEX = 2: the common materials do not pay for the registers of the eight-slot
 // sampling front end (120 VGPRs = 4 waves per SIMD; TEX = 1 holds 7-8).
 constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2;
-template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, int TEX = kTexNone>
+// VIS (the frame recorder's launches): a pixel's inputs are interpolated here from the rasteriser's visibility word and
+// triangle record (vis_interpolate, the resolve's own arithmetic) instead of being read from TGB-v1 planes, which the
+// frame then never writes: 60 B per covered pixel less traffic (8 B word read + zeroed instead of 8 + 8 + 44 written by
+// the resolve and 44 read back here).  The launch that shades a pixel — or, in a tile listed for the TEX = 2 launch, that
+// launch for every pixel, so that its quad partners of the other class are still there — zeroes the word for the next frame.
+template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, int TEX = kTexNone, bool VIS = false>
 __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
     constexpr bool TEXTURED = TEX != kTexNone;
     const uint32_t block_waves = blockDim.x >> 6;   // 4, or 1 (TR_WAVE_BLOCKS: one wave per workgroup)
@@ -1243,6 +1256,13 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         // landed there; bit 1 / bit 2 = fragments of a full-class material / of any other (raster_resolve_body): a
         // launch skips the tiles that hold nothing of the classes it shades without touching their planes
         const uint32_t cover = (!TR_TILE_8X8 && F->tile_cover) ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
+        t.cover = cover;
+        if constexpr (TEX == kTexLite) {
+            // the tile may hold full-class fragments: listed for the TEX = 2 launch behind this one (once: by the wave of
+            // the tile's first quarter)
+            if (F->list_build && (cover & 2u) && cover != 0xFFFFFFFFu && (j & 3u) == 0u && lane == 0u)
+                F->list_build[atomicAdd(F->list_build_count, 1u)] = tile;
+        }
         if (cover == 0u || (TEX == kTexFull && !(cover & 2u))) {
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
@@ -1264,6 +1284,24 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         // lists the kernel keeps re-reading from L2 (measured 115 -> 111 us)
         typedef float f4v __attribute__((ext_vector_type(4)));
         typedef float f2v __attribute__((ext_vector_type(2)));
+        if constexpr (VIS) {
+            // (whole-frame launches only: the rect is the frame, its pitch the visibility buffer's)
+            const unsigned long long key = ld<unsigned long long>(F->vis, gpix * 8u);
+            t.mat = TR_NOT_COVERED;
+            t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
+            t.uv = float2{0.f, 0.f};
+            if (key != 0ull) {
+                vis_fragment v;
+                vis_interpolate(F->records[(uint32_t)key], key, cx, cy, v);
+                t.pd = float4{v.position[0], v.position[1], v.position[2], v.depth};
+                t.ns = float4{v.normal[0], v.normal[1], v.normal[2], v.scale};
+                if constexpr (TEXTURED) t.uv = float2{v.uv[0], v.uv[1]};
+                t.mat = v.material_id;
+            }
+            t.cluster_x = (uint32_t)ld<uint16_t>(F->cluster_x, cx * 2u);
+            t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
+            return;
+        }
         if (TEX == kTexFull && !listed && !F->fp.solo_full) {
             // (a FULL-class launch beside a TEX = 1 launch without a tile list — the host always provides one, this is
             //  the safety net: material ids (4 B per pixel) and their class first, the other planes (40 B per pixel)
@@ -1462,6 +1500,12 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
             const bool mine = ((shaded >> (threadIdx.x & 63u)) & 1ull) != 0ull;
             const bool clears = TEX == kTexLite || S->fp.solo_full != 0u;   // (the launch that writes the opaque pass's clear colour)
             write = TRANSMISSIVE ? mine : (clears ? (inside && (mine || cur_mat_uncovered)) : mine);
+        }
+        if constexpr (VIS) {
+            // the last reader of a visibility word leaves it zeroed for the next frame (see the template's comment)
+            bool last = active;
+            if constexpr (TEX == kTexLite) last = active && (cur.cover & 2u) == 0u;   // (bit 1: the TEX = 2 launch visits the tile)
+            if (last) st<unsigned long long>(launder(L)->vis, mad24(out_py, launder(L)->fp.width, out_px) * 8u, 0ull);
         }
         if (write && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
             claunch* W = launder(L);

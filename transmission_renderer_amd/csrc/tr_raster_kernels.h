@@ -21,6 +21,7 @@
 #pragma once
 
 #include "tr_geometry_kernels.h"
+#include "tr_visibility.h"
 #include "tr_texture_kernels.h"
 
 namespace tr {
@@ -32,21 +33,6 @@ struct tr_geometry_view {
     const uint32_t* index;
     const tr_instance* instances;
 };
-
-struct alignas(16) tr_tri_record {
-    float A[3], B[3], C[3];   // edge functions (positive inside)
-    float z[3], w[3];         // clip z, w per vertex
-    uint16_t x0, y0, x1, y1;  // inclusive pixel bounds (x0 > x1: culled / empty)
-    uint32_t v[3];            // vertex indices
-    uint32_t instance;
-    uint32_t flags;           // bit0: alpha clipped draw
-    uint32_t material_id;     // of the instance
-    float scale;              // of the instance (translation_and_scale.w)
-    // the vertex stage's outputs per corner (vertex_instanced_with_scale: world position, rotated normal, uv), so the
-    // resolve interpolates without redoing three vertex stages per PIXEL
-    float P[3][3], N[3][3], T[3][2];
-};
-static_assert(sizeof(tr_tri_record) == 192, "tr_tri_record is 192 B");
 
 struct tr_layer_counts {      // written by scan_draws / scan_items, read by the later kernels of the layer
     uint32_t num_draws_first;  // draws taken from the layer's first buffer
@@ -149,7 +135,9 @@ __device__ __forceinline__ void raster_setup_body(const tr_geometry_view g, cons
                                                            const uint32_t* __restrict__ tri_base,
                                                            const tr_layer_counts* __restrict__ counts, uint32_t alpha_buffer_b,
                                                            tr_tri_record* __restrict__ records,
-                                                           uint32_t* __restrict__ item_counts) {
+                                                           uint32_t* __restrict__ item_counts,
+                                                           const uint32_t* __restrict__ material_flags /* tr_dmat::flags or null */,
+                                                           uint32_t flags_stride /* in words */) {
 #pragma clang fp contract(off)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= counts->num_triangles) return;
@@ -207,7 +195,9 @@ __device__ __forceinline__ void raster_setup_body(const tr_geometry_view g, cons
         r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0;
     }
     r.instance = inst_id;
-    r.flags = (second && alpha_buffer_b) ? 1u : 0u;
+    // the class of the material, for the tile coverage words the shading launches steer by (shade_kernel's TEX launches)
+    const uint32_t cls = material_flags ? ((material_flags[(size_t)inst.material_id * flags_stride] & 12u) == 4u ? 2u : 4u) : 6u;
+    r.flags = ((second && alpha_buffer_b) ? 1u : 0u) | cls;
     r.material_id = inst.material_id;
     r.scale = inst.translation_and_scale[3];
     records[t] = r;
@@ -273,43 +263,6 @@ __device__ __forceinline__ void raster_scan_items_apply_body(const uint32_t* __r
         running += total;
     }
     if (first + kScanChunk >= n && threadIdx.x == 0) item_base[n] = running;   // the last chunk closes the prefix
-}
-
-// Barycentrics and depth at a pixel centre (oracle: tri_pixel).  `rec` is wave-uniform in the raster kernel
-// (scalar registers) and per lane in the resolve.
-// The three edge functions at a pixel centre and the top-left-rule inside test.
-template <class Rec>
-__device__ __forceinline__ bool tri_edges(const Rec& rec, float pxc, float pyc, float fv[3]) {
-#pragma clang fp contract(off)
-    bool inside = true;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        fv[i] = (rec.A[i] * pxc + rec.B[i] * pyc) + rec.C[i];
-        const bool tie = rec.A[i] > 0.0f || (rec.A[i] == 0.0f && rec.B[i] > 0.0f);
-        inside &= fv[i] > 0.0f || (fv[i] == 0.0f && tie);
-    }
-    return inside;
-}
-
-// Barycentrics and depth from the edge values; true if the fragment survives clipping and the depth range.
-template <class Rec>
-__device__ __forceinline__ bool tri_depth(const Rec& rec, const float fv[3], float lambda[3], float& depth) {
-#pragma clang fp contract(off)
-    const float sum = (fv[0] + fv[1]) + fv[2];
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) lambda[i] = fv[i] * inv;
-    const float zc = (lambda[0] * rec.z[0] + lambda[1] * rec.z[1]) + lambda[2] * rec.z[2];
-    const float wc = (lambda[0] * rec.w[0] + lambda[1] * rec.w[1]) + lambda[2] * rec.w[2];
-    depth = zc / wc;
-    return sum > 0.0f && wc > 0.0f && zc <= wc && depth > 0.0f;
-}
-
-template <class Rec>
-__device__ __forceinline__ bool tri_pixel(const Rec& rec, float pxc, float pyc, float lambda[3], float& depth) {
-    float fv[3];
-    const bool inside = tri_edges(rec, pxc, pyc, fv);
-    return tri_depth(rec, fv, lambda, depth) && inside;
 }
 
 struct tr_alpha_tables {        // what the alpha-clip kill reads (depth_pre_pass_alpha_clip, shader/src/lib.rs:269-292)
@@ -392,14 +345,17 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
                 hit = !(alpha_v < m.alpha_clipping_cutoff);
             }
             if (hit) atomicMax(&vis[pix], ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)t);
-            // the 64x4 block tiles that received a fragment (the 8x8 block lies in two of them, one above the other):
-            // the resolve and, inside tr_record_frame, the shading passes skip the others
+            // the 64x4 block tiles that received a fragment (the 8x8 block lies in two of them, one above the other), and
+            // the material classes of what landed there (bit 0 = touched, bit 1 = full-class textured, bit 2 = any other;
+            // conservative: a fragment that loses the depth test later has tagged its tile all the same).  The resolve
+            // and the shading launches skip tiles by these words.
             const unsigned long long hits = ballot(hit);
             if (hits != 0ull && lane == 0u) {
                 const uint32_t cover_w = (f.width + 63u) >> 6;
                 uint32_t* c = tile_cover + (size_t)(by * 2u) * cover_w + (bx >> 3);
-                if ((uint32_t)hits != 0u) c[0] = 1u;
-                if ((uint32_t)(hits >> 32) != 0u) c[cover_w] = 1u;
+                const uint32_t bits = 1u | (rec.flags & 6u);
+                if ((uint32_t)hits != 0u) atomicOr(c, bits);
+                if ((uint32_t)(hits >> 32) != 0u) atomicOr(c + cover_w, bits);
             }
         }
       }
@@ -413,16 +369,10 @@ struct tr_layer_planes {
     uint32_t* material_id;
 };
 
-// One thread per pixel: the winning triangle's attributes at the pixel centre (vertex_instanced_with_scale outputs,
-// perspective-correct), or "no fragment".
-__device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, const tr_raster_frame f,
-                                                             const tr_tri_record* __restrict__ records,
-                                                             unsigned long long* __restrict__ vis,
-                                                             const tr_layer_planes out, uint32_t* __restrict__ tile_cover,
-                                                             uint32_t* __restrict__ tile_list, uint32_t* __restrict__ tile_list_count,
-                                                             const uint32_t* __restrict__ material_flags /* tr_dmat::flags, stride in words */,
-                                                             uint32_t flags_stride, bool ids_of_untouched_tiles) {
-#pragma clang fp contract(off)
+// One thread per pixel: the winning triangle's attributes at the pixel centre (vis_interpolate), or "no fragment".
+__device__ __forceinline__ void raster_resolve_body(const tr_raster_frame f, const tr_tri_record* __restrict__ records,
+                                                    unsigned long long* __restrict__ vis, const tr_layer_planes out,
+                                                    const uint32_t* __restrict__ tile_cover, bool ids_of_untouched_tiles) {
     const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (px >= f.width || py >= f.height) return;
     const size_t pix = (size_t)py * f.width + px;
@@ -430,28 +380,10 @@ __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, co
     // has no fragment, its visibility words need not be read
     const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
     if (as_constant(tile_cover)[tile] == 0u) {
-        // (inside the frame recorder the shading launches skip untouched tiles by this very word and never read their
-        //  ids: 4 B per pixel of mostly empty layers saved)
         if (ids_of_untouched_tiles) out.material_id[pix] = TR_NOT_COVERED;
         return;
     }
     const unsigned long long key = vis[pix];
-    // The tile's word also tells the shading launches which material CLASSES its fragments belong to (shade_kernel's
-    // TEX launches): bit 1 = a full-class textured material, bit 2 = anything else.  One atomic per wave.
-    {
-        uint32_t cls = 0u;
-        if (key != 0ull) {
-            const uint32_t mat = records[(uint32_t)key].material_id;
-            const uint32_t fl = material_flags ? material_flags[(size_t)mat * flags_stride] & 12u : 0xFFFFFFFFu;
-            cls = fl == 0xFFFFFFFFu ? 6u : (fl == 4u ? 2u : 4u);
-        }
-        const uint32_t bits = (__builtin_amdgcn_ballot_w64((cls & 2u) != 0u) ? 2u : 0u) | (__builtin_amdgcn_ballot_w64((cls & 4u) != 0u) ? 4u : 0u);
-        if (bits && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(true)) - 1)) {
-            const uint32_t before = atomicOr(&tile_cover[tile], bits);
-            // the first wave to tag the tile as holding full-class fragments also lists it for the TEX = 2 launch
-            if ((bits & 2u) && !(before & 2u)) tile_list[atomicAdd(tile_list_count, 1u)] = tile;
-        }
-    }
     if (key == 0ull) {   // no fragment: only the id plane is defined there (the shading passes look at nothing else)
         out.material_id[pix] = TR_NOT_COVERED;
         return;
@@ -459,19 +391,12 @@ __device__ __forceinline__ void raster_resolve_body(const tr_geometry_view g, co
     // The resolve is the last reader of a visibility word: it leaves the buffer zeroed for the next frame, so a frame
     // clears only the words it set instead of filling both whole-frame buffers (133 MB at 4K, 21 us) up front.
     vis[pix] = 0ull;
-    const tr_tri_record& rec = records[(uint32_t)key];
-    float lam[3], depth;
-    tri_pixel(rec, (float)px + 0.5f, (float)py + 0.5f, lam, depth);
-    const auto& P = rec.P;
-    const auto& N = rec.N;
-    const auto& T = rec.T;
-    auto mix = [&](float a, float b, float c) { return (lam[0] * a + lam[1] * b) + lam[2] * c; };
-    out.pos_depth[pix] = float4{mix(P[0][0], P[1][0], P[2][0]), mix(P[0][1], P[1][1], P[2][1]), mix(P[0][2], P[1][2], P[2][2]),
-                                __uint_as_float((uint32_t)(key >> 32))};
-    out.nrm_scale[pix] = float4{mix(N[0][0], N[1][0], N[2][0]), mix(N[0][1], N[1][1], N[2][1]), mix(N[0][2], N[1][2], N[2][2]),
-                                rec.scale};
-    out.uv[pix] = float2{mix(T[0][0], T[1][0], T[2][0]), mix(T[0][1], T[1][1], T[2][1])};
-    out.material_id[pix] = rec.material_id;
+    vis_fragment v;
+    vis_interpolate(records[(uint32_t)key], key, px, py, v);
+    out.pos_depth[pix] = float4{v.position[0], v.position[1], v.position[2], v.depth};
+    out.nrm_scale[pix] = float4{v.normal[0], v.normal[1], v.normal[2], v.scale};
+    out.uv[pix] = float2{v.uv[0], v.uv[1]};
+    out.material_id[pix] = v.material_id;
 }
 
 
@@ -493,8 +418,6 @@ struct tr_layer_work {
     unsigned long long* vis;
     tr_layer_planes planes;
     uint32_t* tile_cover;                      // [ceil(h/4)][ceil(w/64)]: zeroed per frame, set by raster_kernel
-    uint32_t* tile_list;                       // the tiles with full-class fragments ...
-    uint32_t* tile_list_count;                 // ... and their number (zeroed per frame with the coverage maps)
 };
 struct tr_two_layers {
     tr_layer_work l[2];
@@ -550,10 +473,11 @@ __global__ __launch_bounds__(1024) void raster_scan_draws_kernel(const tr_two_la
     if (W.capacity_triangles == 0u) return;
     raster_scan_draws_body(W.draws_a, W.draws_b, draw_counts, W.buffer_a, capacity_draws, W.capacity_triangles, W.tri_base, W.counts);
 }
-__global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two) {
+__global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two,
+                                                           const uint32_t* __restrict__ material_flags, uint32_t flags_stride) {
     TR_PICK_LAYER(two, blockIdx.y);
     if (W.capacity_triangles == 0u) return;
-    raster_setup_body(g, f, W.draws_a, W.draws_b, W.tri_base, W.counts, 1u, W.records, W.item_counts);
+    raster_setup_body(g, f, W.draws_a, W.draws_b, W.tri_base, W.counts, 1u, W.records, W.item_counts, material_flags, flags_stride);
 }
 __global__ __launch_bounds__(1024) void raster_scan_items_reduce_kernel(const tr_two_layers two) {
     TR_PICK_LAYER(two, blockIdx.y);
@@ -570,12 +494,10 @@ __global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const tr_
     if (W.capacity_triangles == 0u) return;
     raster_scan_items_apply_body(W.item_counts, W.chunk_sums, W.counts, W.item_base);
 }
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two,
-                                                             uint32_t first_layer, const uint32_t* __restrict__ material_flags,
-                                                             uint32_t flags_stride, uint32_t ids_of_untouched_tiles) {
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_raster_frame f, const tr_two_layers two, uint32_t first_layer,
+                                                             uint32_t ids_of_untouched_tiles) {
     TR_PICK_LAYER(two, blockIdx.z + first_layer);
-    raster_resolve_body(g, f, W.records, W.vis, W.planes, W.tile_cover, W.tile_list, W.tile_list_count, material_flags, flags_stride,
-                        ids_of_untouched_tiles != 0u);
+    raster_resolve_body(f, W.records, W.vis, W.planes, W.tile_cover, ids_of_untouched_tiles != 0u);
 }
 
 }  // namespace tr

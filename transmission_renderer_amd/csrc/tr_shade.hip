@@ -86,6 +86,8 @@ struct tr_context {
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
     const uint32_t* list_hint = nullptr;               // ... with it: the layer's list of full-class tiles
+    unsigned long long* vis_hint = nullptr;            // ... and, when the frame skipped the resolve, the layer's visibility
+    const tr_tri_record* records_hint = nullptr;       //     words and triangle records: the shading launches read those (VIS)
     const uint32_t* list_count_hint = nullptr;
     uint32_t* d_tile_list_counts = nullptr;            // (inside the d_vis allocation, cleared with the coverage maps)
     uint32_t* d_tile_list[2] = {nullptr, nullptr};     // per layer: the tiles
@@ -454,6 +456,9 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
                        ? ctx->cover_hint : nullptr;
     L.tile_list = L.tile_cover ? ctx->list_hint : nullptr;
     L.tile_list_count = L.tile_list ? ctx->list_count_hint : nullptr;
+    L.list_build = L.list_build_count = nullptr;
+    L.vis = L.tile_cover ? ctx->vis_hint : nullptr;
+    L.records = L.vis ? ctx->records_hint : nullptr;
     L.slice_thr = ctx->d_slice_thr;
     L.cluster_x = ctx->d_cluster_x;
     L.cluster_y_term = ctx->d_cluster_y_term;
@@ -475,12 +480,25 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
 //   full-class materials present: one TEX = 2 launch over the block tiles that hold their pixels — the frame recorder's
 //   resolve has listed them; otherwise a classification launch over the material-id plane lists them first —,
 //   only full-class materials: the TEX = 2 launch alone, sweeping the rect like an untextured pass.
+// One launch of shade_kernel<TRANSMISSIVE, ., TEX, .>: RGBA16F or RGBA32F target; planes, or (RGBA16F inside the frame
+// recorder) the rasteriser's visibility words.
+template <bool TRANSMISSIVE, int TEX>
+void launch_shade(const tr_launch& L, bool half, dim3 grid, dim3 block, hipStream_t stream) {
+    if (half && L.vis) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, TEX, true>), grid, block, 0, stream, L);
+    else if (half) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, TEX, false>), grid, block, 0, stream, L);
+    else hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, float4, TEX, false>), grid, block, 0, stream, L);
+}
+
 template <bool TRANSMISSIVE>
 tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bool half, dim3 grid, dim3 block, bool wave_blocks,
                           hipStream_t stream) {
     if (ctx->any_plain_or_lite) {
-        if (half) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, kTexLite>), grid, block, 0, stream, L);
-        else hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, float4, kTexLite>), grid, block, 0, stream, L);
+        if (ctx->any_full_textured && L.tile_list) {   // (the frame recorder's buffers) the TEX = 1 launch lists the tiles itself
+            L.list_build = const_cast<uint32_t*>(L.tile_list);
+            L.list_build_count = const_cast<uint32_t*>(L.tile_list_count);
+        }
+        launch_shade<TRANSMISSIVE, kTexLite>(L, half, grid, block, stream);
+        L.list_build = L.list_build_count = nullptr;
         if (!ctx->any_full_textured) return TR_OK;
         if (!L.tile_list) {
             const size_t tiles = (size_t)L.fp.tiles_x * L.fp.tiles_y;
@@ -511,14 +529,12 @@ tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bo
         }
         // as many waves as the chip holds of this kernel (4 per SIMD), each striding over the list
         const dim3 grid2(wave_blocks ? ctx->num_cus * 16u : ctx->num_cus * 4u);
-        if (half) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, kTexFull>), grid2, block, 0, stream, L);
-        else hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, float4, kTexFull>), grid2, block, 0, stream, L);
+        launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid2, block, stream);
         return TR_OK;
     }
     L.fp.solo_full = 1u;
     L.tile_list = L.tile_list_count = nullptr;
-    if (half) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, kTexFull>), grid, block, 0, stream, L);
-    else hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, float4, kTexFull>), grid, block, 0, stream, L);
+    launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid, block, stream);
     return TR_OK;
 }
 
@@ -987,9 +1003,11 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
 namespace {
 // fused_demux: the caller has NOT demultiplexed: the first launch does it (from the context's own instance counts,
 // which it leaves zeroed) together with the draw scans of both layers.
+// resolve: write the TGB-v1 planes.  Without it the layers stay visibility words + triangle records, which the caller
+// hands to VIS shading launches (they zero the words; the caller sets ctx->vis_clean once both passes are enqueued).
 tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
                          const tr_push_constants* push, const tr_gbuffer_target* opaque,
-                         const tr_gbuffer_target* transmissive, void* stream_, bool fused_demux) {
+                         const tr_gbuffer_target* transmissive, void* stream_, bool fused_demux, bool resolve) {
     if (!ctx || !draw_counts || !draws || !push || !opaque || !transmissive) return TR_ERR_INVALID_ARGUMENT;
     for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k)
         if (!draws[k]) return TR_ERR_INVALID_ARGUMENT;
@@ -1062,8 +1080,6 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
         W.planes.uv = (float2*)targets[layer]->uv;
         W.planes.material_id = (uint32_t*)targets[layer]->material_id;
         W.tile_cover = ctx->d_tile_cover[layer];
-        W.tile_list = ctx->d_tile_list[layer];
-        W.tile_list_count = ctx->d_tile_list_counts + layer;
     }
     // The visibility buffers are zero on entry: filled once after (re)allocation, and every resolve zeroes the words its
     // frame set (raster_resolve_body).  Per frame only the two tile coverage maps are cleared (260 KB at 4K).
@@ -1071,6 +1087,11 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     ctx->vis_clean = false;   // (until this frame's resolve is enqueued)
     TR_HIP(ctx, hipMemsetAsync(ctx->d_tile_cover[0], 0, (2u * cover_tiles + 2u) * 4u, stream));
     const uint32_t max_cap = std::max(ctx->max_triangles[0], ctx->max_triangles[1]);
+    // (the set-up tags every triangle with its material's class for the tile coverage words the shading launches steer by:
+    //  needs the digested material table; without a GGX LUT there is none yet and every triangle is tagged with both classes)
+    const uint32_t* mat_flags = nullptr;
+    if (ensure_digested(ctx, stream) == TR_OK)
+        mat_flags = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctx->d_dmats) + offsetof(tr_dmat, flags));
     if (fused_demux) {
         tr_draw_buffers out;
         for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k) out.draws[k] = (tr_draw_command*)draws[k];
@@ -1082,7 +1103,8 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
         if (!fused_demux)
             hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1, 2), dim3(1024), 0, stream, two, (const uint32_t*)draw_counts,
                                ctx->num_primitives);
-        hipLaunchKernelGGL(raster_setup_kernel, dim3((max_cap + 255u) / 256u, 2), dim3(256), 0, stream, gv, fr, two);
+        hipLaunchKernelGGL(raster_setup_kernel, dim3((max_cap + 255u) / 256u, 2), dim3(256), 0, stream, gv, fr, two, mat_flags,
+                           (uint32_t)(sizeof(tr_dmat) / 4u));
         if (chunks <= kSmallScanChunks) {   // small layers: one launch for the work-item prefix
             hipLaunchKernelGGL(raster_scan_items_small_kernel, dim3(1, 2), dim3(1024), 0, stream, two);
         } else {
@@ -1099,15 +1121,12 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
                                ctx->d_vis[layer], ctx->d_tile_cover[layer]);
         }
     }
-    // (the resolve tags every tile with the material classes of its fragments for the shading launches: needs the
-    //  digested material table; without a GGX LUT there is none yet and every covered tile is tagged with both classes)
-    const uint32_t* mat_flags = nullptr;
-    if (ensure_digested(ctx, stream) == TR_OK)
-        mat_flags = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctx->d_dmats) + offsetof(tr_dmat, flags));
-    hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, gv, fr, two, 0u,
-                       mat_flags, (uint32_t)(sizeof(tr_dmat) / 4u), fused_demux ? 0u : 1u);   // (fused = the frame recorder's call)
+    if (resolve) {
+        hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, fr, two, 0u,
+                           fused_demux ? 0u : 1u);   // (fused = the frame recorder's call: its shading skips untouched tiles)
+        ctx->vis_clean = true;
+    }
     TR_HIP(ctx, hipGetLastError());
-    ctx->vis_clean = true;
     return TR_OK;
 }
 }  // namespace
@@ -1117,7 +1136,7 @@ extern "C" {
 tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
                        const tr_push_constants* push, const tr_gbuffer_target* opaque,
                        const tr_gbuffer_target* transmissive, void* stream) {
-    return rasterize_impl(ctx, draw_counts, draws, push, opaque, transmissive, stream, false);
+    return rasterize_impl(ctx, draw_counts, draws, push, opaque, transmissive, stream, false, true);
 }
 
 tr_status tr_draw_scene(tr_context* ctx, const tr_culling_push_constants* culling, const tr_push_constants* push,
@@ -1244,8 +1263,7 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
             const tr_status ls = launch_textured<false>(ctx, L, g, half, grid, block, wave_blocks, stream);
             if (ls != TR_OK) return ls;
         } else {
-            if (half) hipLaunchKernelGGL((shade_kernel<false, uint2>), grid, block, 0, stream, L);
-            else hipLaunchKernelGGL((shade_kernel<false, float4>), grid, block, 0, stream, L);
+            launch_shade<false, kTexNone>(L, half, grid, block, stream);
         }
     }
     TR_HIP(ctx, hipGetLastError());
@@ -1347,8 +1365,7 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
             const tr_status ls = launch_textured<true>(ctx, L, g, half, grid, block, wave_blocks, stream);
             if (ls != TR_OK) return ls;
         } else {
-            if (half) hipLaunchKernelGGL((shade_kernel<true, uint2>), grid, block, 0, stream, L);
-            else hipLaunchKernelGGL((shade_kernel<true, float4>), grid, block, 0, stream, L);
+            launch_shade<true, kTexNone>(L, half, grid, block, stream);
         }
     }
     TR_HIP(ctx, hipGetLastError());
@@ -1715,6 +1732,9 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     const uint32_t w = f->push->framebuffer_size[0], h = f->push->framebuffer_size[1];
     if (f->pyramid.width != w || f->pyramid.height != h) return TR_ERR_INVALID_ARGUMENT;
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
+    // RGBA16F frames are shaded straight from the rasteriser's visibility words (shade_kernel's VIS launches): no resolve,
+    // the work planes of the descriptor stay untouched.  RGBA32F frames go through the planes.
+    const bool use_vis = f->hdr_format == TR_FORMAT_RGBA16F;
     zone_scope all(rec, "all commands");
     tr_status st;
     void* draws[TR_NUM_DRAW_BUFFERS] = {ctx->d_draws[0], ctx->d_draws[1], ctx->d_draws[2], ctx->d_draws[3]};
@@ -1743,7 +1763,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         TR_HIP(ctx, hipGetLastError());
         st = tr_set_cluster_tables(ctx, f->cluster_light_counts, f->light_indices, f->num_clusters);
         if (st != TR_OK) return st;
-        st = rasterize_impl(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream, true);
+        st = rasterize_impl(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream, true, !use_vis);
         if (st != TR_OK) return st;
         ctx->counts_clean = true;   // (the fused demultiplex zeroed what it read)
     } else {
@@ -1769,7 +1789,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (st != TR_OK) return st;
     {   // the visibility-buffer rasteriser: stands for the depth pre-passes and the EQUAL-tested colour-pass draws
         zone_scope z(rec, "depth pre pass");
-        st = tr_rasterize(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream);
+        st = rasterize_impl(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream, false, !use_vis);
     }
     if (st != TR_OK) return st;
     }
@@ -1791,8 +1811,12 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->cover_hint = ctx->d_tile_cover[0];
         ctx->list_hint = ctx->d_tile_list[0];
         ctx->list_count_hint = ctx->d_tile_list_counts;
+        ctx->vis_hint = use_vis ? ctx->d_vis[0] : nullptr;
+        ctx->records_hint = ctx->d_records;
         st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
         ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
+        ctx->vis_hint = nullptr;
+        ctx->records_hint = nullptr;
     }
     if (st != TR_OK) return st;
     {
@@ -1805,10 +1829,15 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->cover_hint = ctx->d_tile_cover[1];
         ctx->list_hint = ctx->d_tile_list[1];
         ctx->list_count_hint = ctx->d_tile_list_counts + 1;
+        ctx->vis_hint = use_vis ? ctx->d_vis[1] : nullptr;
+        ctx->records_hint = ctx->d_records + ctx->work_capacity;
         st = tr_shade_transmission(ctx, &layers[1], f->uniforms, f->push, &f->pyramid, f->hdr, f->hdr_format, whole, stream);
         ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
+        ctx->vis_hint = nullptr;
+        ctx->records_hint = nullptr;
     }
     if (st != TR_OK) return st;
+    if (use_vis) ctx->vis_clean = true;   // (both passes enqueued: every visibility word the frame set is zeroed again)
     if (f->ldr_out) {
         zone_scope z(rec, "tonemapping");
         st = tr_tonemap(ctx, f->hdr, w, h, f->tonemap, f->ldr_out, f->bgra, stream);
