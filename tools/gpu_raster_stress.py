@@ -2,7 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from transmission_renderer_amd import meshes, synthetic, wire
+from transmission_renderer_amd import _lib, meshes, synthetic, wire
+if os.environ.get("TR_AB_LIB"):            # an A/B build of the library (tools/build_variant.py)
+    _lib.LIB_PATH = os.path.abspath(os.environ["TR_AB_LIB"])
 from transmission_renderer_amd.renderer import TransmissionRenderer
 
 n_spheres, seg = int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 72

@@ -309,7 +309,25 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
         const uint32_t bstart = bx0 + group * kItemWidthBlocks, bend = min(bstart + kItemWidthBlocks - 1u, bx1);
         const uint32_t py = by * 8u + (lane >> 3);
         const bool alpha_clip = (rec.flags & 1u) != 0u;
-        for (uint32_t bx = bstart; bx <= bend; ++bx) {
+        // Half of the blocks in a large triangle's bounds miss it.  For an item of three or more blocks, lanes 0..7 first
+        // test one block each: an edge function, evaluated as the pixel test evaluates it, is monotone in x and in y
+        // (every rounding is), so its largest value over the block's pixel centres is the one at the corner chosen by
+        // the signs of A and B; negative there = no pixel of the block is inside.  Exactly the blocks the per-pixel test
+        // would find empty or a superset are visited: the result is unchanged.
+        uint32_t blocks = (2u << (bend - bstart)) - 1u;   // bit b: block bstart + b
+        if (bend - bstart >= 2u) {
+            const float xl = (float)((bstart + (lane & 7u)) * 8u) + 0.5f, yl = (float)(by * 8u) + 0.5f;
+            bool maybe = true;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float xc = rec.A[i] > 0.0f ? xl + 7.0f : xl, yc = rec.B[i] > 0.0f ? yl + 7.0f : yl;
+                maybe &= (rec.A[i] * xc + rec.B[i] * yc) + rec.C[i] >= 0.0f;
+            }
+            blocks &= (uint32_t)ballot(maybe);
+        }
+        while (blocks) {
+            const uint32_t bx = bstart + (uint32_t)(__ffs((int)blocks) - 1);
+            blocks &= blocks - 1u;
             const uint32_t px = bx * 8u + (lane & 7u);
             float fv[3], lam[3], depth;
             bool hit = tri_edges(rec, (float)px + 0.5f, (float)py + 0.5f, fv);

@@ -25,15 +25,23 @@ using namespace tr;
 
 namespace tr {
 // The frame recorder's first launch: frustum culling and light assignment are independent of each other, and each is
-// a few microseconds of launch latency on its own.  Blocks [0, cull_blocks) cull, the rest assign lights.
+// a few microseconds of launch latency on its own.  Blocks [0, cull_blocks) cull, the next assign_blocks assign lights,
+// the rest zero the rasteriser's tile coverage maps and list counters (a fill of their own is two more dispatches).
 __global__ __launch_bounds__(256) void frame_front_kernel(const tr_cull_params cp, const tr_primitive_info* __restrict__ primitives,
                                                           const tr_instance* __restrict__ instances,
                                                           uint32_t* __restrict__ instance_counts, uint32_t cull_blocks,
                                                           const tr_assign_params ap, const tr_alight* __restrict__ lights,
                                                           const tr_cluster_aabb* __restrict__ clusters,
-                                                          uint32_t* __restrict__ cluster_counts, uint32_t* __restrict__ light_indices) {
-    if (blockIdx.x < cull_blocks) frustum_culling_body(cp, primitives, instances, instance_counts, blockIdx.x);
-    else assign_lights_body(ap, lights, clusters, cluster_counts, light_indices, blockIdx.x - cull_blocks);
+                                                          uint32_t* __restrict__ cluster_counts, uint32_t* __restrict__ light_indices,
+                                                          uint32_t assign_blocks, uint4* __restrict__ clear, uint32_t clear_vectors) {
+    if (blockIdx.x < cull_blocks) {
+        frustum_culling_body(cp, primitives, instances, instance_counts, blockIdx.x);
+    } else if (blockIdx.x < cull_blocks + assign_blocks) {
+        assign_lights_body(ap, lights, clusters, cluster_counts, light_indices, blockIdx.x - cull_blocks);
+    } else {
+        const uint32_t i = (blockIdx.x - cull_blocks - assign_blocks) * 256u + threadIdx.x;
+        if (i < clear_vectors) clear[i] = uint4{0u, 0u, 0u, 0u};
+    }
 }
 }  // namespace tr
 
@@ -86,6 +94,7 @@ struct tr_context {
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
     const uint32_t* list_hint = nullptr;               // ... with it: the layer's list of full-class tiles
+    bool cover_cleared = false;                        // the frame's first launch has zeroed the coverage maps already
     unsigned long long* vis_hint = nullptr;            // ... and, when the frame skipped the resolve, the layer's visibility
     const tr_tri_record* records_hint = nullptr;       //     words and triangle records: the shading launches read those (VIS)
     const uint32_t* list_count_hint = nullptr;
@@ -1001,6 +1010,41 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
 }  // extern "C"
 
 namespace {
+// The rasteriser's per-frame-size buffers: both layers' visibility words, behind them the two tile coverage maps, the two
+// counters of the full-class tile lists, then the lists.
+tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
+    const size_t npix = (size_t)w * h;
+    if (npix > ctx->vis_pixels) {
+        TR_HIP(ctx, hipDeviceSynchronize());
+        (void)hipFree(ctx->d_vis[0]);
+        ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
+        ctx->vis_pixels = 0;
+        ctx->d_tile_cover[0] = ctx->d_tile_cover[1] = nullptr;
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 4u * (npix / 64u + 65536u + 16384u) * 4u + 64u));
+        ctx->vis_pixels = npix;
+        ctx->vis_clean = false;
+    }
+    if (ctx->vis_w != w || ctx->vis_h != h) {   // another frame size lays the buffers out differently: the previous
+        ctx->vis_clean = false;                  // size's coverage words may lie where this size's visibility words do
+        ctx->vis_w = w;
+        ctx->vis_h = h;
+    }
+    ctx->d_vis[1] = ctx->d_vis[0] + npix;
+    const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
+    ctx->d_tile_cover[0] = (uint32_t*)(ctx->d_vis[0] + 2u * npix);
+    ctx->d_tile_cover[1] = ctx->d_tile_cover[0] + cover_tiles;
+    ctx->d_tile_list_counts = ctx->d_tile_cover[1] + cover_tiles;
+    ctx->d_tile_list[0] = ctx->d_tile_list_counts + 2u;
+    ctx->d_tile_list[1] = ctx->d_tile_list[0] + cover_tiles;
+    return TR_OK;
+}
+// what a frame zeroes before rasterising: the maps and the two counters, rounded up to whole 16-byte vectors (the round-up
+// reaches into the first list, which is rebuilt every frame)
+inline size_t cover_clear_bytes(uint32_t w, uint32_t h) {
+    const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
+    return ((2u * cover_tiles + 2u) * 4u + 15u) & ~(size_t)15u;
+}
+
 // fused_demux: the caller has NOT demultiplexed: the first launch does it (from the context's own instance counts,
 // which it leaves zeroed) together with the draw scans of both layers.
 // resolve: write the TGB-v1 planes.  Without it the layers stay visibility words + triangle records, which the caller
@@ -1021,30 +1065,10 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)w * h;
-    if (npix > ctx->vis_pixels) {
-        TR_HIP(ctx, hipDeviceSynchronize());
-        (void)hipFree(ctx->d_vis[0]);
-        ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
-        ctx->vis_pixels = 0;
-        ctx->d_tile_cover[0] = ctx->d_tile_cover[1] = nullptr;
-        // both layers' visibility buffers and, behind them, their tile coverage maps: cleared by one fill
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 4u * (npix / 64u + 65536u + 16384u) * 4u + 64u));
-        ctx->vis_pixels = npix;
-        ctx->vis_clean = false;
+    {
+        const tr_status vs = ensure_vis_buffers(ctx, w, h);
+        if (vs != TR_OK) return vs;
     }
-    if (ctx->vis_w != w || ctx->vis_h != h) {   // another frame size lays the buffers out differently: the previous
-        ctx->vis_clean = false;                  // size's coverage words may lie where this size's visibility words do
-        ctx->vis_w = w;
-        ctx->vis_h = h;
-    }
-    ctx->d_vis[1] = ctx->d_vis[0] + npix;
-    const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
-    ctx->d_tile_cover[0] = (uint32_t*)(ctx->d_vis[0] + 2u * npix);
-    ctx->d_tile_cover[1] = ctx->d_tile_cover[0] + cover_tiles;
-    // behind the two maps: the two counters of the full-class tile lists (cleared with the maps), then the lists
-    ctx->d_tile_list_counts = ctx->d_tile_cover[1] + cover_tiles;
-    ctx->d_tile_list[0] = ctx->d_tile_list_counts + 2u;
-    ctx->d_tile_list[1] = ctx->d_tile_list[0] + cover_tiles;
     tr_geometry_view gv;
     gv.position = ctx->d_position;
     gv.normal = ctx->d_normal;
@@ -1085,7 +1109,9 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     // frame set (raster_resolve_body).  Per frame only the two tile coverage maps are cleared (260 KB at 4K).
     if (!ctx->vis_clean) TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u, stream));
     ctx->vis_clean = false;   // (until this frame's resolve is enqueued)
-    TR_HIP(ctx, hipMemsetAsync(ctx->d_tile_cover[0], 0, (2u * cover_tiles + 2u) * 4u, stream));
+    if (!(fused_demux && ctx->cover_cleared))   // (the frame recorder's first launch has zeroed them for its own call)
+        TR_HIP(ctx, hipMemsetAsync(ctx->d_tile_cover[0], 0, cover_clear_bytes(w, h), stream));
+    ctx->cover_cleared = false;
     const uint32_t max_cap = std::max(ctx->max_triangles[0], ctx->max_triangles[1]);
     // (the set-up tags every triangle with its material's class for the tile coverage words the shading launches steer by:
     //  needs the digested material table; without a GGX LUT there is none yet and every triangle is tagged with both classes)
@@ -1731,7 +1757,9 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (f->ldr_out && f->hdr_format != TR_FORMAT_RGBA16F) return TR_ERR_INVALID_ARGUMENT;   // the tonemap reads RGBA16F
     const uint32_t w = f->push->framebuffer_size[0], h = f->push->framebuffer_size[1];
     if (f->pyramid.width != w || f->pyramid.height != h) return TR_ERR_INVALID_ARGUMENT;
+    if (w == 0 || h == 0 || w > 65535u || h > 65535u) return TR_ERR_INVALID_ARGUMENT;
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
+    ctx->cover_cleared = false;
     // RGBA16F frames are shaded straight from the rasteriser's visibility words (shade_kernel's VIS launches): no resolve,
     // the work planes of the descriptor stay untouched.  RGBA32F frames go through the planes.
     const bool use_vis = f->hdr_format == TR_FORMAT_RGBA16F;
@@ -1756,11 +1784,16 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ap.num_lights = ctx->num_lights;
         ap.num_clusters = f->num_clusters;
         const uint32_t cull_blocks = (ctx->num_instances + 255u) / 256u, assign_blocks = (f->num_clusters + 3u) / 4u;
-        hipLaunchKernelGGL(frame_front_kernel, dim3(cull_blocks + assign_blocks), dim3(256), 0, s_, cp,
+        st = ensure_vis_buffers(ctx, w, h);
+        if (st != TR_OK) return st;
+        const uint32_t clear_vectors = (uint32_t)(cover_clear_bytes(w, h) / 16u), clear_blocks = (clear_vectors + 255u) / 256u;
+        hipLaunchKernelGGL(frame_front_kernel, dim3(cull_blocks + assign_blocks + clear_blocks), dim3(256), 0, s_, cp,
                            (const tr_primitive_info*)ctx->d_primitives, (const tr_instance*)ctx->d_instances,
                            ctx->d_instance_counts, cull_blocks, ap, (const tr_alight*)ctx->d_alights,
-                           (const tr_cluster_aabb*)f->cluster_aabbs, (uint32_t*)f->cluster_light_counts, (uint32_t*)f->light_indices);
+                           (const tr_cluster_aabb*)f->cluster_aabbs, (uint32_t*)f->cluster_light_counts, (uint32_t*)f->light_indices,
+                           assign_blocks, (uint4*)ctx->d_tile_cover[0], clear_vectors);
         TR_HIP(ctx, hipGetLastError());
+        ctx->cover_cleared = true;
         st = tr_set_cluster_tables(ctx, f->cluster_light_counts, f->light_indices, f->num_clusters);
         if (st != TR_OK) return st;
         st = rasterize_impl(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream, true, !use_vis);
