@@ -74,6 +74,10 @@ struct tr_timer { unsigned long long wait[3]; };
 #ifndef TR_PRIO
 #define TR_PRIO 1
 #endif
+#ifndef TR_PARK_LDS
+#define TR_PARK_LDS 1   // full-class textured pixels: see shade_pixel_textured
+#endif
+constexpr uint32_t kParkedValues = 23u;
 #ifndef TR_UNIFORM_CLUSTERS
 #define TR_UNIFORM_CLUSTERS 1
 #endif
@@ -976,9 +980,20 @@ struct quad_derivs {
 template <bool TRANSMISSIVE>
 __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material, cdmat* dm, float4 pd, float4 ns,
                                                    float2 uv, const quad_derivs& qd, uint32_t lane,
-                                                   const cluster_list& cl, const float* __restrict__ lds_srgb TR_TIMER_PARAM) {
+                                                   const cluster_list& cl_in, const float* __restrict__ lds_srgb,
+                                                   float* lds_park TR_TIMER_PARAM) {
     L = launder(L);
     dm = launder(dm);
+    // TR_PARK_LDS: what the sampling front end does not read — the position, the pixel's cluster list — and what it
+    // produces slot by slot wait in the wave's LDS (one float per lane and value) instead of in registers: the front
+    // end's own state (quad differences, sampling geometry, eight taps, filter temporaries) is the kernel's peak.
+    float* const park = lds_park + lane;
+    auto put = [&](uint32_t f, float v) { if (TR_PARK_LDS) park[f * 64u] = v; };
+    auto get = [&](uint32_t f, float v) { return TR_PARK_LDS ? park[f * 64u] : v; };
+    put(0, pd.x); put(1, pd.y); put(2, pd.z); put(3, pd.w);
+    put(4, __uint_as_float(cl_in.cluster)); put(5, __uint_as_float(cl_in.num_lights)); put(6, __uint_as_float(cl_in.list_offset));
+    put(7, __uint_as_float(cl_in.l0)); put(8, __uint_as_float(cl_in.l1));
+    asm volatile("" ::: "memory");
     const TR_CONSTANT tr_material_info* mi = as_constant(L->materials) + material;
     cdtex* tex = as_constant(L->textures);
     const uint32_t* __restrict__ arena = L->tex_arena;
@@ -1031,6 +1046,8 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(dr), "+v"(dg), "+v"(db));
         slot_done();
     }
+    put(9, dr); put(10, dg); put(11, db);
+    slot_done();
     // get_material_params (lighting.rs:261-301)
     float metallic = mi->metallic_factor, rough = mi->roughness_factor;
     if (id_mr != -1) {
@@ -1038,18 +1055,24 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(metallic), "+v"(rough));
         slot_done();
     }
+    put(12, metallic); put(13, rough);
+    slot_done();
     float scx = mi->specular_colour_factor[0], scy = mi->specular_colour_factor[1], scz = mi->specular_colour_factor[2];
     if (id_spec_colour != -1) {
         with_slot(std::integral_constant<int, 7>{}, [&](auto S) { scx *= S(c0{}); scy *= S(c1{}); scz *= S(c2{}); });
         asm volatile("" : "+v"(scx), "+v"(scy), "+v"(scz));
         slot_done();
     }
+    put(14, scx); put(15, scy); put(16, scz);
+    slot_done();
     float specular_factor = mi->specular_factor;
     if (id_specular != -1) {
         with_slot(std::integral_constant<int, 6>{}, [&](auto S) { specular_factor *= S(c3{}); });
         asm volatile("" : "+v"(specular_factor));
         slot_done();
     }
+    put(17, specular_factor);
+    slot_done();
     // get_emission (lighting.rs:303-313)
     lm.emission[0] = mi->emissive_factor[0];
     lm.emission[1] = mi->emissive_factor[1];
@@ -1059,23 +1082,28 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(lm.emission[0]), "+v"(lm.emission[1]), "+v"(lm.emission[2]));
         slot_done();
     }
+    put(18, lm.emission[0]); put(19, lm.emission[1]); put(20, lm.emission[2]);
+    slot_done();
     lm.transmission_factor = mi->transmission_factor;               // lib.rs:71-77
     if (id_transmission != -1) {
         with_slot(std::integral_constant<int, 4>{}, [&](auto S) { lm.transmission_factor *= S(c0{}); });
         asm volatile("" : "+v"(lm.transmission_factor));
         slot_done();
     }
+    put(21, lm.transmission_factor);
+    slot_done();
     lm.thickness = mi->thickness_factor;                            // lib.rs:120-124
     if (id_thickness != -1) {
         with_slot(std::integral_constant<int, 5>{}, [&](auto S) { lm.thickness *= S(c1{}); });
         asm volatile("" : "+v"(lm.thickness));
         slot_done();
     }
+    put(22, lm.thickness);
+    slot_done();
     lm.eta = dm->eta;
     lm.neg_atten_log2[0] = dm->neg_atten_log2[0];
     lm.neg_atten_log2[1] = dm->neg_atten_log2[1];
     lm.neg_atten_log2[2] = dm->neg_atten_log2[2];
-    lm.flags = (dm->flags & 1u) | (lm.transmission_factor != 0.0f ? 2u : 0u);
 
     // calculate_normal + compute_cotangent_frame (lighting.rs:222-259)
     if (id_normal != -1) {
@@ -1105,11 +1133,27 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     }
     // The per-lane record is digested only now, when every slot has been sampled and the sampling geometry, the quad
     // differences and the taps are dead: the digest's twenty values and the sampling state are never live together.
+    slot_done();
+    dr = get(9, dr); dg = get(10, dg); db = get(11, db);
+    metallic = get(12, metallic); rough = get(13, rough);
+    scx = get(14, scx); scy = get(15, scy); scz = get(16, scz);
+    specular_factor = get(17, specular_factor);
+    lm.emission[0] = get(18, lm.emission[0]); lm.emission[1] = get(19, lm.emission[1]); lm.emission[2] = get(20, lm.emission[2]);
+    lm.transmission_factor = get(21, lm.transmission_factor);
+    lm.thickness = get(22, lm.thickness);
+    lm.flags = (dm->flags & 1u) | (lm.transmission_factor != 0.0f ? 2u : 0u);
     digest_factors<false>(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
                           L->fp.lut_height, L->fp.lut_stride);
     lm.metallic = metallic;
     lm.rough = rough;
-    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd, ns, lane, cl TR_TIMER_ARG);
+    const float4 pd2 = float4{get(0, pd.x), get(1, pd.y), get(2, pd.z), get(3, pd.w)};
+    cluster_list cl = cl_in;   // (the scalar members stay what they are)
+    cl.cluster = __float_as_uint(get(4, __uint_as_float(cl_in.cluster)));
+    cl.num_lights = __float_as_uint(get(5, __uint_as_float(cl_in.num_lights)));
+    cl.list_offset = __float_as_uint(get(6, __uint_as_float(cl_in.list_offset)));
+    cl.l0 = __float_as_uint(get(7, __uint_as_float(cl_in.l0)));
+    cl.l1 = __float_as_uint(get(8, __uint_as_float(cl_in.l1)));
+    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd2, ns, lane, cl TR_TIMER_ARG);
 }
 
 // ------------------------------------------------------------------------ one pixel of a "lite" textured material
@@ -1201,6 +1245,7 @@ struct tile_regs {
 // a full-class material is uploaded, one of TEX = 2: the common materials do not pay for the registers of the eight-slot
 // sampling front end (120 VGPRs = 4 waves per SIMD; TEX = 1 holds 7-8).
 constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2;
+
 // VIS (the frame recorder's launches): a pixel's inputs are interpolated here from the rasteriser's visibility word and
 // triangle record (vis_interpolate, the resolve's own arithmetic) instead of being read from TGB-v1 planes, which the
 // frame then never writes: 60 B per covered pixel less traffic (8 B word read + zeroed instead of 8 + 8 + 44 written by
@@ -1213,6 +1258,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
     __shared__ float lds_srgb[TEXTURED ? 256 : 1];
+    __shared__ float lds_park[(TEX == kTexFull && TR_PARK_LDS) ? (TR_WAVE_BLOCKS ? 1u : 4u) * kParkedValues * 64u : 64u];
     if constexpr (TEXTURED) {
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) lds_srgb[i] = L->srgb_to_linear[i];
         __syncthreads();
@@ -1469,7 +1515,8 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
                 }
                 if (key == mk) {
                     if constexpr (TEX == kTexFull) {
-                        out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb TR_TIMER_ARG);
+                        out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb,
+                                                                 lds_park + (threadIdx.x >> 6) * kParkedValues * 64u TR_TIMER_ARG);
                     } else if constexpr (TEX == kTexLite) {
                         if (dmats[m0].flags & 8u)
                             out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane, cl, lds_srgb TR_TIMER_ARG);

@@ -536,8 +536,8 @@ tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bo
             L.tile_list = ctx->d_class_list + 1;
             L.tile_list_count = ctx->d_class_list;
         }
-        // as many waves as the chip holds of this kernel (4 per SIMD), each striding over the list
-        const dim3 grid2(wave_blocks ? ctx->num_cus * 16u : ctx->num_cus * 4u);
+        // as many waves as the chip holds of this kernel (4-5 per SIMD), each striding over the list
+        const dim3 grid2(wave_blocks ? ctx->num_cus * 20u : ctx->num_cus * 5u);
         launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid2, block, stream);
         return TR_OK;
     }
