@@ -610,7 +610,9 @@ typedef struct tr_frame_desc {
     uint32_t _reserved;
     void* cluster_light_counts;                    /* out: num_clusters u32; bound as the passes' tables */
     void* light_indices;                           /* out: num_clusters * 128 u32 */
-    tr_gbuffer_target opaque_layer;                /* work: whole-frame TGB-v1 planes */
+    tr_gbuffer_target opaque_layer;                /* work: whole-frame TGB-v1 planes.  Scratch: an RGBA16F frame is shaded
+                                                      straight from the rasteriser's visibility words and leaves them
+                                                      untouched; an RGBA32F frame resolves into them */
     tr_gbuffer_target transmissive_layer;
     tr_pyramid pyramid;                            /* work: opaque_sampled_hdr_framebuffer */
     void* hdr;                                     /* out: the HDR colour target, whole frame */
