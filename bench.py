@@ -444,7 +444,7 @@ def run_rank(args) -> int:
                                      f"{composite}: {comp.backend}")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "tr::shade_kernel<true, uint2, false>", "avg_kernel_ms": round(kernel_ms, 4),
+                         "kernel": "tr::shade_kernel<true, uint2, 0, false>", "avg_kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL,
                          "read_only_frac": round(pixels_rank * READ_BYTES_PER_PIXEL / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                          "bytes_needed_per_pixel": NEEDED_BYTES_PER_PIXEL,

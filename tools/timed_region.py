@@ -9,7 +9,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 b = json.load(open(sys.argv[2]))
 r = lambda x: round(x, 2)
-out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py (tools/prof_round.sh), kernel tr::shade_kernel<true, uint2, false>; durations in us",
+out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py (tools/prof_round.sh), kernel tr::shade_kernel<true, uint2, 0, false>; durations in us",
        "launches_total": len(d), "launches_logged": sum(c for _, c in b["launch_log"]),
        "all_launches": {"avg": r(st.mean(d)), "min": r(min(d)), "max": r(max(d))}, "phases": {}}
 pos = 0
