@@ -180,6 +180,53 @@ def cpu_baseline(scene, lut, width, height, budget_s=12.0):
                       f"frame ({rows_total * width / 1e6:.1f} Mpx) in {dt:.1f} s, {cores} threads"}
 
 
+def frame_pipeline_time(width, height):
+    """us per frame of tr_record_frame on the procedural `meshes` scene (own context; see run_rank)."""
+    import numpy as np
+    import torch
+    from transmission_renderer_amd import meshes, synthetic, wire
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    r = TransmissionRenderer(0)
+    try:
+        scene = synthetic.make_scene(width, height, num_point_lights=2, with_gbuffer=False, textured=True)
+        geometry = meshes.make_mesh_scene(extra_instances=True)
+        scene["materials"][2].alpha_clipping_cutoff = 0.75
+        scene["materials"][7].alpha_clipping_cutoff = 0.6
+        r.upload_ggx_lut()
+        r.upload_materials(scene["materials"])
+        r.upload_textures(scene["textures"])
+        r.upload_lights(scene["lights"])
+        r.upload_geometry(geometry)
+        _, view = wire.default_camera()
+        aabbs = r.write_cluster_data(scene["uniforms"], wire.inverse_perspective(width, height), (width, height))
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(width, height), view)
+        work = r.new_frame_buffers(width, height)
+        q = wire.view_rotation_inverse(view)
+        frame = lambda: r.record_frame(scene["uniforms"], scene["push"], culling, view, q, aabbs, work)   # noqa: E731
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.2:
+            for _ in range(4):
+                frame()
+            torch.cuda.synchronize()
+        ts = []
+        for _ in range(8):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                frame()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b) / 20)
+        t = float(np.median(ts))
+        return {"us_per_frame": round(t * 1e3, 1), "frames_per_s": round(1e3 / t, 1),
+                "scene": f"procedural `meshes` scene, {len(geometry['index']) // 3} triangles, textured + alpha-clipped + transmissive "
+                         f"materials, sun + 2 punctual lights, {width}x{height}, RGBA16F + tonemapped RGBA8 out",
+                "stages": "culling | light assignment -> demultiplex -> visibility-buffer rasteriser (2 layers) -> opaque -> "
+                          "mip chain -> transmissive -> tonemap; one tr_record_frame call per frame, 160 frames back to back"}
+    finally:
+        r.close()
+
+
 def selftest_cpu(args, world, rank):
     """Launcher + band arithmetic + composite order without a GPU (gloo, host tensors)."""
     import torch
@@ -421,6 +468,16 @@ def run_rank(args) -> int:
             "note": "every synthetic material with transmission_factor = 1 (in the headline scene 4 of 16 have 0 and skip "
                     "the refraction taps, LUT and btdf lobes)"}
 
+    # The whole frame of the path this pass belongs to, for the record (reported, not the metric): culling -> light
+    # assignment -> demultiplex -> rasteriser -> opaque -> mip chain -> transmissive -> tonemap through ONE native call per
+    # frame (tr_record_frame) on a procedural textured scene at the same frame size, back to back.
+    frame_pipeline = None
+    if not distributed and not args.no_variants and not args.all_transmissive and args.roughness_override is None:
+        try:
+            frame_pipeline = frame_pipeline_time(fw, fh)
+        except Exception as e:   # (never costs the metric its line)
+            frame_pipeline = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         kernel_s = kernel_ms * 1e-3
         achieved = pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL / kernel_s / 1e9
@@ -483,6 +540,8 @@ def run_rank(args) -> int:
                                           "with_composite": round(single_gpu_ms / ms_per_step, 3)}
         if variants:
             out["variants"] = variants
+        if frame_pipeline:
+            out["frame_pipeline"] = frame_pipeline
         if world == 1 and not args.no_cpu_baseline:
             if variants:   # the CPU baseline shades the headline scene
                 scene = synthetic.make_scene(fw, fh, num_point_lights=args.lights, with_gbuffer=False,
