@@ -1906,4 +1906,54 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const uint2* __restrict__ 
     }
 }
 
+// The frame recorder's tonemap: it knows, from the rasteriser's tile coverage words of both layers, which 64x4 block tiles
+// no fragment landed in — they hold the passes' clear colour, texel for texel — and a scene's background is often half
+// the frame.  One workgroup covers two adjacent tiles (128x4 pixels, two pixels per thread); when one of them is
+// untouched the workgroup's first wave evaluates the operator ONCE on the clear colour's texel (the same function on the
+// same bits: the same output as evaluating every pixel) and the untouched tiles' threads only store it.
+struct tr_tonemap_tiles {
+    const uint32_t* cover[2];   // per layer: [tiles_y][tiles_x] words, 0 = no fragment in the tile
+    uint32_t width, height, tiles_x;
+};
+__global__ __launch_bounds__(256) void tonemap_tiles_kernel(const uint2* __restrict__ hdr, uint32_t* __restrict__ out,
+                                                            const tr_tonemap_params p, int bgra, const tr_tonemap_tiles tt) {
+    __shared__ uint32_t clear_out;
+    const uint32_t row = threadIdx.x >> 6, col2 = threadIdx.x & 63u;
+    const uint32_t tile_y = blockIdx.y, tile_x0 = blockIdx.x * 2u;
+    // (scalar) the coverage of the workgroup's two tiles
+    bool sky[2];
+#pragma unroll
+    for (uint32_t k = 0; k < 2u; ++k) {
+        const uint32_t tx = min(tile_x0 + k, tt.tiles_x - 1u);
+        const uint32_t t = tile_y * tt.tiles_x + tx;
+        sky[k] = as_constant(tt.cover[0])[t] == 0u && as_constant(tt.cover[1])[t] == 0u;
+    }
+    const float e1 = p.saturation / p.cross_saturation;
+    if (sky[0] || sky[1]) {   // (uniform)
+        if (threadIdx.x < 64u) {
+            const uint32_t v = tonemap_pixel(0x00000000u, 0x3C000000u, p, e1, bgra);   // RGBA16F (0, 0, 0, 1)
+            if (threadIdx.x == 0u) clear_out = v;
+        }
+        __syncthreads();
+    }
+    const uint32_t px = tile_x0 * 64u + col2 * 2u, py = tile_y * 4u + row;
+    if (px >= tt.width || py >= tt.height) return;
+    const uint32_t i = py * tt.width + px;
+    const bool mine_sky = col2 < 32u ? sky[0] : sky[1];
+    if (px + 1u < tt.width && ((i & 1u) == 0u)) {   // (two pixels, 16-byte aligned: even widths)
+        if (mine_sky) {
+            const uint32_t c = clear_out;
+            *reinterpret_cast<uint2*>(out + i) = uint2{c, c};
+        } else {
+            const uint4 q = *reinterpret_cast<const uint4*>(hdr + i);
+            *reinterpret_cast<uint2*>(out + i) = uint2{tonemap_pixel(q.x, q.y, p, e1, bgra), tonemap_pixel(q.z, q.w, p, e1, bgra)};
+        }
+    } else {
+        for (uint32_t k = 0; k < 2u && px + k < tt.width; ++k) {
+            const uint2 q = hdr[i + k];
+            out[i + k] = mine_sky ? clear_out : tonemap_pixel(q.x, q.y, p, e1, bgra);
+        }
+    }
+}
+
 }  // namespace tr

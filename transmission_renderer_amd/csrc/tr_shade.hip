@@ -1873,7 +1873,18 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (use_vis) ctx->vis_clean = true;   // (both passes enqueued: every visibility word the frame set is zeroed again)
     if (f->ldr_out) {
         zone_scope z(rec, "tonemapping");
-        st = tr_tonemap(ctx, f->hdr, w, h, f->tonemap, f->ldr_out, f->bgra, stream);
+        if (((uintptr_t)f->hdr & 15u) || ((uintptr_t)f->ldr_out & 7u)) return TR_ERR_INVALID_ARGUMENT;
+        // (the tiles no fragment of either layer landed in hold the clear colour: tonemapped once per workgroup)
+        tr_tonemap_tiles tt;
+        tt.cover[0] = ctx->d_tile_cover[0];
+        tt.cover[1] = ctx->d_tile_cover[1];
+        tt.width = w;
+        tt.height = h;
+        tt.tiles_x = (w + 63u) / 64u;
+        hipLaunchKernelGGL(tonemap_tiles_kernel, dim3((tt.tiles_x + 1u) / 2u, (h + 3u) / 4u), dim3(256), 0, (hipStream_t)stream,
+                           (const uint2*)f->hdr, (uint32_t*)f->ldr_out, *f->tonemap, (int)f->bgra, tt);
+        TR_HIP(ctx, hipGetLastError());
+        st = TR_OK;
     }
     return st;
 }
