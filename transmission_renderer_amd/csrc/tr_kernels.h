@@ -74,6 +74,10 @@ struct tr_timer { unsigned long long wait[3]; };
 #ifndef TR_PRIO
 #define TR_PRIO 1
 #endif
+#ifndef TR_VIS_STRIPES
+#define TR_VIS_STRIPES 1
+#endif
+constexpr uint32_t kStripeTileRows = 4u;
 #ifndef TR_PARK_LDS
 #define TR_PARK_LDS 1   // full-class textured pixels: see shade_pixel_textured
 #endif
@@ -164,6 +168,8 @@ struct tr_frame_params {
     uint32_t rect_x0, rect_y0, rect_x1, rect_y1;
     uint32_t tiles_x, tiles_y;   // 64x4 tiles covering the rect
     uint32_t tiles_x_magic;      // floor(2^32 / tiles_x): tile / tiles_x on the scalar unit (one fix-up step)
+    uint32_t stripe_tiles;       // VIS launches: block tiles per stripe of kStripeTileRows tile rows, and
+    uint32_t stripe_magic;       // floor(2^32 / stripe_tiles)
     uint32_t lut_width, lut_stride;  // pair-table stride in entries (= lut_width + 2)
     uint32_t lut_height;
     uint32_t pyr_levels;
@@ -1278,8 +1284,20 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     // each (75 us at 4K for the demo frame's one small full-class object at 4 waves per SIMD).
     const bool listed = TEX == kTexFull && L->tile_list != nullptr;
     const uint32_t listed_tiles = listed ? as_constant(L->tile_list_count)[0] : 0u;
+    // VIS launches (real frames, where whole screen regions are empty or cheap): the XCDs are dealt STRIPES of
+    // kStripeTileRows tile rows in turn instead of one contiguous band each, so that every XCD gets its share of the
+    // covered part of the screen (a frame whose upper half is sky left half of the XCDs idle).
+    const bool striped = VIS && TR_VIS_STRIPES && !listed;
+    uint32_t stripes_own = 0u, striped_len = 0u;
+    if (striped) {
+        const uint32_t st = L->fp.stripe_tiles;
+        const uint32_t nstripes = (ntiles + st - 1u) / st;
+        stripes_own = xcd < nstripes ? (nstripes - 1u - xcd) / 8u + 1u : 0u;
+        const bool owns_last = stripes_own != 0u && ((nstripes - 1u) & 7u) == xcd;
+        striped_len = stripes_own * st - (owns_last ? nstripes * st - ntiles : 0u);
+    }
     const uint32_t band_start = listed ? 0u : xcd * per + min(xcd, rem);
-    const uint32_t band_len = listed ? listed_tiles : per + (xcd < rem ? 1u : 0u);
+    const uint32_t band_len = listed ? listed_tiles : striped ? striped_len : per + (xcd < rem ? 1u : 0u);
 
     // Out-of-rect lanes read a clamped (valid) pixel and are masked later.  There is no software prefetch of the
     // next tile: its 13 registers cost two of the eight resident waves per SIMD, and even scheduled so that nothing
@@ -1287,7 +1305,16 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
     auto fetch = [&](uint32_t j, tile_regs& t) {
         claunch* F = launder(L);
-        const uint32_t tile = listed ? as_constant(F->tile_list)[j >> 2] : band_start + (j >> 2);
+        uint32_t tile = listed ? as_constant(F->tile_list)[j >> 2] : band_start + (j >> 2);
+        if (striped) {   // local tile q of this XCD: stripe q / stripe_tiles of its own, i.e. stripe (that * 8 + xcd) of the frame
+            const uint32_t q = j >> 2, st = F->fp.stripe_tiles;
+            uint32_t own = __umulhi(q, F->fp.stripe_magic), off = q - own * st;
+            if (off >= st) {
+                off -= st;
+                ++own;
+            }
+            tile = (own * 8u + xcd) * st + off;
+        }
         // tile / tiles_x without the vector unit: q = mulhi(tile, floor(2^32 / d)) is the quotient or one less
         uint32_t tyi = __umulhi(tile, F->fp.tiles_x_magic);
         uint32_t txi = tile - tyi * F->fp.tiles_x;

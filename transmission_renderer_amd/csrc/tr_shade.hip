@@ -386,6 +386,8 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     fp->tiles_x = (rect.x1 - rect.x0 + kBlockTileW - 1u) / kBlockTileW;
     fp->tiles_y = (rect.y1 - rect.y0 + kBlockTileH - 1u) / kBlockTileH;
     fp->tiles_x_magic = (uint32_t)(0x100000000ull / fp->tiles_x > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->tiles_x);
+    fp->stripe_tiles = fp->tiles_x * kStripeTileRows;
+    fp->stripe_magic = (uint32_t)(0x100000000ull / fp->stripe_tiles > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->stripe_tiles);
 #if TR_ABLATION
     if (const char* e = std::getenv("TR_ABLATE")) fp->ablate = (uint32_t)std::atoi(e);  // profiling builds only
 #endif
