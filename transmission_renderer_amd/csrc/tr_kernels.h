@@ -77,7 +77,10 @@ struct tr_timer { unsigned long long wait[3]; };
 #ifndef TR_VIS_STRIPES
 #define TR_VIS_STRIPES 1
 #endif
-constexpr uint32_t kStripeTileRows = 4u;
+#ifndef TR_STRIPE_ROWS
+#define TR_STRIPE_ROWS 4
+#endif
+constexpr uint32_t kStripeTileRows = TR_STRIPE_ROWS;
 #ifndef TR_PARK_LDS
 #define TR_PARK_LDS 1   // full-class textured pixels: see shade_pixel_textured
 #endif
