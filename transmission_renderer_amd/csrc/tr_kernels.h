@@ -224,6 +224,11 @@ struct tr_launch {
     // VIS launches (the frame recorder): the layer's visibility words and triangle records instead of the planes
     unsigned long long* vis;
     const tr_tri_record* records;
+    // opaque VIS launches: the transmissive layer's words and coverage map.  The rasteriser keeps the pixel's NEAREST
+    // transmissive fragment whatever lies in front of it (raster_kernel); the opaque launch, the last to know the opaque
+    // depth, zeroes that word where the fragment is not nearer than the opaque surface.
+    unsigned long long* vis_front;
+    const uint32_t* cover_front;
     uint32_t* tile_counters;            // per XCD kSubCounters tile counters + one count of finished waves, 256 bytes apart
 };
 typedef const TR_CONSTANT tr_launch claunch;
@@ -1239,6 +1244,7 @@ struct tile_regs {
     float2 uv;                                        // TEXTURED only
     uint32_t mat, cluster_x, cluster_y_term, px, py;  // (the two table values are only added when used)
     uint32_t cover;                                   // (scalar) the block tile's coverage word
+    uint32_t cover_front;                             // (scalar) VIS opaque: the transmissive layer's word of the tile
 };
 
 // Experiments only: an occupancy target for the register allocator, e.g. -DTR_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(TEXTURED ? 5 : 8)))'
@@ -1333,6 +1339,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         // launch skips the tiles that hold nothing of the classes it shades without touching their planes
         const uint32_t cover = (!TR_TILE_8X8 && F->tile_cover) ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
         t.cover = cover;
+        if constexpr (VIS && !TRANSMISSIVE) t.cover_front = F->cover_front ? as_constant(F->cover_front)[tile] : 0u;
         if constexpr (TEX == kTexLite) {
             // the tile may hold full-class fragments: listed for the TEX = 2 launch behind this one (once: by the wave of
             // the tile's first quarter)
@@ -1583,6 +1590,19 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
             bool last = active;
             if constexpr (TEX == kTexLite) last = active && (cur.cover & 2u) == 0u;   // (bit 1: the TEX = 2 launch visits the tile)
             if (last) st<unsigned long long>(launder(L)->vis, mad24(out_py, launder(L)->fp.width, out_px) * 8u, 0ull);
+            if constexpr (!TRANSMISSIVE) {
+                // (scalar) a transmissive fragment landed in this tile: a pixel this launch shades knows its opaque depth —
+                // the transmissive winner stays only if it is nearer (depth GREATER, reversed Z)
+                bool owner = active;
+                if constexpr (TEXTURED) owner = ((shaded >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+                if (cur.cover_front != 0u && owner) {
+                    claunch* V = launder(L);
+                    const uint32_t at = mad24(out_py, V->fp.width, out_px) * 8u;
+                    const unsigned long long front = ld<unsigned long long>(V->vis_front, at);
+                    if (front != 0ull && !(__uint_as_float((uint32_t)(front >> 32)) > cur.pd.w))
+                        st<unsigned long long>(V->vis_front, at, 0ull);
+                }
+            }
         }
         if (write && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores
             claunch* W = launder(L);

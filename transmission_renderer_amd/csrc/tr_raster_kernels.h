@@ -272,15 +272,30 @@ struct tr_alpha_tables {        // what the alpha-clip kill reads (depth_pre_pas
     uint32_t num_textures;
 };
 
-__global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, const tr_raster_frame f,
-                                                     const tr_tri_record* __restrict__ records,
-                                                     const uint32_t* __restrict__ item_base,
-                                                     const tr_layer_counts* __restrict__ counts,
-                                                     const tr_alpha_tables alpha,
-                                                     const unsigned long long* __restrict__ behind /* layer 0's buffer or null */,
-                                                     unsigned long long* __restrict__ vis,
-                                                     uint32_t* __restrict__ tile_cover /* [ceil(h/4)][ceil(w/64)], zeroed */) {
+// Both layers in one launch (blockIdx.y = layer): the transmissive layer's fragments are NOT tested against the opaque
+// depth here — its winner is the nearest transmissive fragment of the pixel, and whether that one lies in front of the
+// opaque surface is decided by whoever consumes the opaque word last (the resolve, or the opaque VIS launch: it zeroes a
+// hidden transmissive word).  The result is the same — if the nearest transmissive fragment is hidden, all are; if not,
+// it is also the nearest of the visible ones — and the small layer's launch (19 us of mostly latency on the demo frame)
+// runs beside the large one's instead of behind it.
+struct tr_raster_layers {
+    const tr_tri_record* records[2];
+    const uint32_t* item_base[2];
+    const tr_layer_counts* counts[2];
+    unsigned long long* vis[2];
+    uint32_t* tile_cover[2];     // [ceil(h/4)][ceil(w/64)], zeroed
+    uint32_t enabled[2];         // (a layer that cannot have triangles has no buffers)
+};
+__global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_raster_layers rl,
+                                                     const tr_alpha_tables alpha) {
 #pragma clang fp contract(off)
+    const uint32_t layer = blockIdx.y;
+    if (!rl.enabled[layer]) return;
+    const tr_tri_record* __restrict__ records = rl.records[layer];
+    const uint32_t* __restrict__ item_base = rl.item_base[layer];
+    const tr_layer_counts* __restrict__ counts = rl.counts[layer];
+    unsigned long long* __restrict__ vis = rl.vis[layer];
+    uint32_t* __restrict__ tile_cover = rl.tile_cover[layer];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves = gridDim.x * 4u;
     const uint32_t n_items = counts->num_items, n_tris = counts->num_triangles;
@@ -335,7 +350,6 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             if (ballot(hit) == 0ull) continue;   // the block misses the triangle (half of a large triangle's box does)
             hit = tri_depth(rec, fv, lam, depth) && hit;
             const size_t pix = (size_t)py * f.width + px;
-            if (hit && behind) hit = depth > __uint_as_float((uint32_t)(behind[pix] >> 32));   // nearer than the opaque surface
             if (hit && alpha_clip) {
                 // implicit-LOD fetch of the diffuse texture: uv at the two quad partners from the same triangle
                 // (what helper invocations compute), differences oriented like dFdx / dFdy
@@ -387,37 +401,6 @@ struct tr_layer_planes {
     uint32_t* material_id;
 };
 
-// One thread per pixel: the winning triangle's attributes at the pixel centre (vis_interpolate), or "no fragment".
-__device__ __forceinline__ void raster_resolve_body(const tr_raster_frame f, const tr_tri_record* __restrict__ records,
-                                                    unsigned long long* __restrict__ vis, const tr_layer_planes out,
-                                                    const uint32_t* __restrict__ tile_cover, bool ids_of_untouched_tiles) {
-    const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (px >= f.width || py >= f.height) return;
-    const size_t pix = (size_t)py * f.width + px;
-    // one word per 64x4 block tile (this workgroup), set by raster_kernel when a fragment landed in it: an untouched tile
-    // has no fragment, its visibility words need not be read
-    const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
-    if (as_constant(tile_cover)[tile] == 0u) {
-        if (ids_of_untouched_tiles) out.material_id[pix] = TR_NOT_COVERED;
-        return;
-    }
-    const unsigned long long key = vis[pix];
-    if (key == 0ull) {   // no fragment: only the id plane is defined there (the shading passes look at nothing else)
-        out.material_id[pix] = TR_NOT_COVERED;
-        return;
-    }
-    // The resolve is the last reader of a visibility word: it leaves the buffer zeroed for the next frame, so a frame
-    // clears only the words it set instead of filling both whole-frame buffers (133 MB at 4K, 21 us) up front.
-    vis[pix] = 0ull;
-    vis_fragment v;
-    vis_interpolate(records[(uint32_t)key], key, px, py, v);
-    out.pos_depth[pix] = float4{v.position[0], v.position[1], v.position[2], v.depth};
-    out.nrm_scale[pix] = float4{v.normal[0], v.normal[1], v.normal[2], v.scale};
-    out.uv[pix] = float2{v.uv[0], v.uv[1]};
-    out.material_id[pix] = v.material_id;
-}
-
-
 // ---- both layers per launch ----------------------------------------------------------------------------------------
 // The front end of a layer (scan of the draw stream, vertex stage + setup, the three scan passes over the work items)
 // is five small launches, each bound by launch latency at scene sizes like the demos'; the two layers are
@@ -441,6 +424,48 @@ struct tr_two_layers {
     tr_layer_work l[2];
 };
 #define TR_PICK_LAYER(two, which) const tr_layer_work W = (which) ? (two).l[1] : (two).l[0]
+
+// One thread per pixel and BOTH layers: the winning triangles' attributes at the pixel centre (vis_interpolate), or "no
+// fragment".  The transmissive layer's winner counts only if it is nearer than the opaque surface (see raster_kernel).
+__device__ __forceinline__ void raster_resolve_layer(const tr_raster_frame f, const tr_tri_record* __restrict__ records,
+                                                     unsigned long long key, const tr_layer_planes out, size_t pix, uint32_t px, uint32_t py) {
+    if (key == 0ull) {   // no fragment: only the id plane is defined there (the shading passes look at nothing else)
+        out.material_id[pix] = TR_NOT_COVERED;
+        return;
+    }
+    vis_fragment v;
+    vis_interpolate(records[(uint32_t)key], key, px, py, v);
+    out.pos_depth[pix] = float4{v.position[0], v.position[1], v.position[2], v.depth};
+    out.nrm_scale[pix] = float4{v.normal[0], v.normal[1], v.normal[2], v.scale};
+    out.uv[pix] = float2{v.uv[0], v.uv[1]};
+    out.material_id[pix] = v.material_id;
+}
+__device__ __forceinline__ void raster_resolve_body(const tr_raster_frame f, const tr_two_layers& two, bool ids_of_untouched_tiles) {
+    const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u), py = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (px >= f.width || py >= f.height) return;
+    const size_t pix = (size_t)py * f.width + px;
+    // one word per 64x4 block tile (this workgroup) and layer, set by raster_kernel when a fragment landed in it: an
+    // untouched tile has no fragment, its visibility words need not be read
+    const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned long long key[2];
+#pragma unroll
+    for (uint32_t l = 0; l < 2u; ++l) {
+        const bool touched = two.l[l].tile_cover && as_constant(two.l[l].tile_cover)[tile] != 0u;
+        key[l] = touched ? two.l[l].vis[pix] : 0ull;
+        // The resolve is the last reader of a visibility word: it leaves the buffer zeroed for the next frame, so a frame
+        // clears only the words it set instead of filling both whole-frame buffers (133 MB at 4K, 21 us) up front.
+        if (key[l] != 0ull) two.l[l].vis[pix] = 0ull;
+    }
+    if (key[1] != 0ull && !(__uint_as_float((uint32_t)(key[1] >> 32)) > __uint_as_float((uint32_t)(key[0] >> 32)))) key[1] = 0ull;
+#pragma unroll
+    for (uint32_t l = 0; l < 2u; ++l) {
+        const bool touched = two.l[l].tile_cover && as_constant(two.l[l].tile_cover)[tile] != 0u;
+        if (!touched && !ids_of_untouched_tiles) continue;
+        raster_resolve_layer(f, two.l[l].records, key[l], two.l[l].planes, pix, px, py);
+    }
+}
+
+
 
 // The frame recorder's fused launches (tr_record_frame / tr_draw_scene): every step of the front end is a tiny,
 // launch-latency-bound kernel (~4.5 us each back to back), so steps that run in ONE workgroup anyway share a launch.
@@ -512,10 +537,9 @@ __global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const tr_
     if (W.capacity_triangles == 0u) return;
     raster_scan_items_apply_body(W.item_counts, W.chunk_sums, W.counts, W.item_base);
 }
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_raster_frame f, const tr_two_layers two, uint32_t first_layer,
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_raster_frame f, const tr_two_layers two,
                                                              uint32_t ids_of_untouched_tiles) {
-    TR_PICK_LAYER(two, blockIdx.z + first_layer);
-    raster_resolve_body(f, W.records, W.vis, W.planes, W.tile_cover, ids_of_untouched_tiles != 0u);
+    raster_resolve_body(f, two, ids_of_untouched_tiles != 0u);
 }
 
 }  // namespace tr

@@ -97,6 +97,8 @@ struct tr_context {
     bool cover_cleared = false;                        // the frame's first launch has zeroed the coverage maps already
     unsigned long long* vis_hint = nullptr;            // ... and, when the frame skipped the resolve, the layer's visibility
     const tr_tri_record* records_hint = nullptr;       //     words and triangle records: the shading launches read those (VIS)
+    unsigned long long* vis_front_hint = nullptr;      // opaque VIS launches: the transmissive layer's words and coverage map
+    const uint32_t* cover_front_hint = nullptr;        //   (a transmissive winner behind the opaque surface is zeroed there)
     const uint32_t* list_count_hint = nullptr;
     uint32_t* d_tile_list_counts = nullptr;            // (inside the d_vis allocation, cleared with the coverage maps)
     uint32_t* d_tile_list[2] = {nullptr, nullptr};     // per layer: the tiles
@@ -470,6 +472,8 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.list_build = L.list_build_count = nullptr;
     L.vis = L.tile_cover ? ctx->vis_hint : nullptr;
     L.records = L.vis ? ctx->records_hint : nullptr;
+    L.vis_front = L.vis ? ctx->vis_front_hint : nullptr;
+    L.cover_front = L.vis ? ctx->cover_front_hint : nullptr;
     L.slice_thr = ctx->d_slice_thr;
     L.cluster_x = ctx->d_cluster_x;
     L.cluster_y_term = ctx->d_cluster_y_term;
@@ -1140,17 +1144,20 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
             hipLaunchKernelGGL(raster_scan_items_chunks_kernel, dim3(1, 2), dim3(1024), 0, stream, two);
             hipLaunchKernelGGL(raster_scan_items_apply_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
         }
+        tr_raster_layers rl;
         for (uint32_t layer = 0; layer < 2u; ++layer) {
-            if (ctx->max_triangles[layer] == 0u) continue;
             const tr_layer_work& W = two.l[layer];
-            hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * 8u), dim3(256), 0, stream, gv, fr,
-                               (const tr_tri_record*)W.records, (const uint32_t*)W.item_base, (const tr_layer_counts*)W.counts, at,
-                               layer ? (const unsigned long long*)ctx->d_vis[0] : (const unsigned long long*)nullptr,
-                               ctx->d_vis[layer], ctx->d_tile_cover[layer]);
+            rl.records[layer] = W.records;
+            rl.item_base[layer] = W.item_base;
+            rl.counts[layer] = W.counts;
+            rl.vis[layer] = ctx->d_vis[layer];
+            rl.tile_cover[layer] = ctx->d_tile_cover[layer];
+            rl.enabled[layer] = ctx->max_triangles[layer] != 0u ? 1u : 0u;
         }
+        hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * 8u, 2), dim3(256), 0, stream, gv, fr, rl, at);
     }
     if (resolve) {
-        hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u, 2), dim3(256), 0, stream, fr, two, 0u,
+        hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u), dim3(256), 0, stream, fr, two,
                            fused_demux ? 0u : 1u);   // (fused = the frame recorder's call: its shading skips untouched tiles)
         ctx->vis_clean = true;
     }
@@ -1848,10 +1855,14 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->list_count_hint = ctx->d_tile_list_counts;
         ctx->vis_hint = use_vis ? ctx->d_vis[0] : nullptr;
         ctx->records_hint = ctx->d_records;
+        ctx->vis_front_hint = use_vis ? ctx->d_vis[1] : nullptr;
+        ctx->cover_front_hint = ctx->d_tile_cover[1];
         st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
         ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
         ctx->vis_hint = nullptr;
         ctx->records_hint = nullptr;
+        ctx->vis_front_hint = nullptr;
+        ctx->cover_front_hint = nullptr;
     }
     if (st != TR_OK) return st;
     {
