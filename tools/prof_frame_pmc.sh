@@ -23,7 +23,7 @@ out = sys.argv[1]
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(out, "pmc*/**/*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):
-        pmc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        pmc[row["Kernel_Name"][:110]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 rep = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in pmc.items() if k.startswith(("tr::", "void tr::"))}
 json.dump(rep, open(os.path.join(out, "summary.json"), "w"), indent=1)
 for k, cs in rep.items():
