@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     // VIS launches (real frames, where whole screen regions are empty or cheap): the XCDs are dealt STRIPES of
     // kStripeTileRows tile rows in turn instead of one contiguous band each, so that every XCD gets its share of the
     // covered part of the screen (a frame whose upper half is sky left half of the XCDs idle).
-    const bool striped = VIS && TR_VIS_STRIPES && !listed;
+    const bool striped = (VIS || TEX != kTexNone) && TR_VIS_STRIPES && !listed;
     uint32_t stripes_own = 0u, striped_len = 0u;
     if (striped) {
         const uint32_t st = L->fp.stripe_tiles;
