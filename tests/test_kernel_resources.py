@@ -68,7 +68,8 @@ def test_headline_kernel_holds_eight_waves_per_simd(kernels):
     # gfx950: 512 VGPRs per SIMD lane, granule 8: <= 64 -> 8 waves, <= 72 -> 7, <= 80 -> 6, <= 96 -> 5, <= 128 -> 4
     assert _shade(kernels, True, "uint2", 0, False)["vgpr"] <= 64      # what bench.py times
     assert _shade(kernels, False, "uint2", 0, False)["vgpr"] <= 64
-    assert _shade(kernels, False, "uint2", 0, True)["vgpr"] <= 64      # the frame recorder's untextured opaque pass
+    assert _shade(kernels, False, "uint2", 0, True)["vgpr"] <= 64      # the frame recorder's untextured passes
+    assert _shade(kernels, True, "uint2", 0, True)["vgpr"] <= 64       # (with an occupancy hint: TR_WAVES_ATTR)
 
 
 def test_textured_launch_classes_keep_their_occupancy(kernels):

@@ -1,6 +1,6 @@
 """Whole-frame rate of the glTF-in/frame-out pipeline at steady-state clocks (run on the GPU box): tr_record_frame
 (culling, light assignment, demultiplex, rasteriser, opaque, mips, transmissive, tonemap) back to back.
-    python tools/gpu_bench_frame.py [scene.glb | meshes] [width height]"""
+    python tools/gpu_bench_frame.py [scene.glb | meshes | plain] [width height]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "meshes"
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160)
 r = TransmissionRenderer(0)
 scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False, textured=(name == "meshes"))
-if name == "meshes":
+if name in ("meshes", "plain"):   # (plain: the same geometry with untextured materials)
     geometry = meshes.make_mesh_scene(extra_instances=True)
     scene["materials"][2].alpha_clipping_cutoff = 0.75
     scene["materials"][7].alpha_clipping_cutoff = 0.6

@@ -1249,7 +1249,11 @@ struct tile_regs {
 
 // Experiments only: an occupancy target for the register allocator, e.g. -DTR_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(TEXTURED ? 5 : 8)))'
 #ifndef TR_WAVES_ATTR
-#define TR_WAVES_ATTR
+// The untextured transmissive variant fed from visibility words (67 registers left to itself) fits 64 without a spill
+// once the allocator is told that eight waves are wanted; every other variant is left to itself (forced up, the RGBA32F
+// variant and the textured classes spill, and scratch costs more than the waves give: DESIGN.md 3.1;
+// tests/test_kernel_resources.py holds the line).
+#define TR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((TEX == kTexNone && TRANSMISSIVE && VIS) ? 8 : 1)))
 #endif
 // TEX: which material classes the launch shades (the host launches what the uploaded materials need, see tr_shade.hip):
 //   0  no uploaded material has a texture slot: every material through the scalar record;
