@@ -476,7 +476,7 @@ __global__ __launch_bounds__(1024) void frame_demux_scan_kernel(const tr_primiti
                                                                 uint32_t* __restrict__ draw_counts, const tr_draw_buffers out,
                                                                 const tr_two_layers two) {
     demultiplex_draws_body<true>(primitives, instance_counts, num_primitives, draw_counts, out);
-    __threadfence();
+    __threadfence_block();   // (producer and consumer are this workgroup: a device-scope fence writes back the whole L2 of the XCD)
     __syncthreads();
     const volatile uint32_t* counts_now = draw_counts;   // (written above by this workgroup)
     for (uint32_t layer = 0; layer < 2u; ++layer) {
