@@ -81,6 +81,9 @@ struct tr_timer { unsigned long long wait[3]; };
 #define TR_STRIPE_ROWS 4
 #endif
 constexpr uint32_t kStripeTileRows = TR_STRIPE_ROWS;
+#ifndef TR_LITE_ONE_LEVEL
+#define TR_LITE_ONE_LEVEL 1
+#endif
 #ifndef TR_PARK_LDS
 #define TR_PARK_LDS 1   // full-class textured pixels: see shade_pixel_textured
 #endif
@@ -1183,13 +1186,20 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
     tex_geom g;
     tex_taps taps;
     tex_geom_compute(g, t, uv.x, uv.y, duv);
-    texture_issue_shared(taps, L->tex_arena, t, g);
     const bool srgb = t->srgb != 0u;
     lite_dmat lm;
     lm.m = dm;
-    lm.diffuse[0] = mi->diffuse_factor[0] * texture_resolve_shared<0>(taps, g, srgb, lds_srgb);
-    lm.diffuse[1] = mi->diffuse_factor[1] * texture_resolve_shared<1>(taps, g, srgb, lds_srgb);
-    lm.diffuse[2] = mi->diffuse_factor[2] * texture_resolve_shared<2>(taps, g, srgb, lds_srgb);
+    if (TR_LITE_ONE_LEVEL && ballot(g.frac != 0.0f) == 0ull) {   // (uniform) every pixel of the wave exactly on its lower level
+        texture_issue_shared<1>(taps, L->tex_arena, t, g);
+        lm.diffuse[0] = mi->diffuse_factor[0] * texture_resolve_shared<0, 1>(taps, g, srgb, lds_srgb);
+        lm.diffuse[1] = mi->diffuse_factor[1] * texture_resolve_shared<1, 1>(taps, g, srgb, lds_srgb);
+        lm.diffuse[2] = mi->diffuse_factor[2] * texture_resolve_shared<2, 1>(taps, g, srgb, lds_srgb);
+    } else {
+        texture_issue_shared(taps, L->tex_arena, t, g);
+        lm.diffuse[0] = mi->diffuse_factor[0] * texture_resolve_shared<0>(taps, g, srgb, lds_srgb);
+        lm.diffuse[1] = mi->diffuse_factor[1] * texture_resolve_shared<1>(taps, g, srgb, lds_srgb);
+        lm.diffuse[2] = mi->diffuse_factor[2] * texture_resolve_shared<2>(taps, g, srgb, lds_srgb);
+    }
     // The colour is first USED at the end of the pixel; left to itself the optimiser sinks the whole filter down there
     // and keeps the eight taps, their weights and the decode look-ups alive across the light loop (+40 registers).
     asm volatile("" : "+v"(lm.diffuse[0]), "+v"(lm.diffuse[1]), "+v"(lm.diffuse[2]));

@@ -220,20 +220,24 @@ __device__ __forceinline__ void tex_geom_compute(tex_geom& g, cdtex* t, float u,
     tex_geom_level(g, 1, o.y - base, max(w >> l1, 1u), max(h >> l1, 1u), uu, vv);
 }
 
+template <int LEVELS = 2>
 __device__ __forceinline__ void texture_issue_shared(tex_taps& f, const uint32_t* __restrict__ arena, cdtex* t, const tex_geom& g) {
     const uint32_t* chain = arena + t->offset[0];       // scalar base: the taps are saddr + voffset loads
 #pragma unroll
-    for (int lv = 0; lv < 2; ++lv)
+    for (int lv = 0; lv < LEVELS; ++lv)
 #pragma unroll
         for (int k = 0; k < 4; ++k) f.t[lv][k] = ld<uint32_t>(chain, g.o[lv][k]);
 }
 
-template <int K>
+// LEVELS = 1: the wave's pixels all sit exactly on their lower level (frac == 0: a magnified texture, lambda clamped to
+// 0): the upper level's taps would be multiplied by zero — (lv1 - lv0) * 0 + lv0 == lv0 for finite texels — and are
+// neither fetched nor decoded.
+template <int K, int LEVELS = 2>
 __device__ __forceinline__ float texture_resolve_shared(const tex_taps& f, const tex_geom& g, bool srgb,
                                                         const float* __restrict__ lds_srgb) {
     float lv[2];
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < LEVELS; ++l) {
         float a, b, c, d;
         if (srgb && K < 3) {
             a = lds_srgb[(f.t[l][0] >> (8 * K)) & 0xFFu];
@@ -249,7 +253,7 @@ __device__ __forceinline__ float texture_resolve_shared(const tex_taps& f, const
         const float top = fmaf(b - a, g.fx[l], a), bot = fmaf(d - c, g.fx[l], c);
         lv[l] = fmaf(bot - top, g.fy[l], top);
     }
-    const float r = fmaf(lv[1] - lv[0], g.frac, lv[0]);
+    const float r = LEVELS == 2 ? fmaf(lv[1] - lv[0], g.frac, lv[0]) : lv[0];
     return (srgb && K < 3) ? r : r * (1.0f / 255.0f);
 }
 
