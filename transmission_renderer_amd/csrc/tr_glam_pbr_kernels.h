@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void ibl_volume_refraction_kernel(const tr_ibl
     const float tu = fmaf(cx, hw, 0.5f), tv = fmaf(cy, hw, 0.5f);
     const float lod = fast_log2((float)p.framebuffer_size_x) * m_rough_ior(lm);   // :334-335
     pyramid_fetch pf;
-    pyramid_issue<false>(pf, t.pyramid, as_constant(t.levels), t.pyr_levels, tu, tv, lod, lane);
+    pyramid_issue(pf, t.pyramid, as_constant(t.levels), t.pyr_levels, tu, tv, lod, lane);
     lut_fetch lf;
     uint32_t row0, row1;
     lut_rows(lm.rough, t.lut_height, t.lut_stride, lf.fy, row0, row1);

@@ -2,14 +2,15 @@
 //
 // Shape of the work
 //   One thread shades one pixel; a wave is a 16x4 pixel tile (four 256 B row segments per float4 plane, one 128 B
-//   segment of the RGBA16F target per row), a 256-thread workgroup a 64x4 screen tile.  Workgroups are persistent
-//   and renumbered so that each XCD (own L2) owns a contiguous band of the screen: the data-dependent taps into
-//   the opaque pyramid then re-use texel rows inside one L2 instead of being fetched by all eight.
+//   segment of the RGBA16F target per row) and a workgroup of its own, so the dispatcher refills a wave slot the
+//   moment its wave retires.  The 64x4 block tiles of the rect are numbered so that each XCD (own L2) owns a
+//   contiguous band of the screen (or, for real frames, stripes of it): the data-dependent taps into the opaque
+//   pyramid then re-use texel rows inside one L2 instead of being fetched by all eight.
 //
-// What bounds it (rocprofv3 PMC, profiles/r01): VALU issue and latency, not HBM — ~510 vector instructions per
-// pixel against 60 B of traffic.  So the math is arranged to be short, NOT as a transliteration of the reference,
-// and the kernel is kept at 64 VGPRs (8 waves per SIMD), because resident waves are what hides the scalar-load,
-// G-buffer and tap latencies:
+// What bounds it (rocprofv3 PMC, profiles/): VALU issue and latency, not HBM — ~460 vector instructions per
+// 64-pixel tile against 52-60 B of traffic per pixel.  So the math is arranged to be short, NOT as a transliteration
+// of the reference, and the kernel is kept at 64 VGPRs (8 waves per SIMD), because resident waves are what hides the
+// scalar-load, G-buffer and tap latencies:
 //   * everything that depends only on the material is digested once per upload into `tr_dmat`
 //     and read through the scalar unit: a wave handles one material at a time (waves that
 //     straddle several run a waterfall loop over them), so there is a single code path and the
@@ -22,13 +23,17 @@
 //     x^5 three multiplies.  (On gfx950 v_pk_fma_f32 issues at half the rate of v_fma_f32 — tools/ubench —
 //     so packing buys nothing: the build disables packed-fp32 selection.)
 //   * horizontally adjacent texels come in one 16-byte load, filtered as one weighted sum of v_fma_mix_f32;
-//   * the cluster x / y lookups are exact tables (built with the reference's own IEEE division on
-//     the host), the depth slice is one v_log_f32;
+//   * the cluster x / y lookups are exact tables (built with the reference's own IEEE division on the host); the
+//     depth slice is one v_log_f32 made exact against a table of slice thresholds (depth_slice);
+//   * the light list is walked on the scalar unit: one list per tile in the usual case, a waterfall over the tile's
+//     distinct clusters otherwise (cluster_lookup);
 //   * every buffer is addressed as scalar base + 32-bit byte offset (saddr/voffset loads, 24-bit multiply-adds);
 //   * the pyramid / LUT taps are issued after the light loop (see shade_pixel) and there is no register
 //     prefetch of the next tile: both were worth less than the two extra waves their registers cost.
 // These differ from the reference's op order by a few ulp of fp32 (and are closer to exact
 // arithmetic where the reference is ill-conditioned); parity criteria: tests/test_gpu_parity.py.
+// Variants that were measured and rejected are recorded in DESIGN.md 3.1 (and in the history of this file), not kept
+// here as switches.
 //
 // Reference semantics implemented here (file:line relative to the reference root):
 //   fragment_transmission        shader/src/lib.rs:37-162
@@ -68,43 +73,17 @@ struct tr_timer { unsigned long long wait[3]; };
 #define TR_TIMER_ARG
 #endif
 
-// Issue priority rises through the phases of a tile (TR_PRIO): among the waves of a SIMD the one nearest to the end of
-// its tile wins the arbitration, finishes, and has its next tile's loads in flight while the others compute — without
-// it the round-robin arbitration keeps waves that started together in lockstep (all wait, then all compute).
-#ifndef TR_PRIO
-#define TR_PRIO 1
-#endif
-#ifndef TR_VIS_STRIPES
-#define TR_VIS_STRIPES 1
-#endif
-#ifndef TR_STRIPE_ROWS
-#define TR_STRIPE_ROWS 4
-#endif
-constexpr uint32_t kStripeTileRows = TR_STRIPE_ROWS;
-#ifndef TR_LITE_ONE_LEVEL
-#define TR_LITE_ONE_LEVEL 1
-#endif
-#ifndef TR_PARK_LDS
-#define TR_PARK_LDS 1   // full-class textured pixels: see shade_pixel_textured
-#endif
-constexpr uint32_t kParkedValues = 23u;
-#ifndef TR_UNIFORM_CLUSTERS
-#define TR_UNIFORM_CLUSTERS 1
-#endif
+// Issue priority rises through the phases of a tile: among the waves of a SIMD the one nearest to the end of its tile
+// wins the arbitration, finishes, and has its next tile's loads in flight while the others compute — without it the
+// round-robin arbitration keeps waves that started together in lockstep (all wait, then all compute).
 template <int P>
 __device__ __forceinline__ void tile_phase() {
-#if TR_PRIO == 1
     __builtin_amdgcn_s_setprio(P);
-#elif TR_PRIO == 2   // experiments (all measured equal or slower): memory-issuing phases first, compute phases low
-    __builtin_amdgcn_s_setprio(P == 0 ? 3 : P == 1 ? 0 : P == 2 ? 3 : 1);
-#elif TR_PRIO == 3   // two levels
-    __builtin_amdgcn_s_setprio(P >= 2 ? 1 : 0);
-#elif TR_PRIO == 4   // only the last phase raised
-    __builtin_amdgcn_s_setprio(P == 3 ? 3 : 0);
-#endif
 }
+constexpr uint32_t kStripeTileRows = 4u;   // VIS / textured launches: tile rows per XCD stripe (1 ... 8 measure the same)
+constexpr uint32_t kParkedValues = 20u;    // full-class textured pixels: values parked in LDS, see shade_pixel_textured
 
-// ---------------------------------------------------------------- digested material (176 B)
+// ---------------------------------------------------------------- digested material (240 B)
 // Index 0 of every pair belongs to the basic_brdf lobe, index 1 to the transmission_btdf lobe.
 struct alignas(16) tr_dmat {
     float diffuse[3];      // diffuse_factor.rgb (base colour)
@@ -132,9 +111,22 @@ struct alignas(16) tr_dmat {
     float bt_a[3];         // k[1] * (1 - f0): the btdf lobe is accumulated as sum(I D'V') and sum(I D'V' p') and
     float bt_b[3];         // k[1] * (f90 - f0): resolved once per pixel as bt_a * sum1 - bt_b * sum2
     uint32_t lut_line;     // first entry of this material's GGX LUT line (build_lut_lines_kernel), in entries
-    uint32_t _pad[2];
+    float neg_eta2;        // -(eta * eta)   (refract's k = 1 - eta^2 (1 - (n.i)^2))
+    uint32_t _pad;
+    // The composite of a pixel whose material has no texture slots (shade_pixel's finish), with tf = transmission_factor
+    // folded in: lib.rs:157-159 is  diffuse' = lerp(D, tf * X, tf) = (1 - tf) D + tf^2 X  with D = c_diff * sum_d and
+    // X = diffuse * ((1 - (f0 A + f90 B)) T + bt_a * sum_ta - bt_b * sum_tb), so
+    //   out = kd * sum_d + kt * (1 - (f0 A + f90 B)) T + kta * sum_ta - ktb * sum_tb + specular + emission
+    float kd[3];           // c_diff * (1 - tf)
+    float _pad1;
+    float kt[3];           // tf^2 * diffuse
+    float _pad2;
+    float kta[3];          // tf^2 * diffuse * bt_a
+    float _pad3;
+    float ktb[3];          // tf^2 * diffuse * bt_b
+    float _pad4;
 };
-static_assert(sizeof(tr_dmat) == 176, "digested material is 176 B");
+static_assert(sizeof(tr_dmat) == 240, "digested material is 240 B");
 
 // Light as the kernels read it: the reference's 48-byte record (shared-structs/src/lib.rs:70-78)
 // with the per-light constants of spotlight_factor (:129-138) digested at upload.
@@ -153,6 +145,24 @@ struct tr_level_table {           // pyramid geometry, one entry per mip level
     float hf[TR_MAX_MIP_LEVELS];
     float xlim[TR_MAX_MIP_LEVELS];       // max(width - 2, 0): left texel of the right-most 16-byte pair
 };
+
+// What the refraction tap of a material WITHOUT texture slots needs from the opaque pyramid (digest_taps_kernel, once
+// per (material table, pyramid geometry, framebuffer width)): the pyramid lod of ibl_volume_refraction
+// (glam-pbr/src/lib.rs:334-335) depends on the material only, so its level pair, the interpolation weight and the
+// geometry of the two levels are one scalar record per material — the pixel neither forms the lod nor walks the level
+// table (eight vector instructions on wave-uniform values and a dependent scalar round trip per tile before).
+// Index 0 of every pair is the lower level (floor(lod)), index 1 the next.
+struct alignas(16) tr_dtap {
+    float t;                  // frac(lod): weight of level 1
+    uint32_t narrow;          // bit k: level k is one texel wide (the 16-byte pair's second texel is not its neighbour)
+    uint32_t offset[2];       // byte offset of the level from the pyramid base
+    uint32_t pitch[2];        // bytes from a row to the next; 0 when the level has one row (both taps read that row)
+    uint32_t width[2];        // texels per row
+    float wf[2], hf[2];       // (float)width, (float)height
+    float xhi[2], yhi[2];     // width - 1, height - 1: the clamp of the texel coordinate
+    float xlim[2], ylim[2];   // max(width - 2, 0), max(height - 2, 0): the first texel / row of the last pair
+};
+static_assert(sizeof(tr_dtap) == 80, "tap record is 80 B");
 
 // Everything a shading launch needs besides the planes; passed by value (kernarg -> SGPRs).
 struct tr_frame_params {
@@ -176,7 +186,8 @@ struct tr_frame_params {
     uint32_t tiles_x_magic;      // floor(2^32 / tiles_x): tile / tiles_x on the scalar unit (one fix-up step)
     uint32_t stripe_tiles;       // VIS launches: block tiles per stripe of kStripeTileRows tile rows, and
     uint32_t stripe_magic;       // floor(2^32 / stripe_tiles)
-    uint32_t lut_width, lut_stride;  // pair-table stride in entries (= lut_width + 2)
+    float lut_wf;                // (float)lut_width
+    uint32_t lut_stride;         // pair-table stride in entries (= lut_width + 2)
     uint32_t lut_height;
     uint32_t pyr_levels;
     uint32_t solo_full;          // TEX = 2 launch only: every uploaded material is of the full class, there is no TEX = 1
@@ -188,6 +199,7 @@ struct tr_frame_params {
 typedef const TR_CONSTANT tr_dmat cdmat;
 typedef const TR_CONSTANT tr_dlight cdlight;
 typedef const TR_CONSTANT tr_level_table clevels;
+typedef const TR_CONSTANT tr_dtap cdtap;
 typedef const TR_CONSTANT uint32_t cu32;
 
 // The single kernel argument of shade_kernel: frame parameters and every pointer.  The kernel reads it
@@ -203,6 +215,7 @@ struct tr_launch {
     const uint32_t* lut_pairs;          // (R,G)[x-1], (R,G)[x] per entry
     const float4* lut_lines;            // per material: the LUT at the material's roughness, (A,B)[x-1], (A,B)[x] per entry
     const tr_level_table* levels;
+    const tr_dtap* dtaps;               // per material, see tr_dtap
     const uint16_t* cluster_x;          // [frame width]  u32(frag_coord.x / cluster_size.x)
     const uint32_t* cluster_y_term;     // [frame height] u32(frag_coord.y / cluster_size.y) * num_clusters.x
     const float4* pos_depth;
@@ -232,7 +245,6 @@ struct tr_launch {
     // depth, zeroes that word where the fragment is not nearer than the opaque surface.
     unsigned long long* vis_front;
     const uint32_t* cover_front;
-    uint32_t* tile_counters;            // per XCD kSubCounters tile counters + one count of finished waves, 256 bytes apart
 };
 typedef const TR_CONSTANT tr_launch claunch;
 
@@ -261,6 +273,7 @@ __device__ __forceinline__ float m_oma2(const TR_CONSTANT tr_dmat& m, int k) { r
 __device__ __forceinline__ float m_k(const TR_CONSTANT tr_dmat& m, int k) { return m.k[k]; }
 __device__ __forceinline__ float m_df(const TR_CONSTANT tr_dmat& m, int k) { return m.df[k]; }
 __device__ __forceinline__ float m_rough_ior(const TR_CONSTANT tr_dmat& m) { return m.rough_ior; }
+__device__ __forceinline__ float m_neg_eta2(const TR_CONSTANT tr_dmat& m) { return m.neg_eta2; }
 // (the operand goes through an empty volatile asm: the recomputation stays where it is used instead of being hoisted
 //  out of the light loop back into a register of its own)
 __device__ __forceinline__ float here(float x) {
@@ -271,6 +284,7 @@ __device__ __forceinline__ float m_oma2(const lane_dmat& m, int k) { return 1.0f
 __device__ __forceinline__ float m_k(const lane_dmat& m, int k) { return here(m.a2[k]) * (0.5f * kFrac1Pi); }
 __device__ __forceinline__ float m_df(const lane_dmat& m, int k) { return m.f90 - here(m.f0[k]); }
 __device__ __forceinline__ float m_rough_ior(const lane_dmat& m) { return m.rough * m.ior_clamp; }
+__device__ __forceinline__ float m_neg_eta2(const lane_dmat& m) { return -m.eta * m.eta; }
 __device__ __forceinline__ float mat_bt_a(const lane_dmat* m, int k) { return m_k(*m, 1) * (1.0f - m->f0[k]); }
 __device__ __forceinline__ float mat_bt_b(const lane_dmat* m, int k) { return m_k(*m, 1) * m_df(*m, k); }
 
@@ -294,6 +308,25 @@ __device__ __forceinline__ float mat_diffuse(const lite_dmat* m, int k) { return
 __device__ __forceinline__ float mat_c_diff(const lite_dmat* m, int k) {
     const float diff = m->diffuse[k];
     return (diff + (0.0f - diff) * 0.0f) * kFrac1Pi;                 // lerp(diffuse, 0, metallic = 0) / pi
+}
+
+// min / max against a table value in a scalar register, as ONE instruction: for a value it cannot prove canonical
+// (anything loaded) the compiler puts a canonicalising v_max x, x in front of fminf / fmaxf.  NaN in `a` gives `s`.
+__device__ __forceinline__ float min_s(float a, float s) {
+    float r;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float max_v(float a, float b) {   // fmaxf of two register values, no canonicalisation
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max(x, eps): Dot::new's clamp (glam-pbr/src/lib.rs:93-98) as one instruction (the literal is the first source)
+__device__ __forceinline__ float clamp_eps(float x) {
+    float r;
+    asm("v_max_f32_e32 %0, 0x34000000, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 // ------------------------------------------------------------------------ one light
@@ -340,8 +373,8 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
     // |v+l|^2 = 2 + 2 v.l (|v| = |l| = 1) vanishes where v = -l; rounding can push it below zero: floor it.
     {
         const float inv_h = rsq(fmaxf(fmaf(2.0f, vl, 2.0f), 1e-12f));
-        const float voh = fmaxf((1.0f + vl) * inv_h, kEpsilon);   // Dot::new clamps to EPSILON (:93-98)
-        const float nol = fmaxf(nl_raw, kEpsilon);
+        const float voh = clamp_eps((1.0f + vl) * inv_h);          // Dot::new clamps to EPSILON (:93-98)
+        const float nol = clamp_eps(nl_raw);
         const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;   // fresnel_schlick :137-139
         const float sin2 = c2 * (inv_h * inv_h);                   // 1 - (n.h)^2
         const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
@@ -376,8 +409,8 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         if (btdf) {
             const float vlm = fmaf(-2.0f * nl_raw, nov_raw, vl);
             const float inv_h = rsq(fmaxf(fmaf(2.0f, vlm, 2.0f), 1e-12f));
-            const float voh = fmaxf((vlm + 1.0f) * inv_h, kEpsilon);
-            const float nolm = fmaxf(-nl_raw, kEpsilon);
+            const float voh = clamp_eps((vlm + 1.0f) * inv_h);
+            const float nolm = clamp_eps(-nl_raw);
             const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
             const float sin2 = c2 * (inv_h * inv_h);
             const float f = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - sin2, sin2) : 1.0f;
@@ -498,28 +531,54 @@ __device__ __forceinline__ void pyramid_issue_levels(pyramid_fetch& pf, const ui
     pf.narrow1 = w1 < 2u;
 }
 
-// UNIFORM_LOD: `lod` depends on the material only and the material is in scalar registers, so the whole wave
-// shares the level pair.  Otherwise (roughness from a texture) the wave walks the distinct level pairs of its
-// lanes, normally one or two.
-template <bool UNIFORM_LOD>
+// The same taps for a material whose lod is in its tap record (tr_dtap: scalar registers).  Per level and axis:
+//   t = clamp(u * size - 0.5, 0, size - 1);  b = min(floor(t), max(size - 2, 0));  weight = t - b
+// — in BOTH axes the pair (b, b + 1) is fetched: at the far edge b = size - 2 and the weight becomes exactly 1, which
+// is the clamped tap (i0 = i1 = size - 1, any weight) of the sampler.  So the second row is the first row's address
+// plus the level's pitch: one offset per level, two scalar bases.  A level of one row has pitch 0, a level of one
+// column is flagged narrow (pyramid_resolve).
+__device__ __forceinline__ void pyramid_issue_record(pyramid_fetch& pf, const uint2* __restrict__ texels, cdtap* tp, float u,
+                                                     float v) {
+    const char* base = reinterpret_cast<const char*>(texels);
+    float wx[2], wy[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float tx = __builtin_amdgcn_fmed3f(fmaf(u, tp->wf[k], -0.5f), 0.0f, tp->xhi[k]);
+        const float bx = min_s(floorf(tx), tp->xlim[k]);
+        wx[k] = tx - bx;
+        const float ty = __builtin_amdgcn_fmed3f(fmaf(v, tp->hf[k], -0.5f), 0.0f, tp->yhi[k]);
+        const float by = min_s(floorf(ty), tp->ylim[k]);
+        wy[k] = ty - by;
+        const uint32_t at = mad24((uint32_t)by, tp->width[k], (uint32_t)bx) * 8u;
+        const char* row0 = base + tp->offset[k];
+        const char* row1 = row0 + tp->pitch[k];
+        const u32x4 a = ld<u32x4_a8>(row0, at), b = ld<u32x4_a8>(row1, at);   // global_load_dwordx4, saddr + voffset
+        pf.r0[k] = uint4{a.x, a.y, a.z, a.w};
+        pf.r1[k] = uint4{b.x, b.y, b.z, b.w};
+    }
+    pf.wx = v2f{wx[0], wx[1]};
+    pf.wy = v2f{wy[0], wy[1]};
+    pf.t = tp->t;
+    pf.narrow0 = (tp->narrow & 1u) != 0u;
+    pf.narrow1 = (tp->narrow & 2u) != 0u;
+}
+
+// Per-lane lod (roughness from a texture): the wave walks the distinct level pairs of its lanes, normally one or two,
+// so that level geometry is scalar inside pyramid_issue_levels.
 __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __restrict__ texels,
                                               clevels* lv, uint32_t levels, float u, float v,
                                               float lod, uint32_t lane) {
     float l = fminf(fmaxf(lod, 0.0f), (float)(levels - 1u));
     float lf = floorf(l);
     pf.t = l - lf;
-    if constexpr (UNIFORM_LOD) {
-        pyramid_issue_levels(pf, texels, lv, levels, u, v, __builtin_amdgcn_readfirstlane((uint32_t)lf));
-    } else {
-        const uint32_t mine = (uint32_t)lf;
-        uint64_t todo = ballot(true);
-        while (todo) {
-            const int first = __ffsll((unsigned long long)todo) - 1;
-            const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, first);
-            const uint64_t group = ballot(mine == l0);
-            todo &= ~group;
-            if ((group >> lane) & 1ull) pyramid_issue_levels(pf, texels, lv, levels, u, v, l0);
-        }
+    const uint32_t mine = (uint32_t)lf;
+    uint64_t todo = ballot(true);
+    while (todo) {
+        const int first = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, first);
+        const uint64_t group = ballot(mine == l0);
+        todo &= ~group;
+        if ((group >> lane) & 1ull) pyramid_issue_levels(pf, texels, lv, levels, u, v, l0);
     }
 }
 
@@ -528,8 +587,13 @@ __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __
 // so that every term is a v_fma_mix_f32 reading the half-precision texel in place (no v_cvt_f32_f16, which
 // runs at half rate, and no subtractions); it equals the lerp form of the oracle up to fp32 rounding.
 __device__ __forceinline__ f3 pyramid_resolve(pyramid_fetch& pf) {
-    if (pf.narrow0) { pf.r0[0].z = pf.r0[0].x; pf.r0[0].w = pf.r0[0].y; pf.r1[0].z = pf.r1[0].x; pf.r1[0].w = pf.r1[0].y; }
-    if (pf.narrow1) { pf.r0[1].z = pf.r0[1].x; pf.r0[1].w = pf.r0[1].y; pf.r1[1].z = pf.r1[1].x; pf.r1[1].w = pf.r1[1].y; }
+    // (scalar, rare: only the last levels of a pyramid are one texel wide; the empty asm keeps the branch a branch —
+    //  if-converted, every pixel pays eight v_cndmask for it)
+    if (pf.narrow0 || pf.narrow1) {
+        asm volatile("");
+        if (pf.narrow0) { pf.r0[0].z = pf.r0[0].x; pf.r0[0].w = pf.r0[0].y; pf.r1[0].z = pf.r1[0].x; pf.r1[0].w = pf.r1[0].y; }
+        if (pf.narrow1) { pf.r0[1].z = pf.r0[1].x; pf.r0[1].w = pf.r0[1].y; pf.r1[1].z = pf.r1[1].x; pf.r1[1].w = pf.r1[1].y; }
+    }
     float w[2][4];
     const float lw[2] = {1.0f - pf.t, pf.t};
 #pragma unroll
@@ -584,7 +648,7 @@ __device__ __forceinline__ void lut_issue(lut_fetch& lf, const uint32_t* __restr
 __device__ __forceinline__ void lut_line_issue(lut_fetch& lf, const float4* __restrict__ lines, float lut_wf,
                                                uint32_t line, float nov_raw) {
     float x = fmaf(nov_raw, lut_wf, -0.5f);
-    x = fminf(fmaxf(x, -1.0f), lut_wf);
+    x = min_s(fmaxf(x, -1.0f), lut_wf);
     float fl = floorf(x);
     lf.fx = x - fl;
     uint32_t k = (uint32_t)((int)fl + 1);
@@ -677,15 +741,18 @@ __device__ __forceinline__ void digest_factors(D& d, float metallic, float rough
 }
 
 // ------------------------------------------------------------------------ cluster lookup
-// What a pixel knows about its light list before the light loop: requested for all 64 pixels of a tile at once,
-// before the wave splits by material.
+// What a tile knows about its light lists before the light loop.  The list is always walked on the scalar unit: the
+// usual tile lies in one cluster (they are 240 pixels wide at 4K and 1/16 of the log-depth range deep), a tile that
+// straddles clusters whose lists are the SAME list (count and entries, compared through the scalar unit here) is
+// treated like one, and any other tile runs the light loop once per distinct cluster with that cluster's lanes
+// (shade_pixel).  There is no per-lane list walk: it cost the pixel five vector registers across the sun and the
+// prologue, a second instantiation of the light evaluation and ten register copies where the two walks joined.
+constexpr uint32_t kNoCluster = 0xFFFFFFFFu;
 struct cluster_list {
     uint32_t cluster;       // cluster index (the debug view prints it)
-    uint32_t num_lights;
-    uint32_t list_offset;   // byte offset of the list in light_indices
-    uint32_t l0, l1;        // its first two entries: lists of up to two lights need no load inside the light loop
-    bool uniform;           // (scalar) every pixel of the tile is in one cluster: its list is walked on the scalar unit
-    uint32_t s_cluster;     // (scalar) that cluster, or 0xFFFFFFFF when it is out of range (no lights)
+    uint32_t key;           // the cluster whose list the lane walks; kNoCluster: out of range (robust access: no lights)
+    bool uniform;           // (scalar) every pixel of the tile walks the list of s_cluster
+    uint32_t s_cluster;     // (scalar) the first working lane's key
     uint32_t s_num, s_l0, s_l1;   // (scalar) its count and the first two entries of its list
 };
 
@@ -715,13 +782,7 @@ struct slice_params {   // (scalar registers)
     uint32_t max;
     const float* thr;
 };
-#ifndef TR_EXACT_SLICE
-#define TR_EXACT_SLICE 1   // 0 (experiments only, tools/ab_kernel.py): round 1's estimate-only slice, what exactness costs
-#endif
 __device__ __forceinline__ uint32_t depth_slice(const slice_params& sp, float depth) {
-#if !TR_EXACT_SLICE
-    return (uint32_t)fmaxf(fmaf(-sp.scale, fast_log2(fmaf(depth, 2.0f * sp.fmn, sp.fpn - sp.fmn)), sp.k), 0.0f);
-#endif
     const float zs = fmaf(-sp.scale, fast_log2(slice_denominator(depth, sp.fpn, sp.fmn)), sp.k);
     uint32_t cz = cvt_u32_sat(zs);
     const float fr = __builtin_amdgcn_fractf(zs);
@@ -735,42 +796,44 @@ __device__ __forceinline__ uint32_t depth_slice(const slice_params& sp, float de
     return cz;
 }
 
-// shader/src/lib.rs:88-98: x / y from exact tables (cluster_xy), the depth slice from depth_slice().
-__device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, uint32_t cluster_xy) {
+// (scalar) count of a cluster's list, clamped to the 128 slots (borrowed tables may count past them, like the
+// reference's counter); kNoCluster has no lights
+__device__ __forceinline__ uint32_t cluster_count(claunch* L, uint32_t sc) {
+    if (sc == kNoCluster || TR_ABLATE(L, 8u)) return 0u;
+    return min(as_constant(L->cluster_counts)[sc], TR_MAX_LIGHTS_PER_CLUSTER);
+}
+__device__ __forceinline__ const TR_CONSTANT uint32_t* cluster_entries(claunch* L, uint32_t sc) {
+    return as_constant(L->light_indices) + (size_t)(sc == kNoCluster ? 0u : sc) * TR_MAX_LIGHTS_PER_CLUSTER;
+}
+
+// shader/src/lib.rs:88-98: x / y from exact tables (cluster_xy), the depth slice from depth_slice().  Runs with the
+// whole wave; `has_work`: the lane has a pixel to shade (the others follow the first one that has: a tile with holes
+// stays uniform).  At least one lane has work.
+__device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, uint32_t cluster_xy, bool has_work) {
     cluster_list c;
     const uint32_t cz = depth_slice(slice_params{L->fp.lcc_scale, L->fp.slice_fpn, L->fp.slice_fmn, L->fp.slice_k,
                                                  L->fp.slice_max, L->slice_thr}, depth);
     c.cluster = mad24(cz, L->fp.clusters_xy, cluster_xy);   // (cz <= slice_max for every depth >= 0: far below 2^24)
-    const bool in_range = c.cluster < L->fp.num_clusters_total;  // out-of-range reads as 0 lights (robust access)
-    const uint32_t csafe = in_range ? c.cluster : 0u;
-    c.list_offset = csafe * (TR_MAX_LIGHTS_PER_CLUSTER * 4u);
-#if TR_UNIFORM_CLUSTERS
-    // The usual tile lies in one cluster (they are 240 pixels wide at 4K and 1/16 of the log-depth range deep): then
-    // nothing is fetched here, the light loop reads count and list through the scalar unit.
-    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cluster);
-    c.uniform = ballot(c.cluster != c0) == 0ull;
-    c.s_cluster = c0 < L->fp.num_clusters_total ? c0 : 0xFFFFFFFFu;
-    if (c.uniform) {   // count and the head of the list are requested here, a tile phase ahead of the light loop
-        const bool ok = c.s_cluster != 0xFFFFFFFFu && !TR_ABLATE(L, 8u);
-        const uint32_t sc = ok ? c.s_cluster : 0u;
-        const uint32_t n = as_constant(L->cluster_counts)[sc];
-        const TR_CONSTANT uint32_t* list = as_constant(L->light_indices) + (size_t)sc * TR_MAX_LIGHTS_PER_CLUSTER;
-        c.s_l0 = list[0];
-        c.s_l1 = list[1];
-        c.s_num = ok ? min(n, TR_MAX_LIGHTS_PER_CLUSTER) : 0u;
-        c.num_lights = c.l0 = c.l1 = 0u;
-        return c;
+    const uint32_t own = c.cluster < L->fp.num_clusters_total ? c.cluster : kNoCluster;
+    const uint64_t work = ballot(has_work);
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)own, __ffsll((unsigned long long)work) - 1);
+    c.key = has_work ? own : c0;
+    uint64_t others = ballot(c.key != c0);
+    c.s_cluster = c0;
+    // count and the head of the list are requested here, a tile phase ahead of the light loop
+    c.s_num = cluster_count(L, c0);
+    const TR_CONSTANT uint32_t* list0 = cluster_entries(L, c0);
+    c.s_l0 = list0[0];
+    c.s_l1 = list0[1];
+    bool same = true;
+    while (others != 0ull && same) {   // (rare) the tile straddles clusters: is it one list all the same?
+        const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)c.key, __ffsll((unsigned long long)others) - 1);
+        others &= ~ballot(c.key == ck);
+        const TR_CONSTANT uint32_t* list = cluster_entries(L, ck);
+        same = cluster_count(L, ck) == c.s_num;
+        for (uint32_t i = 0; same && i < c.s_num; ++i) same = list[i] == list0[i];
     }
-#else
-    c.uniform = false;
-    c.s_cluster = c.s_num = c.s_l0 = c.s_l1 = 0u;
-#endif
-    const uint32_t n = ld<uint32_t>(L->cluster_counts, csafe * 4u);
-    const uint2 first = ld<uint2>(L->light_indices, c.list_offset);   // (lists are 512-byte aligned)
-    c.l0 = first.x;
-    c.l1 = first.y;
-    c.num_lights = in_range ? min(n, TR_MAX_LIGHTS_PER_CLUSTER) : 0u;   // (borrowed tables may count past the 128 slots, like the reference's counter)
-    if (TR_ABLATE(L, 8u)) c.num_lights = 0;
+    c.uniform = same;
     return c;
 }
 
@@ -782,7 +845,7 @@ __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, 
 // `const lane_dmat*` — per-lane values digested from the sampled textures; `ns.xyz` is then the normal after
 // normal mapping.
 template <bool TRANSMISSIVE, class MatP>
-__device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 ns, uint32_t lane,
+__device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index, float4 pd, float4 ns, uint32_t lane,
                                           const cluster_list& cl TR_TIMER_PARAM) {
     // (roughness, ior and the LUT line are the table's: one level pair and one LUT line per wave)
     constexpr bool SCALAR_MATERIAL = std::is_same<MatP, cdmat*>::value || std::is_same<MatP, const lite_dmat*>::value;
@@ -797,7 +860,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     float inv_n = rsq(dot3(ns.x, ns.y, ns.z, ns.x, ns.y, ns.z));
     const f3 n = {ns.x * inv_n, ns.y * inv_n, ns.z * inv_n};
     const float nov_raw = dot3(n.x, n.y, n.z, v.x, v.y, v.z);
-    const float nov = fmaxf(nov_raw, kEpsilon);
+    const float nov = clamp_eps(nov_raw);
     pixel_frame px;
     px.n = n;
     px.v = v;
@@ -807,8 +870,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
     px.nov_raw = nov_raw;
     px.nov = nov;
 
-    const uint32_t num_lights = cl.num_lights;
-    uint32_t uniform_lights = 0u;   // (scalar) the count when the tile's cluster is uniform
+    uint32_t lights_walked = 0u;   // (opaque pass, debug view) the count of the list the lane walked
 
     // ---- ibl_volume_refraction, part 1 (glam-pbr/src/lib.rs:292-337): where the refracted ray leaves
     //      the volume, projected to the screen; the taps are in flight while the lights are evaluated.
@@ -823,7 +885,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         const auto mb = mat_base(m);
         // refract(-v, n, ior) :248-256 ; unit length by construction (Snell), so no re-normalise
         float eta = mb->eta;
-        float k = fmaf(-eta * eta, fmaf(-nov_raw, nov_raw, 1.0f), 1.0f);
+        float k = fmaf(m_neg_eta2(*mb), fmaf(-nov_raw, nov_raw, 1.0f), 1.0f);
         float cn = fmaf(-eta, nov_raw, fast_sqrt(k));   // eta * n.i + sqrt(k), n.i = -n.v
         len = mb->thickness * ns.w;                      // thickness * model_scale :264
         float ex = fmaf(fmaf(-eta, v.x, -cn * n.x), len, pos.x);
@@ -836,28 +898,29 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         float hw = 0.5f * rcp(cw);                      // (clip.xy / clip.w + 1) / 2  :330-332
         float tu = fmaf(cx, hw, 0.5f);
         float tv = fmaf(cy, hw, 0.5f);
-        float lod = L->fp.log2_fb_width * m_rough_ior(*mb); // :334-335
-        if (!TR_ABLATE(L, 1u)) pyramid_issue<SCALAR_MATERIAL>(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane);
-        else { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
+        // lod = log2(framebuffer width) * roughness * clamp(2 ior - 2, 0, 1) (:334-335): the material's alone when it
+        // has no texture slots (its tap record), per lane otherwise
         if constexpr (SCALAR_MATERIAL) {
-            lut_line_issue(lf, L->lut_lines, (float)L->fp.lut_width, mb->lut_line, nov_raw);
+            if (!TR_ABLATE(L, 1u)) pyramid_issue_record(pf, L->pyramid, as_constant(L->dtaps) + mat_index, tu, tv);
+        } else {
+            float lod = L->fp.log2_fb_width * m_rough_ior(*mb);
+            if (!TR_ABLATE(L, 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane);
+        }
+        if (TR_ABLATE(L, 1u)) { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
+        if constexpr (SCALAR_MATERIAL) {
+            lut_line_issue(lf, L->lut_lines, L->fp.lut_wf, mb->lut_line, nov_raw);
         } else {   // per-pixel roughness: the row pair is found here, not carried through the light loop
             uint32_t row0, row1;
             lut_rows(mb->rough, L->fp.lut_height, L->fp.lut_stride, lf.fy, row0, row1);
-            lut_issue(lf, L->lut_pairs, (float)L->fp.lut_width, row0, row1, nov_raw);
+            lut_issue(lf, L->lut_pairs, L->fp.lut_wf, row0, row1, nov_raw);
         }
     }
     };
 
     // ================= phases 2+3: the sun, then the clustered punctual lights =================
-    // Every lane walks its own cluster's list; at each step the lanes whose next light index equals that of the
-    // first pending lane evaluate it together, with the light read through the scalar unit.  When the lists
-    // agree (the normal case, also across cluster boundaries) that is one pass per light.
-#ifndef TR_SUN_FIRST
-#define TR_SUN_FIRST 1   // the sun writes the accumulators (0: zero-initialised and accumulated, experiments only)
-#endif
+    // The sun writes the accumulators instead of adding to zeros (eval_light<FIRST>).
     light_acc acc;
-    if (!TR_SUN_FIRST || TR_ABLATION) acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (TR_ABLATION) acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto lights_phase = [&]() {
         claunch* L2 = launder(L);
         const auto m2 = mat_base(launder(m));
@@ -867,89 +930,101 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         }
         // sun (lighting.rs:37-53 / 171-177)
         if (!TR_ABLATE(L2, 4u))
-            eval_light<TRANSMISSIVE, TR_SUN_FIRST && !TR_ABLATION>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
+            eval_light<TRANSMISSIVE, !TR_ABLATION>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
                                      {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, transmits);
         tile_phase<1>();
     };
-    // punctual lights (lighting.rs:55-92 / 179-217)
-    auto punctual_uniform = [&]() {   // one cluster for the whole tile: count, list and lights all through the scalar unit
+    // punctual lights (lighting.rs:55-92 / 179-217): count, list and lights all through the scalar unit.  One trip of
+    // the outer loop per distinct list of the tile: a single one when cl.uniform (the usual case), otherwise a waterfall
+    // over the clusters of this material's lanes, each trip with exec = the lanes of that cluster.
+    auto punctual = [&]() {
         claunch* L2 = launder(L);
         const auto m2 = mat_base(launder(m));
         cdlight* lights = as_constant(L2->lights);
-        {
-            const uint32_t n = cl.s_num;
-            const uint32_t sc = cl.s_cluster == 0xFFFFFFFFu ? 0u : opaque(cl.s_cluster);
-            const TR_CONSTANT uint32_t* list = as_constant(L2->light_indices) + (size_t)sc * TR_MAX_LIGHTS_PER_CLUSTER;
-            for (uint32_t i = 0; i < n; ++i) {
-                const uint32_t idx = i == 0u ? cl.s_l0 : i == 1u ? cl.s_l1 : list[i];
-                eval_punctual<TRANSMISSIVE>(acc, *m2, lights[idx], pos, px, transmits);
+        uint64_t pending = cl.uniform ? 0ull : ballot(true);
+        do {
+            uint32_t ck = cl.s_cluster, n = cl.s_num;
+            if (!cl.uniform) {
+                ck = (uint32_t)__builtin_amdgcn_readlane((int)cl.key, __ffsll((unsigned long long)pending) - 1);
+                pending &= ~ballot(cl.key == ck);
+                n = cluster_count(L2, opaque(ck));
             }
-            uniform_lights = n;
-        }
-    };
-    auto punctual_per_lane = [&]() {
-        claunch* L2 = launder(L);
-        const auto m2 = mat_base(launder(m));
-        cdlight* lights = as_constant(L2->lights);
-        constexpr uint32_t kDone = 0xFFFFFFFFu;   // a lane whose list is exhausted
-        uint32_t i = 0;
-        uint32_t head = num_lights ? cl.l0 : kDone;
-        uint64_t pending = ballot(head != kDone);
-        // (wave-uniform: with at most two lights per list — l0, l1 — the loop has no memory access at all)
-        const bool long_lists = ballot(num_lights > 2u) != 0ull;
-        while (pending) {
-            const int l0 = __ffsll((unsigned long long)pending) - 1;
-            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)head, l0);
-            const uint32_t h0s = opaque(h0);
-            if (head == h0) {
-                ++i;
-                uint32_t next = cl.l1;
-                if (long_lists && i >= 2u)   // longer lists: the entry is in flight during the evaluation
-                    next = ld<uint32_t>(L2->light_indices, cl.list_offset + min(i, TR_MAX_LIGHTS_PER_CLUSTER - 1u) * 4u);
-                eval_punctual<TRANSMISSIVE>(acc, *m2, lights[h0s], pos, px, transmits);
-                head = i < num_lights ? next : kDone;
+            if (cl.uniform || cl.key == ck) {
+                const TR_CONSTANT uint32_t* list = cluster_entries(L2, opaque(ck));
+#pragma clang loop unroll(disable)   // (left alone the first two trips are peeled: three copies of the light evaluation)
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t idx = (cl.uniform && i == 0u) ? cl.s_l0 : (cl.uniform && i == 1u) ? cl.s_l1 : list[i];
+                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[idx], pos, px, transmits);
+                }
+                if constexpr (!TRANSMISSIVE) lights_walked = n;
             }
-            pending = ballot(head != kDone);
-        }
+        } while (pending != 0ull);
     };
     // ================= phase 4: resolve the taps, composite =================
     auto finish = [&]() -> f3 {
         claunch* L4 = launder(L);
         MatP mo = launder(m);                  // what a base-colour texture changes is read through `mo`,
         const auto m4 = mat_base(mo);          // every other constant from the record
-        f3 diffuse = {acc.d.x * mat_c_diff(mo, 0), acc.d.y * mat_c_diff(mo, 1), acc.d.z * mat_c_diff(mo, 2)};
-
-        if (transmits) {
-            // ---- ibl_volume_refraction, part 2 (:337-353)
-            f3 T = pyramid_resolve(pf);
-            if (m4->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
-                T.x *= fast_exp2(m4->neg_atten_log2[0] * len);
-                T.y *= fast_exp2(m4->neg_atten_log2[1] * len);
-                T.z *= fast_exp2(m4->neg_atten_log2[2] * len);
+        f3 out;
+        if constexpr (std::is_same<MatP, cdmat*>::value) {
+            // the material's composite constants with transmission_factor folded in (tr_dmat::kd ...)
+            // (the opaque pass, `fragment`, knows no transmission: plain c_diff)
+            const TR_CONSTANT float* kd = TRANSMISSIVE ? m4->kd : m4->c_diff;
+            out = {fmaf(kd[0], acc.d.x, acc.s.x), fmaf(kd[1], acc.d.y, acc.s.y), fmaf(kd[2], acc.d.z, acc.s.z)};
+            if (transmits) {
+                // ---- ibl_volume_refraction, part 2 (:337-353)
+                f3 T = pyramid_resolve(pf);
+                if (m4->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
+                    T.x *= fast_exp2(m4->neg_atten_log2[0] * len);
+                    T.y *= fast_exp2(m4->neg_atten_log2[1] * len);
+                    T.z *= fast_exp2(m4->neg_atten_log2[2] * len);
+                }
+                const v2f AB = lut_line_resolve(lf);
+                const float w = fmaf(-m4->f90, AB.y, 1.0f);      // 1 - (f0 A + f90 B), channel by channel
+                out.x = fmaf(m4->kta[0], acc.ta.x, out.x);
+                out.y = fmaf(m4->kta[1], acc.ta.y, out.y);
+                out.z = fmaf(m4->kta[2], acc.ta.z, out.z);
+                out.x = fmaf(-m4->ktb[0], acc.tb.x, out.x);
+                out.y = fmaf(-m4->ktb[1], acc.tb.y, out.y);
+                out.z = fmaf(-m4->ktb[2], acc.tb.z, out.z);
+                out.x = fmaf(m4->kt[0], fmaf(-m4->f0[0], AB.x, w) * T.x, out.x);
+                out.y = fmaf(m4->kt[1], fmaf(-m4->f0[1], AB.x, w) * T.y, out.y);
+                out.z = fmaf(m4->kt[2], fmaf(-m4->f0[2], AB.x, w) * T.z, out.z);
             }
-            v2f AB;
-            if constexpr (SCALAR_MATERIAL) AB = lut_line_resolve(lf);
-            else AB = lut_resolve(lf, lf.fy);
-            // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
-            const float fb = m4->f90 * AB.y;
-            const float bx = fmaf(-mat_bt_b(m4, 0), acc.tb.x, mat_bt_a(m4, 0) * acc.ta.x);   // sum over lights of transmission_btdf
-            const float by = fmaf(-mat_bt_b(m4, 1), acc.tb.y, mat_bt_a(m4, 1) * acc.ta.y);
-            const float bz = fmaf(-mat_bt_b(m4, 2), acc.tb.z, mat_bt_a(m4, 2) * acc.ta.z);
-            float tx = fmaf(1.0f - fmaf(m4->f0[0], AB.x, fb), T.x, bx) * mat_diffuse(mo, 0);
-            float ty = fmaf(1.0f - fmaf(m4->f0[1], AB.x, fb), T.y, by) * mat_diffuse(mo, 1);
-            float tz = fmaf(1.0f - fmaf(m4->f0[2], AB.x, fb), T.z, bz) * mat_diffuse(mo, 2);
-            // lib.rs:157-159: real = tf * transmission; diffuse = lerp(diffuse, real, tf)
-            float tf = m4->transmission_factor;
-            diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
-            diffuse.y = fmaf(fmaf(tf, ty, -diffuse.y), tf, diffuse.y);
-            diffuse.z = fmaf(fmaf(tf, tz, -diffuse.z), tf, diffuse.z);
+            out = {out.x + m4->emission[0], out.y + m4->emission[1], out.z + m4->emission[2]};
+        } else {
+            f3 diffuse = {acc.d.x * mat_c_diff(mo, 0), acc.d.y * mat_c_diff(mo, 1), acc.d.z * mat_c_diff(mo, 2)};
+            if (transmits) {
+                // ---- ibl_volume_refraction, part 2 (:337-353)
+                f3 T = pyramid_resolve(pf);
+                if (m4->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
+                    T.x *= fast_exp2(m4->neg_atten_log2[0] * len);
+                    T.y *= fast_exp2(m4->neg_atten_log2[1] * len);
+                    T.z *= fast_exp2(m4->neg_atten_log2[2] * len);
+                }
+                v2f AB;
+                if constexpr (SCALAR_MATERIAL) AB = lut_line_resolve(lf);
+                else AB = lut_resolve(lf, lf.fy);
+                // (1 - (f0*A + f90*B)) * attenuated * base_colour, summed with the btdf lobes
+                const float fb = m4->f90 * AB.y;
+                const float bx = fmaf(-mat_bt_b(m4, 0), acc.tb.x, mat_bt_a(m4, 0) * acc.ta.x);   // sum over lights of transmission_btdf
+                const float by = fmaf(-mat_bt_b(m4, 1), acc.tb.y, mat_bt_a(m4, 1) * acc.ta.y);
+                const float bz = fmaf(-mat_bt_b(m4, 2), acc.tb.z, mat_bt_a(m4, 2) * acc.ta.z);
+                float tx = fmaf(1.0f - fmaf(m4->f0[0], AB.x, fb), T.x, bx) * mat_diffuse(mo, 0);
+                float ty = fmaf(1.0f - fmaf(m4->f0[1], AB.x, fb), T.y, by) * mat_diffuse(mo, 1);
+                float tz = fmaf(1.0f - fmaf(m4->f0[2], AB.x, fb), T.z, bz) * mat_diffuse(mo, 2);
+                // lib.rs:157-159: real = tf * transmission; diffuse = lerp(diffuse, real, tf)
+                float tf = m4->transmission_factor;
+                diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
+                diffuse.y = fmaf(fmaf(tf, ty, -diffuse.y), tf, diffuse.y);
+                diffuse.z = fmaf(fmaf(tf, tz, -diffuse.z), tf, diffuse.z);
+            }
+            out = {diffuse.x + acc.s.x + m4->emission[0], diffuse.y + acc.s.y + m4->emission[1],
+                   diffuse.z + acc.s.z + m4->emission[2]};
         }
-
-        f3 out = {diffuse.x + acc.s.x + m4->emission[0], diffuse.y + acc.s.y + m4->emission[1],
-                  diffuse.z + acc.s.z + m4->emission[2]};
         if constexpr (!TRANSMISSIVE) {
             if (L4->fp.debug_clusters != 0u) {  // lib.rs:241-245
-                f3 a = debug_colour_for_id(cl.uniform ? uniform_lights : num_lights), b = debug_colour_for_id(cl.cluster);
+                f3 a = debug_colour_for_id(lights_walked), b = debug_colour_for_id(cl.cluster);
                 out = {fmaf(b.x - 0.5f, 0.025f, a.x), fmaf(b.y - 0.5f, 0.025f, a.y), fmaf(b.z - 0.5f, 0.025f, a.z)};
             }
         }
@@ -975,10 +1050,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, float4 pd, float4 
         return finish();
     };
     lights_phase();   // the sun
-    // (Instantiating the rest of the pixel behind each list walk, to save the ~10 register copies where the two walks
-    //  join, was tried: the scheduler then keeps 84 registers live — a lost wave costs more than the copies.)
-    if (cl.uniform) punctual_uniform();
-    else punctual_per_lane();
+    punctual();
     return tail();
 }
 
@@ -1001,15 +1073,14 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
                                                    float* lds_park TR_TIMER_PARAM) {
     L = launder(L);
     dm = launder(dm);
-    // TR_PARK_LDS: what the sampling front end does not read — the position, the pixel's cluster list — and what it
+    // What the sampling front end does not read — the position, the pixel's cluster list — and what it
     // produces slot by slot wait in the wave's LDS (one float per lane and value) instead of in registers: the front
     // end's own state (quad differences, sampling geometry, eight taps, filter temporaries) is the kernel's peak.
     float* const park = lds_park + lane;
-    auto put = [&](uint32_t f, float v) { if (TR_PARK_LDS) park[f * 64u] = v; };
-    auto get = [&](uint32_t f, float v) { return TR_PARK_LDS ? park[f * 64u] : v; };
+    auto put = [&](uint32_t f, float v) { park[f * 64u] = v; };
+    auto get = [&](uint32_t f) { return park[f * 64u]; };
     put(0, pd.x); put(1, pd.y); put(2, pd.z); put(3, pd.w);
-    put(4, __uint_as_float(cl_in.cluster)); put(5, __uint_as_float(cl_in.num_lights)); put(6, __uint_as_float(cl_in.list_offset));
-    put(7, __uint_as_float(cl_in.l0)); put(8, __uint_as_float(cl_in.l1));
+    put(4, __uint_as_float(cl_in.cluster)); put(5, __uint_as_float(cl_in.key));
     asm volatile("" ::: "memory");
     const TR_CONSTANT tr_material_info* mi = as_constant(L->materials) + material;
     cdtex* tex = as_constant(L->textures);
@@ -1063,7 +1134,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(dr), "+v"(dg), "+v"(db));
         slot_done();
     }
-    put(9, dr); put(10, dg); put(11, db);
+    put(6, dr); put(7, dg); put(8, db);
     slot_done();
     // get_material_params (lighting.rs:261-301)
     float metallic = mi->metallic_factor, rough = mi->roughness_factor;
@@ -1072,7 +1143,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(metallic), "+v"(rough));
         slot_done();
     }
-    put(12, metallic); put(13, rough);
+    put(9, metallic); put(10, rough);
     slot_done();
     float scx = mi->specular_colour_factor[0], scy = mi->specular_colour_factor[1], scz = mi->specular_colour_factor[2];
     if (id_spec_colour != -1) {
@@ -1080,7 +1151,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(scx), "+v"(scy), "+v"(scz));
         slot_done();
     }
-    put(14, scx); put(15, scy); put(16, scz);
+    put(11, scx); put(12, scy); put(13, scz);
     slot_done();
     float specular_factor = mi->specular_factor;
     if (id_specular != -1) {
@@ -1088,7 +1159,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(specular_factor));
         slot_done();
     }
-    put(17, specular_factor);
+    put(14, specular_factor);
     slot_done();
     // get_emission (lighting.rs:303-313)
     lm.emission[0] = mi->emissive_factor[0];
@@ -1099,7 +1170,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(lm.emission[0]), "+v"(lm.emission[1]), "+v"(lm.emission[2]));
         slot_done();
     }
-    put(18, lm.emission[0]); put(19, lm.emission[1]); put(20, lm.emission[2]);
+    put(15, lm.emission[0]); put(16, lm.emission[1]); put(17, lm.emission[2]);
     slot_done();
     lm.transmission_factor = mi->transmission_factor;               // lib.rs:71-77
     if (id_transmission != -1) {
@@ -1107,7 +1178,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(lm.transmission_factor));
         slot_done();
     }
-    put(21, lm.transmission_factor);
+    put(18, lm.transmission_factor);
     slot_done();
     lm.thickness = mi->thickness_factor;                            // lib.rs:120-124
     if (id_thickness != -1) {
@@ -1115,7 +1186,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(lm.thickness));
         slot_done();
     }
-    put(22, lm.thickness);
+    put(19, lm.thickness);
     slot_done();
     lm.eta = dm->eta;
     lm.neg_atten_log2[0] = dm->neg_atten_log2[0];
@@ -1151,26 +1222,23 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     // The per-lane record is digested only now, when every slot has been sampled and the sampling geometry, the quad
     // differences and the taps are dead: the digest's twenty values and the sampling state are never live together.
     slot_done();
-    dr = get(9, dr); dg = get(10, dg); db = get(11, db);
-    metallic = get(12, metallic); rough = get(13, rough);
-    scx = get(14, scx); scy = get(15, scy); scz = get(16, scz);
-    specular_factor = get(17, specular_factor);
-    lm.emission[0] = get(18, lm.emission[0]); lm.emission[1] = get(19, lm.emission[1]); lm.emission[2] = get(20, lm.emission[2]);
-    lm.transmission_factor = get(21, lm.transmission_factor);
-    lm.thickness = get(22, lm.thickness);
+    dr = get(6); dg = get(7); db = get(8);
+    metallic = get(9); rough = get(10);
+    scx = get(11); scy = get(12); scz = get(13);
+    specular_factor = get(14);
+    lm.emission[0] = get(15); lm.emission[1] = get(16); lm.emission[2] = get(17);
+    lm.transmission_factor = get(18);
+    lm.thickness = get(19);
     lm.flags = (dm->flags & 1u) | (lm.transmission_factor != 0.0f ? 2u : 0u);
     digest_factors<false>(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
                           L->fp.lut_height, L->fp.lut_stride);
     lm.metallic = metallic;
     lm.rough = rough;
-    const float4 pd2 = float4{get(0, pd.x), get(1, pd.y), get(2, pd.z), get(3, pd.w)};
+    const float4 pd2 = float4{get(0), get(1), get(2), get(3)};
     cluster_list cl = cl_in;   // (the scalar members stay what they are)
-    cl.cluster = __float_as_uint(get(4, __uint_as_float(cl_in.cluster)));
-    cl.num_lights = __float_as_uint(get(5, __uint_as_float(cl_in.num_lights)));
-    cl.list_offset = __float_as_uint(get(6, __uint_as_float(cl_in.list_offset)));
-    cl.l0 = __float_as_uint(get(7, __uint_as_float(cl_in.l0)));
-    cl.l1 = __float_as_uint(get(8, __uint_as_float(cl_in.l1)));
-    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, pd2, ns, lane, cl TR_TIMER_ARG);
+    cl.cluster = __float_as_uint(get(4));
+    cl.key = __float_as_uint(get(5));
+    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, material, pd2, ns, lane, cl TR_TIMER_ARG);
 }
 
 // ------------------------------------------------------------------------ one pixel of a "lite" textured material
@@ -1189,7 +1257,7 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
     const bool srgb = t->srgb != 0u;
     lite_dmat lm;
     lm.m = dm;
-    if (TR_LITE_ONE_LEVEL && ballot(g.frac != 0.0f) == 0ull) {   // (uniform) every pixel of the wave exactly on its lower level
+    if (ballot(g.frac != 0.0f) == 0ull) {   // (uniform) every pixel of the wave exactly on its lower level
         texture_issue_shared<1>(taps, L->tex_arena, t, g);
         lm.diffuse[0] = mi->diffuse_factor[0] * texture_resolve_shared<0, 1>(taps, g, srgb, lds_srgb);
         lm.diffuse[1] = mi->diffuse_factor[1] * texture_resolve_shared<1, 1>(taps, g, srgb, lds_srgb);
@@ -1203,12 +1271,12 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
     // The colour is first USED at the end of the pixel; left to itself the optimiser sinks the whole filter down there
     // and keeps the eight taps, their weights and the decode look-ups alive across the light loop (+40 registers).
     asm volatile("" : "+v"(lm.diffuse[0]), "+v"(lm.diffuse[1]), "+v"(lm.diffuse[2]));
-    return shade_pixel<TRANSMISSIVE, const lite_dmat*>(L, &lm, pd, ns, lane, cl TR_TIMER_ARG);
+    return shade_pixel<TRANSMISSIVE, const lite_dmat*>(L, &lm, material, pd, ns, lane, cl TR_TIMER_ARG);
 }
 
 // ------------------------------------------------------------------------ the shading kernel
-// Grid: 8 * k workgroups, k per XCD (hardware workgroup b runs on XCD b % 8), of one wave each (TR_WAVE_BLOCKS),
-// kGridRounds times what is resident.  The 64x4-pixel block tiles of the rect are cut into 8
+// Grid: 8 * k workgroups, k per XCD (hardware workgroup b runs on XCD b % 8), of one wave each, kGridRounds times what
+// is resident.  The 64x4-pixel block tiles of the rect are cut into 8
 // contiguous bands, one per XCD; the wave in slot w of its XCD takes the 16x4 quarters w, w + W, ... of the band, so an
 // XCD sweeps its band front to back and its L2 serves a compact window of the screen (and of the opaque pyramid behind
 // it).  A wave is a 16x4 pixel tile — few waves straddle a material or cluster border, every plane row segment is
@@ -1218,37 +1286,9 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
 // forms the quad differences with two lane swizzles (the 16x4 wave tile holds whole 2x2 quads: partner lanes are
 // lane^1 and lane^16; the host guarantees an even rect origin) before the wave splits by material, and sends
 // materials flagged as textured through shade_pixel_textured.  The sRGB decode table sits in LDS.
-constexpr uint32_t kTileCounterStride = 64u;   // words: every counter in a cache line (and L2 channel) of its own
-#ifndef TR_SUB_COUNTERS
-#define TR_SUB_COUNTERS 16
-#endif
-constexpr uint32_t kSubCounters = TR_SUB_COUNTERS;         // tile counters per XCD: same-address atomics complete 11-14 ns apart
-                                               // (tools/ubench/scalar_atomic.hip), a 4K band has 16 200 tiles
-constexpr uint32_t kDoneGroups = 16u;
-constexpr uint32_t kXcdCounterWords = (kSubCounters + kDoneGroups + 1u) * kTileCounterStride;
-constexpr uint32_t kTileCounterWords = 8u * kXcdCounterWords;
-#ifndef TR_COUNTER_SCOPE
-#define TR_COUNTER_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
-#endif
-#ifndef TR_DYNAMIC_TILES
-#define TR_DYNAMIC_TILES 0
-#endif
-#ifndef TR_LOAD_BEFORE_STORE
-#define TR_LOAD_BEFORE_STORE 0
-#endif
-#ifndef TR_WAVE_BLOCKS
-#define TR_WAVE_BLOCKS 1
-#endif
-// Wave tile shape: 16x4 pixels (block tile 64x4), or TR_TILE_8X8: 8x8 (block tile 32x8)
-#ifndef TR_TILE_8X8
-#define TR_TILE_8X8 0
-#endif
-constexpr uint32_t kWaveTileW = TR_TILE_8X8 ? 8u : 16u, kWaveTileH = TR_TILE_8X8 ? 8u : 4u;
-constexpr uint32_t kBlockTileW = 4u * kWaveTileW, kBlockTileH = kWaveTileH;
-#ifndef TR_NT_STORE
-#define TR_NT_STORE 1
-#endif
-constexpr uint32_t kGridRounds = TR_DYNAMIC_TILES ? 1u : 8u;   // blocks in the grid per resident block
+constexpr uint32_t kWaveTileW = 16u, kWaveTileH = 4u;                       // wave tile: 16x4 pixels
+constexpr uint32_t kBlockTileW = 4u * kWaveTileW, kBlockTileH = kWaveTileH;   // block tile: four of them side by side
+constexpr uint32_t kGridRounds = 8u;   // waves in the grid per resident wave
 struct tile_regs {
     float4 pd, ns;
     float2 uv;                                        // TEXTURED only
@@ -1257,12 +1297,11 @@ struct tile_regs {
     uint32_t cover_front;                             // (scalar) VIS opaque: the transmissive layer's word of the tile
 };
 
-// Experiments only: an occupancy target for the register allocator, e.g. -DTR_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(TEXTURED ? 5 : 8)))'
-#ifndef TR_WAVES_ATTR
 // The untextured transmissive variant fed from visibility words (67 registers left to itself) fits 64 without a spill
 // once the allocator is told that eight waves are wanted; every other variant is left to itself (forced up, the RGBA32F
 // variant and the textured classes spill, and scratch costs more than the waves give: DESIGN.md 3.1;
 // tests/test_kernel_resources.py holds the line).
+#ifndef TR_WAVES_ATTR
 #define TR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((TEX == kTexNone && TRANSMISSIVE && VIS) ? 8 : 1)))
 #endif
 // TEX: which material classes the launch shades (the host launches what the uploaded materials need, see tr_shade.hip):
@@ -1281,18 +1320,17 @@ constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2;
 // the resolve and 44 read back here).  The launch that shades a pixel — or, in a tile listed for the TEX = 2 launch, that
 // launch for every pixel, so that its quad partners of the other class are still there — zeroes the word for the next frame.
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, int TEX = kTexNone, bool VIS = false>
-__global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
+__global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
     constexpr bool TEXTURED = TEX != kTexNone;
-    const uint32_t block_waves = blockDim.x >> 6;   // 4, or 1 (TR_WAVE_BLOCKS: one wave per workgroup)
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
     __shared__ float lds_srgb[TEXTURED ? 256 : 1];
-    __shared__ float lds_park[(TEX == kTexFull && TR_PARK_LDS) ? (TR_WAVE_BLOCKS ? 1u : 4u) * kParkedValues * 64u : 64u];
+    __shared__ float lds_park[TEX == kTexFull ? kParkedValues * 64u : 64u];
+    const uint32_t lane = threadIdx.x;   // one wave per workgroup
     if constexpr (TEXTURED) {
-        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) lds_srgb[i] = L->srgb_to_linear[i];
+        for (uint32_t i = lane; i < 256u; i += 64u) lds_srgb[i] = L->srgb_to_linear[i];
         __syncthreads();
     }
-    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lx = lane & (kWaveTileW - 1u), ly = lane / kWaveTileW;   // position inside the wave's tile
 
     // One contiguous band of the rect's block tiles (row-major) per XCD.  Dealing the tiles to the XCDs in k smaller
@@ -1310,7 +1348,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     // VIS launches (real frames, where whole screen regions are empty or cheap): the XCDs are dealt STRIPES of
     // kStripeTileRows tile rows in turn instead of one contiguous band each, so that every XCD gets its share of the
     // covered part of the screen (a frame whose upper half is sky left half of the XCDs idle).
-    const bool striped = (VIS || TEX != kTexNone) && TR_VIS_STRIPES && !listed;
+    const bool striped = (VIS || TEX != kTexNone) && !listed;
     uint32_t stripes_own = 0u, striped_len = 0u;
     if (striped) {
         const uint32_t st = L->fp.stripe_tiles;
@@ -1351,7 +1389,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         // (scalar) the coverage word of the block tile, when the frame recorder rasterised the layer itself: 0 = nothing
         // landed there; bit 1 / bit 2 = fragments of a full-class material / of any other (raster_resolve_body): a
         // launch skips the tiles that hold nothing of the classes it shades without touching their planes
-        const uint32_t cover = (!TR_TILE_8X8 && F->tile_cover) ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
+        const uint32_t cover = F->tile_cover ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
         t.cover = cover;
         if constexpr (VIS && !TRANSMISSIVE) t.cover_front = F->cover_front ? as_constant(F->cover_front)[tile] : 0u;
         if constexpr (TEX == kTexLite) {
@@ -1432,72 +1470,17 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
     const unsigned long long t_loop = tr_now();
     const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
 #endif
-    // Which tile next.  Default: static — the wave in slot w of its XCD takes the 16x4 tiles w, w + W, w + 2W, ... of the
-    // band (W = waves of the XCD in the grid; the four waves of a block cover one 64x4 block tile side by side, so
-    // their plane rows are 1 KB contiguous and their stores 512 B).  TR_DYNAMIC_TILES=1: tiles are handed out from
-    // per-XCD counters when a wave is free — kSubCounters of them, because same-address atomics complete 11-14 ns
-    // apart (tools/ubench/scalar_atomic.hip) and a 4K band has 16 200 tiles; counter s hands out the tiles s, s + 64,
-    // ...; a wave starts on the counter of its slot and moves on when that is exhausted; the last wave of the XCD to
-    // finish re-arms the counters.  It balances the waves (static: the longest-lived wave of the 4K frame runs 36 %
-    // longer than the mean) but measured slower (135 vs 100 us): a tile then takes 16.6k instead of 11.7k cycles,
-    // the waves of a block no longer touching neighbouring memory at the same time.
+    // Which tile next: static — the wave in slot w of its XCD takes the 16x4 tiles w, w + W, w + 2W, ... of the band
+    // (W = waves of the XCD in the grid; four neighbouring waves cover one 64x4 block tile side by side, so their plane
+    // rows are 1 KB contiguous and their stores 512 B).  Handing tiles out dynamically balances the waves (static: the
+    // longest-lived wave of the 4K frame runs 36 % longer than the mean) but measured slower.
     const uint32_t wave_tiles = band_len * 4u;
-    const uint32_t slot = listed ? __builtin_amdgcn_readfirstlane(blockIdx.x * block_waves + (threadIdx.x >> 6))
-                                 : __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * block_waves + (threadIdx.x >> 6));
-#if TR_DYNAMIC_TILES
-    // mode 1: every wave takes 16x4 tiles on its own; mode 2: the block's first wave takes a 64x4 block tile for the four
-    // waves (shared through LDS behind the block's barrier), which keeps them on neighbouring memory at the same time
-    constexpr bool kBlockUnits = TR_DYNAMIC_TILES == 2;
-    __shared__ uint32_t shared_unit[2];
-    uint32_t parity = 0u;
-    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t units = kBlockUnits ? band_len : wave_tiles;
-    const bool grabber = !kBlockUnits || wave_in_block == 0u;
-    uint32_t* const counters = L->tile_counters + xcd * kXcdCounterWords;
-    uint32_t sub = (kBlockUnits ? (blockIdx.x >> 3) : slot) & (kSubCounters - 1u);
-    uint32_t moves = 0u;   // counters found exhausted so far (they stay exhausted)
-    auto grab = [&]() -> uint32_t {
-        uint32_t v = 0u;
-        if (lane == 0u)
-            v = __hip_atomic_fetch_add(counters + sub * kTileCounterStride, 1u, __ATOMIC_RELAXED, TR_COUNTER_SCOPE);
-        return v;   // (lane 0)
-    };
-    // the unit of a counter value, or, once every counter is exhausted, a value >= units
-    auto resolve = [&](uint32_t request) -> uint32_t {
-        uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane(request) * kSubCounters + sub;
-        while (u >= units && ++moves < kSubCounters) {
-            sub = (sub + 1u) & (kSubCounters - 1u);
-            u = (uint32_t)__builtin_amdgcn_readfirstlane(grab()) * kSubCounters + sub;
-        }
-        return u;
-    };
-    auto share = [&](uint32_t u) -> uint32_t {
-        if constexpr (kBlockUnits) {
-            if (grabber && lane == 0u) shared_unit[parity] = u;
-            __syncthreads();   // (two slots: the next write of this one is behind the next barrier)
-            u = __builtin_amdgcn_readfirstlane(shared_unit[parity]);
-            parity ^= 1u;
-        }
-        return u;
-    };
-    auto tile_of = [&](uint32_t u) -> uint32_t { return u >= units ? 0xFFFFFFFFu : (kBlockUnits ? u * 4u + wave_in_block : u); };
-    uint32_t j = tile_of(share(grabber ? resolve(grab()) : 0u));
-#else
+    const uint32_t slot = listed ? blockIdx.x : (blockIdx.x >> 3);
     uint32_t j = slot;
-#endif
     tile_regs cur;
-#if TR_LOAD_BEFORE_STORE
-    if (j < wave_tiles) fetch(j, cur);
-#endif
     while (j < wave_tiles) {
         tile_phase<0>();
-#if !TR_LOAD_BEFORE_STORE
         fetch(j, cur);
-#endif
-#if TR_DYNAMIC_TILES
-        uint32_t request = 0u;
-        if (grabber) request = grab();   // (travels with the tile's plane loads)
-#endif
 #if TR_TIMING
         const unsigned long long t_fetch = tr_now();
         tr_drain();
@@ -1512,9 +1495,6 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         f3 out = {0.f, 0.f, 0.f};  // clear colour of the opaque pass (src/main.rs:1592-1601)
         uint64_t todo = ballot(key != TR_NOT_COVERED);
         uint64_t shaded = 0ull;   // TEX != 0: the lanes whose material class this launch shades
-#if TR_DYNAMIC_TILES
-        request = __builtin_amdgcn_readfirstlane(request);   // (older than the plane loads: it is here) into a scalar register
-#endif
         cdmat* dmats = as_constant(S->dmats);
         if (TR_ABLATE(S, 32u)) {  // profiling only: pure streaming skeleton
             todo = 0;
@@ -1524,7 +1504,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
 #if TR_TIMING
             const unsigned long long t_cluster = tr_now();
 #endif
-            const cluster_list cl = cluster_lookup(S, cur.pd.w, cur.cluster_x + cur.cluster_y_term);
+            const cluster_list cl = cluster_lookup(S, cur.pd.w, cur.cluster_x + cur.cluster_y_term, key != TR_NOT_COVERED);
 #if TR_TIMING
             tr_drain();
             timer.wait[1] += tr_now() - t_cluster;
@@ -1536,11 +1516,11 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
                 // clamped to the frame edge read the same pixel as their partner: zero as well)
                 const bool covered = cur.mat != TR_NOT_COVERED;
                 auto swz_x = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x041F)); };  // lane ^ 1
-                auto swz_y = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), TR_TILE_8X8 ? 0x201F : 0x401F)); };  // lane ^ 16 (^ 8): the pixel below / above
+                auto swz_y = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); };  // lane ^ 16: the pixel below / above
                 // (every swizzle is evaluated by the whole wave, outside any condition: a lane-crossing read under a
                 // short-circuit would run with the uncovered lanes switched off and read zeros from them)
                 const int mat_x = __builtin_amdgcn_ds_swizzle((int)cur.mat, 0x041F);
-                const int mat_y = __builtin_amdgcn_ds_swizzle((int)cur.mat, TR_TILE_8X8 ? 0x201F : 0x401F);
+                const int mat_y = __builtin_amdgcn_ds_swizzle((int)cur.mat, 0x401F);
                 const bool cov_x = covered & (mat_x != (int)TR_NOT_COVERED), cov_y = covered & (mat_y != (int)TR_NOT_COVERED);
                 const float sgn_x = (lane & 1u) ? -1.0f : 1.0f, sgn_y = (lane & kWaveTileW) ? -1.0f : 1.0f;
                 const float nvx = -(S->fp.view_position[0] - cur.pd.x), nvy = -(S->fp.view_position[1] - cur.pd.y),
@@ -1567,14 +1547,14 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
                 if (key == mk) {
                     if constexpr (TEX == kTexFull) {
                         out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb,
-                                                                 lds_park + (threadIdx.x >> 6) * kParkedValues * 64u TR_TIMER_ARG);
+                                                                 lds_park TR_TIMER_ARG);
                     } else if constexpr (TEX == kTexLite) {
                         if (dmats[m0].flags & 8u)
                             out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane, cl, lds_srgb TR_TIMER_ARG);
                         else
-                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
+                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
                     } else {
-                        out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
+                        out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
                     }
                 }
             }
@@ -1582,20 +1562,13 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
         // The next tile's plane loads are issued BEFORE this tile's store: memory operations complete in order, so a
         // load behind the store could not be waited for without waiting for the store's acknowledgement as well.
         const uint32_t out_px = cur.px, out_py = cur.py;
-#if TR_DYNAMIC_TILES
-        j = tile_of(share(grabber ? resolve(request) : 0u));
-#else
-        j += (listed ? gridDim.x : (gridDim.x >> 3)) * block_waves;
-#endif
-#if TR_LOAD_BEFORE_STORE
-        if (j < wave_tiles) fetch(j, cur);
-#endif
+        j += listed ? gridDim.x : (gridDim.x >> 3);
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         // (with textured materials uploaded: a launch writes the pixels of the classes it shades; the TEX = 1 launch
         //  also writes the opaque pass's clear colour)
         bool write = TRANSMISSIVE ? active : inside;
         if constexpr (TEXTURED) {
-            const bool mine = ((shaded >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+            const bool mine = ((shaded >> lane) & 1ull) != 0ull;
             const bool clears = TEX == kTexLite || S->fp.solo_full != 0u;   // (the launch that writes the opaque pass's clear colour)
             write = TRANSMISSIVE ? mine : (clears ? (inside && (mine || cur_mat_uncovered)) : mine);
         }
@@ -1608,7 +1581,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
                 // (scalar) a transmissive fragment landed in this tile: a pixel this launch shades knows its opaque depth —
                 // the transmissive winner stays only if it is nearer (depth GREATER, reversed Z)
                 bool owner = active;
-                if constexpr (TEXTURED) owner = ((shaded >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+                if constexpr (TEXTURED) owner = ((shaded >> lane) & 1ull) != 0ull;
                 if (cur.cover_front != 0u && owner) {
                     claunch* V = launder(L);
                     const uint32_t at = mad24(out_py, V->fp.width, out_px) * 8u;
@@ -1623,7 +1596,7 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
             const uint32_t pix = mad24(out_py, W->fp.width, out_px);
             if constexpr (sizeof(OutT) == 8) {
                 const uint2 o = pack_rgba16f(out.x, out.y, out.z, 1.0f);
-                if constexpr (TRANSMISSIVE && TR_NT_STORE) {   // the last writer of the frame: streamed out past L2 (the opaque pass's
+                if constexpr (TRANSMISSIVE) {   // the last writer of the frame: streamed out past L2 (the opaque pass's
                     typedef uint32_t u2v __attribute__((ext_vector_type(2)));   // targets are re-read at once: cached)
                     __builtin_nontemporal_store(u2v{o.x, o.y}, reinterpret_cast<u2v*>(static_cast<char*>(W->hdr) + pix * 8u));
                 } else {
@@ -1638,28 +1611,6 @@ __global__ __launch_bounds__(TR_WAVE_BLOCKS ? 64 : 256) TR_WAVES_ATTR void shade
             }
         }
     }
-#if TR_DYNAMIC_TILES
-    // Re-arming the counters for the next launch: the last participant (block, or wave in mode 1) of the XCD to leave
-    // its loop zeroes them.  "Last" is found in two levels — 16 groups, then one count of finished groups — because
-    // everybody finishes at the same moment and same-address atomics complete 12 ns apart.
-    if constexpr (kBlockUnits) __syncthreads();
-    if (grabber && lane == 0u) {
-        const uint32_t participants = kBlockUnits ? (gridDim.x >> 3) : (gridDim.x >> 3) * block_waves;
-        const uint32_t me = kBlockUnits ? (blockIdx.x >> 3) : slot;
-        const uint32_t group = me & (kDoneGroups - 1u);
-        const uint32_t group_size = (participants - group + kDoneGroups - 1u) / kDoneGroups;
-        uint32_t* const done = counters + kSubCounters * kTileCounterStride;
-        if (__hip_atomic_fetch_add(done + group * kTileCounterStride, 1u, __ATOMIC_RELAXED, TR_COUNTER_SCOPE) == group_size - 1u) {
-            const uint32_t groups = participants < kDoneGroups ? participants : kDoneGroups;
-            uint32_t* const top = done + kDoneGroups * kTileCounterStride;
-            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, TR_COUNTER_SCOPE) == groups - 1u) {
-                // every other participant of this XCD has left its loop: nobody reads the counters again in this launch
-                for (uint32_t s = 0; s < kSubCounters + kDoneGroups + 1u; ++s)
-                    __hip_atomic_store(counters + s * kTileCounterStride, 0u, __ATOMIC_RELAXED, TR_COUNTER_SCOPE);
-            }
-        }
-    }
-#endif
 #if TR_TIMING
     if (lane == 0) {
         atomicAdd(&tr_timing_counters[0][blockIdx.x & 1023u], timer.wait[0]);
@@ -1705,6 +1656,37 @@ __global__ __launch_bounds__(256) void depth_slice_kernel(const float* __restric
     if (i < count) out[i] = z;
 }
 
+// ------------------------------------------------------------------------ tap records
+// One thread per material: tr_dtap from the digested material, the pyramid's level table and log2(framebuffer width) —
+// the operations shade_pixel used to run per tile (contraction off), so the level pair and the weight are what they were.
+__global__ void digest_taps_kernel(const tr_dmat* __restrict__ dmats, const tr_level_table* __restrict__ lv, uint32_t levels,
+                                   float log2_fb_width, tr_dtap* __restrict__ out, uint32_t count) {
+#pragma clang fp contract(off)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float lod = log2_fb_width * dmats[i].rough_ior;               // glam-pbr/src/lib.rs:334-335
+    const float l = fminf(fmaxf(lod, 0.0f), (float)(levels - 1u));      // sampler: lod in [0, levels - 1], NaN -> 0
+    const float lf = floorf(l);
+    tr_dtap d;
+    d.t = l - lf;
+    const uint32_t pair[2] = {(uint32_t)lf, min((uint32_t)lf + 1u, levels - 1u)};
+    d.narrow = 0u;
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t w = lv->width[pair[k]], h = lv->height[pair[k]];
+        d.offset[k] = lv->offset[pair[k]] * 8u;
+        d.pitch[k] = h >= 2u ? w * 8u : 0u;
+        d.width[k] = w;
+        d.wf[k] = (float)w;
+        d.hf[k] = (float)h;
+        d.xhi[k] = (float)(w - 1u);
+        d.yhi[k] = (float)(h - 1u);
+        d.xlim[k] = w >= 2u ? (float)(w - 2u) : 0.0f;
+        d.ylim[k] = h >= 2u ? (float)(h - 2u) : 0.0f;
+        if (w < 2u) d.narrow |= 1u << k;
+    }
+    out[i] = d;
+}
+
 // ------------------------------------------------------------------------ material digestion
 // One thread per material; runs once per tr_upload_materials.  Same fp32 operations as the
 // reference where a value is a pure function of MaterialInfo (glam-pbr/src/lib.rs:141-161,
@@ -1725,6 +1707,7 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
                    mi.diffuse_factor[0], mi.diffuse_factor[1], mi.diffuse_factor[2], lut_height, lut_stride);
     for (int k = 0; k < 3; ++k) d.emission[k] = mi.emissive_factor[k];
     d.eta = 1.0f / ior;
+    d.neg_eta2 = -(d.eta * d.eta);
     d.transmission_factor = mi.transmission_factor;
     d.thickness = mi.thickness_factor;
     const bool has_atten = !(mi.attenuation_distance == __builtin_inff());
@@ -1741,7 +1724,15 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
         d.neg_atten_log2[k] = has_atten ? (-coeff) * kLog2e : 0.0f;
     }
     d.lut_line = i * lut_stride;
-    for (int k = 0; k < 2; ++k) d._pad[k] = 0u;
+    d._pad = 0u;
+    d._pad1 = d._pad2 = d._pad3 = d._pad4 = 0.0f;
+    const float tf = mi.transmission_factor, tf2 = tf * tf;
+    for (int k = 0; k < 3; ++k) {
+        d.kd[k] = d.c_diff[k] * (1.0f - tf);
+        d.kt[k] = tf2 * d.diffuse[k];
+        d.kta[k] = d.kt[k] * d.bt_a[k];
+        d.ktb[k] = d.kt[k] * d.bt_b[k];
+    }
     out[i] = d;
 }
 

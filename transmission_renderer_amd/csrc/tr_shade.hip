@@ -53,6 +53,9 @@ struct tr_context {
     // materials
     tr_material_info* d_materials_raw = nullptr;
     tr_dmat* d_dmats = nullptr;
+    tr_dtap* d_dtaps = nullptr;     // per material: the refraction tap's level pair (digest_taps_kernel), valid for ...
+    bool dtaps_valid = false;       // ... these digested materials, the level table in d_levels and this framebuffer width
+    float dtaps_log2_width = 0.0f;
     uint32_t num_materials = 0, cap_materials = 0;
     bool dmats_dirty = false;
     std::vector<tr_material_info> stage_materials;
@@ -132,7 +135,6 @@ struct tr_context {
 
     // pyramid level table
     tr_level_table* d_levels = nullptr;
-    uint32_t* d_tile_counters = nullptr;   // shade_kernel's per-XCD tile counters (kTileCounterWords, zero between launches)
     tr_level_table h_levels{};
     uint32_t h_levels_count = 0;
 
@@ -193,6 +195,7 @@ tr_status ensure_digested(tr_context* ctx, hipStream_t stream) {
                        (const uint32_t*)ctx->d_lut_pairs, (const tr_dmat*)ctx->d_dmats, ctx->d_lut_lines, ctx->lut_stride, n);
     TR_HIP(ctx, hipGetLastError());
     ctx->dmats_dirty = false;
+    ctx->dtaps_valid = false;
     return TR_OK;
 }
 
@@ -212,7 +215,22 @@ tr_status ensure_levels(tr_context* ctx, const tr_pyramid* p, hipStream_t stream
         ctx->h_levels.xlim[l] = ctx->h_levels.width[l] >= 2u ? (float)(ctx->h_levels.width[l] - 2u) : 0.0f;
     }
     ctx->h_levels_count = p->levels;
+    ctx->dtaps_valid = false;
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_levels, &ctx->h_levels, sizeof(tr_level_table), hipMemcpyHostToDevice, stream));
+    return TR_OK;
+}
+
+// The per-material tap records of the transmissive pass (tr_dtap): after ensure_digested and ensure_levels.
+tr_status ensure_tap_records(tr_context* ctx, float log2_fb_width, hipStream_t stream) {
+    if (ctx->dtaps_valid && std::memcmp(&ctx->dtaps_log2_width, &log2_fb_width, sizeof(float)) == 0) return TR_OK;
+    if (!ctx->d_dtaps || ctx->num_materials == 0 || ctx->h_levels_count == 0) return TR_ERR_TABLES_MISSING;
+    if ((uint64_t)ctx->h_levels.offset[ctx->h_levels_count - 1u] * 8u + 16u > 0xFFFFFFFFull) return TR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(digest_taps_kernel, dim3((ctx->num_materials + 63u) / 64u), dim3(64), 0, stream,
+                       (const tr_dmat*)ctx->d_dmats, (const tr_level_table*)ctx->d_levels, ctx->h_levels_count, log2_fb_width,
+                       ctx->d_dtaps, ctx->num_materials);
+    TR_HIP(ctx, hipGetLastError());
+    ctx->dtaps_valid = true;
+    ctx->dtaps_log2_width = log2_fb_width;
     return TR_OK;
 }
 
@@ -393,7 +411,7 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
 #if TR_ABLATION
     if (const char* e = std::getenv("TR_ABLATE")) fp->ablate = (uint32_t)std::atoi(e);  // profiling builds only
 #endif
-    fp->lut_width = ctx->lut_w;
+    fp->lut_wf = (float)ctx->lut_w;
     fp->lut_stride = ctx->lut_stride;
     fp->lut_height = ctx->lut_h;
     return TR_OK;
@@ -462,7 +480,7 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.lut_pairs = ctx->d_lut_pairs;
     L.lut_lines = ctx->d_lut_lines;
     L.levels = ctx->d_levels;
-    L.tile_counters = ctx->d_tile_counters;
+    L.dtaps = ctx->d_dtaps;
     // the coverage map of the layer, when tr_record_frame rasterised it itself and shades the whole frame
     L.tile_cover = (ctx->cover_hint && fp.rect_x0 == 0u && fp.rect_y0 == 0u && fp.g_origin_x == 0u && fp.g_origin_y == 0u &&
                     fp.rect_x1 == fp.width && fp.rect_y1 == fp.height && fp.g_width == fp.width)
@@ -505,7 +523,7 @@ void launch_shade(const tr_launch& L, bool half, dim3 grid, dim3 block, hipStrea
 }
 
 template <bool TRANSMISSIVE>
-tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bool half, dim3 grid, dim3 block, bool wave_blocks,
+tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bool half, dim3 grid, dim3 block,
                           hipStream_t stream) {
     if (ctx->any_plain_or_lite) {
         if (ctx->any_full_textured && L.tile_list) {   // (the frame recorder's buffers) the TEX = 1 launch lists the tiles itself
@@ -543,7 +561,7 @@ tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bo
             L.tile_list_count = ctx->d_class_list;
         }
         // as many waves as the chip holds of this kernel (4-5 per SIMD), each striding over the list
-        const dim3 grid2(wave_blocks ? ctx->num_cus * 20u : ctx->num_cus * 5u);
+        const dim3 grid2(ctx->num_cus * 20u);
         launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid2, block, stream);
         return TR_OK;
     }
@@ -599,7 +617,7 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         // The TEXTURED variants hold fewer waves (4 per SIMD) and are launched with the same grid: 16 rounds for them.
         hipDeviceProp_t prop;
         int resident_waves = 0;
-        const int launched_block = TR_WAVE_BLOCKS ? 64 : 256;
+        const int launched_block = 64;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_waves, shade_kernel<true, uint2>, launched_block, 0) != hipSuccess ||
             resident_waves <= 0) {
             resident_waves = 32 * 64 / launched_block;   // 8 waves per SIMD (the kernel is built for 64 VGPRs)
@@ -614,13 +632,10 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
     }
     if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_slice_thr, sizeof(float) * (TR_MAX_DEPTH_SLICES + 2)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_colour_tables, sizeof(tr_colour_tables)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_tile_counters, kTileCounterWords * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(ctx->d_tile_counters, 0, kTileCounterWords * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_colour_tables, sizeof(tr_colour_tables)) != hipSuccess) {
         (void)hipFree(ctx->d_levels);
         (void)hipFree(ctx->d_slice_thr);
         (void)hipFree(ctx->d_colour_tables);
-        (void)hipFree(ctx->d_tile_counters);
         delete ctx;
         return TR_ERR_OUT_OF_MEMORY;
     }
@@ -631,7 +646,6 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
             (void)hipFree(ctx->d_levels);
             (void)hipFree(ctx->d_slice_thr);
             (void)hipFree(ctx->d_colour_tables);
-            (void)hipFree(ctx->d_tile_counters);
             delete ctx;
             return TR_ERR_NO_DEVICE;
         }
@@ -646,6 +660,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipDeviceSynchronize();
     (void)hipFree(ctx->d_materials_raw);
     (void)hipFree(ctx->d_dmats);
+    (void)hipFree(ctx->d_dtaps);
     (void)hipFree(ctx->d_lights);
     (void)hipFree(ctx->d_alights);
     (void)hipFree(ctx->d_lut_rgba8);
@@ -654,7 +669,6 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_levels);
     (void)hipFree(ctx->d_slice_thr);
     (void)hipFree(ctx->d_class_list);
-    (void)hipFree(ctx->d_tile_counters);
     (void)hipFree(ctx->d_cluster_x);
     (void)hipFree(ctx->d_cluster_y_term);
     (void)hipFree(ctx->d_tex_arena);
@@ -720,11 +734,14 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
     if (count > ctx->cap_materials) {
         (void)hipFree(ctx->d_materials_raw);
         (void)hipFree(ctx->d_dmats);
+        (void)hipFree(ctx->d_dtaps);
         ctx->d_materials_raw = nullptr;
         ctx->d_dmats = nullptr;
+        ctx->d_dtaps = nullptr;
         ctx->cap_materials = 0;
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_materials_raw, sizeof(tr_material_info) * count));
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_dmats, sizeof(tr_dmat) * count));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_dtaps, sizeof(tr_dtap) * count));
         ctx->cap_materials = count;
     }
     ctx->stage_materials.assign(materials_host, materials_host + count);
@@ -1285,9 +1302,8 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     st = check_textured_launch(ctx, g, fp);
     if (st != TR_OK) return st;
     fp.pyr_levels = 1;
-    // one-wave workgroups (TR_WAVE_BLOCKS): same waves, four times the blocks
-    const bool wave_blocks = TR_WAVE_BLOCKS != 0;
-    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * (wave_blocks ? 4u : 1u)), block(wave_blocks ? 64 : 256);
+    // one-wave workgroups: blocks_per_xcd counts units of four waves
+    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * 4u), block(64);
     {
         tr_launch L;
         fill_launch(L, ctx, fp, g);
@@ -1295,7 +1311,7 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
         L.mip0 = (uint2*)opaque_mip0_out;
         const bool half = format == TR_FORMAT_RGBA16F;
         if (ctx->any_textured) {   // one launch per material class (see launch_textured)
-            const tr_status ls = launch_textured<false>(ctx, L, g, half, grid, block, wave_blocks, stream);
+            const tr_status ls = launch_textured<false>(ctx, L, g, half, grid, block, stream);
             if (ls != TR_OK) return ls;
         } else {
             launch_shade<false, kTexNone>(L, half, grid, block, stream);
@@ -1382,14 +1398,15 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     if (st != TR_OK) return st;
     st = ensure_levels(ctx, p, stream);
     if (st != TR_OK) return st;
+    st = ensure_tap_records(ctx, fp.log2_fb_width, stream);
+    if (st != TR_OK) return st;
     st = ensure_cluster_tables(ctx, u, fp.width, fp.height, stream);
     if (st != TR_OK) return st;
     st = check_textured_launch(ctx, g, fp);
     if (st != TR_OK) return st;
     fp.pyr_levels = p->levels;
-    // one-wave workgroups (TR_WAVE_BLOCKS): same waves, four times the blocks
-    const bool wave_blocks = TR_WAVE_BLOCKS != 0;
-    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * (wave_blocks ? 4u : 1u)), block(wave_blocks ? 64 : 256);
+    // one-wave workgroups: blocks_per_xcd counts units of four waves
+    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * 4u), block(64);
     {
         tr_launch L;
         fill_launch(L, ctx, fp, g);
@@ -1397,7 +1414,7 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
         L.hdr = hdr_inout;
         const bool half = format == TR_FORMAT_RGBA16F;
         if (ctx->any_textured) {   // one launch per material class (see launch_textured)
-            const tr_status ls = launch_textured<true>(ctx, L, g, half, grid, block, wave_blocks, stream);
+            const tr_status ls = launch_textured<true>(ctx, L, g, half, grid, block, stream);
             if (ls != TR_OK) return ls;
         } else {
             launch_shade<true, kTexNone>(L, half, grid, block, stream);
