@@ -6,6 +6,13 @@ metric   shaded Mpixels/s (+ p50 frame ms) of the 4K transmissive pass: `fragmen
          light rig (sun + 1 punctual light), RGBA16F target, inputs resident in HBM.
 step     one transmissive pass over one 3840x2160 frame (tr_shade_transmission) — at N > 1 followed by the
          composite (tr_allgather_frame: RCCL all-gather of the row bands).
+frames in flight (N = 1)   `--streams S` (default 2): the K frames of the timed region are independent (a renderer has
+         S frames in flight: S colour targets), so step k is issued on HIP stream k mod S into target k mod S and the
+         hardware starts frame k+1's waves in the wave slots frame k's stragglers leave empty — on ONE stream a launch
+         waits for the last wave of the one before, and ~5 % of the launch is its fill and drain (tools/gpu_overlap_probe.py).
+         `value` and `roofline` are wall clock / K of that region; kernels of different streams overlap, so a kernel's
+         own start-to-end duration (what rocprofv3 lists) is about S times that; the same K launches on ONE stream are
+         timed right after and reported as `single_stream` (frac and ms, the round-1/2 way of running it).
 
 python bench.py --gpus N   starts by itself: with WORLD_SIZE unset and N > 1 it spawns N child processes (one per
          GPU, before anything touches a GPU) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 set; under
@@ -36,10 +43,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ALGORITHMIC_BYTES_PER_PIXEL = 60  # 44 B G-buffer read + 8 B opaque-colour read + 8 B RGBA16F write
-READ_BYTES_PER_PIXEL = 52
-# what the variant that runs here has to move: the untextured kernel does not read the 8 B/px uv plane
-NEEDED_BYTES_PER_PIXEL = 52       # 16 + 16 + 4 (planes) + 8 (opaque colour) + 8 (write)
+# Bytes per shaded pixel.  SURVEY.md 8d counts 44 B G-buffer read + 8 B opaque-colour read + 8 B RGBA16F write = 60 B
+# and names 52 B (its read-only figure) the conservative claim.  52 B is also exactly what THIS variant has to move: the
+# untextured kernel never loads the 8 B/px uv plane (16 + 16 + 4 planes + 8 opaque colour + 8 write).  `roofline.frac`
+# is priced on the 52; the 60 B figure is reported beside it as `frac_survey_60B`.
+SURVEY_BYTES_PER_PIXEL = 60
+ALGORITHMIC_BYTES_PER_PIXEL = 52
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
 
 
@@ -55,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--composite", choices=("overlap", "serial", "none"), default="overlap",
                     help="N > 1: how the composite all-gather enters the timed step")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="N = 1: frames in flight — step k goes to HIP stream k mod S and colour target k mod S (1: every "
+                         "launch behind the previous one on one stream)")
     ap.add_argument("--all-transmissive", action="store_true",
                     help="every synthetic material gets transmission_factor 1 (DragonAttenuation's is 1): no tile skips "
                          "the refraction taps; the default run reports this variant beside the headline number")
@@ -149,24 +161,48 @@ def make_mip0_torch(width: int, height: int, device):
     return img
 
 
+def native_oracle():
+    """The oracle as BASELINE.md 2 describes the CPU baseline: `-O3 -march=native`, no fast-math, no FMA contraction —
+    compiled HERE (the host the baseline is timed on; a -march=native object from another machine may not even run)
+    from oracle/tr_oracle.c into oracle/_native/.  The parity checker stays the portable -O2 build; the two give the same
+    bits (no contraction, no reassociation).  Returns (ctypes library or None, description)."""
+    import ctypes as C
+    src = os.path.join(ROOT, "oracle", "tr_oracle.c")
+    out_dir = os.path.join(ROOT, "oracle", "_native")
+    out = os.path.join(out_dir, "libtr_oracle_native.so")
+    flags = ["-O3", "-march=native", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared", "-pthread"]
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.run(["gcc"] + flags + [src, "-o", out, "-lm"], check=True, capture_output=True, timeout=120)
+        return C.CDLL(out), "gcc " + " ".join(flags[:2])
+    except Exception:
+        return None, "gcc -O2 (oracle/Makefile; the -O3 -march=native build failed on this host)"
+
+
 def cpu_baseline(scene, lut, width, height, budget_s=12.0):
     """The oracle (scalar fp32 C restatement of the reference, row-band threads) timed on this host's cores on a
     bounded sample of the same workload: whole frames, as many as fit the budget."""
     import numpy as np
     from oracle import oracle
     from transmission_renderer_amd import synthetic
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))      # the cores this process may run on (cgroup / affinity), not the machine's
+    except AttributeError:
+        cores = os.cpu_count() or 1
     binding = oracle.SceneBinding(scene, lut)
     tex = oracle.new_pyramid(width, height, synthetic.make_opaque_mip0(width, height))
     oracle.generate_mips(width, height, tex)
     hdr16 = np.zeros((height, width, 4), dtype=np.float16)
     hdr32 = np.zeros((height, width, 4), dtype=np.float32)
+    native, how = native_oracle()
+    if native is not None:
+        oracle._bind_passes(native)
 
     def run(rows):
         y0 = max(0, height // 2 - rows // 2)
         band = synthetic.make_gbuffer(width, height, rows=(y0, y0 + rows))
         t0 = time.perf_counter()
-        oracle.shade_transmission(binding, band, tex, hdr_f16=hdr16, hdr_f32=hdr32, nthreads=cores)
+        oracle.shade_transmission(binding, band, tex, hdr_f16=hdr16, hdr_f32=hdr32, nthreads=cores, lib=native)
         return time.perf_counter() - t0
 
     run(min(height, max(cores, 16)))                 # warm-up (page in the planes, spin up the threads)
@@ -176,7 +212,7 @@ def cpu_baseline(scene, lut, width, height, budget_s=12.0):
     dt = dt1 + sum(run(rows) for _ in range(reps - 1))
     rows_total = rows * reps
     return {"value": rows_total * width / dt / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/libtr_oracle.so o_shade_transmission, {reps} x {rows} rows x {width} px of the same "
+            "sample": f"oracle/tr_oracle.c o_shade_transmission ({how}), {reps} x {rows} rows x {width} px of the same "
                       f"frame ({rows_total * width / 1e6:.1f} Mpx) in {dt:.1f} s, {cores} threads"}
 
 
@@ -306,7 +342,9 @@ def run_rank(args) -> int:
     pyr = OpaquePyramid(fw, fh, dev)                                                  # replicated read-only input
     pyr.level(0).copy_(make_mip0_torch(fw, fh, dev))
     r.generate_mips(pyr)
-    frames = [torch.zeros((padded, fw, 4), dtype=torch.float16, device=dev) for _ in range(2 if composite == "overlap" else 1)]
+    n_streams = max(1, args.streams) if not distributed else 1
+    frames = [torch.zeros((padded, fw, 4), dtype=torch.float16, device=dev)
+              for _ in range(2 if composite == "overlap" else n_streams)]
     uniforms, push = scene["uniforms"], scene["push"]
     rect = (0, y0, fw, y1)
     comp = sharded.Compositor(world, rank, renderer=r, single_rank_comm=args.rehearse_distributed) if distributed else None
@@ -314,6 +352,7 @@ def run_rank(args) -> int:
 
     compute = torch.cuda.current_stream()
     comm = torch.cuda.Stream() if composite == "overlap" else None
+    flight = [compute] + [torch.cuda.Stream() for _ in range(n_streams - 1)]   # N = 1: one stream per frame in flight
     shaded = [torch.cuda.Event() for _ in frames]
     gathered = [None for _ in frames]
     launches = {"count": 0}
@@ -338,6 +377,9 @@ def run_rank(args) -> int:
                 ev = torch.cuda.Event()
                 ev.record(comm)
                 gathered[i] = ev
+        elif n_streams > 1:
+            with torch.cuda.stream(flight[k % n_streams]):
+                shade(buf)
         else:
             shade(buf)
             if composite == "serial":
@@ -346,10 +388,17 @@ def run_rank(args) -> int:
     # Untimed warm-up: W steps — and before them, as many band launches as it takes to have kept the GPU busy for
     # 50 ms: its clocks ramp over the first ~10 ms of load (the first ~70 back-to-back 4K launches run 10-15 % slow),
     # and the metric is steady-state throughput.  The count is reported (`clock_ramp_launches`).
+    # (with several frames in flight the ramp runs the same pattern as the timed region — the first few hundred
+    #  launches after a second hardware queue comes into use run ~6 % slow, tools/gpu_overlap_probe.py — for 150 ms)
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.05:
+    ramp_k = 0
+    while time.perf_counter() - t_ramp < (0.15 if n_streams > 1 else 0.05):
         for _ in range(16):
-            shade(frames[0])
+            if n_streams > 1:
+                step(ramp_k)
+                ramp_k += 1
+            else:
+                shade(frames[0])
         torch.cuda.synchronize()
     clock_ramp_launches = launches["count"]
     for k in range(W):
@@ -361,12 +410,17 @@ def run_rank(args) -> int:
     # Timed region: exactly K steps back to back, bracketed by the barrier + synchronize pairs (wall clock -> value).
     # At N = 1 ONE pair of HIP events on the launch stream brackets the K launches (-> the kernel's average launch
     # duration for the roofline); no per-launch events: each record is a barrier packet that costs ~5 us.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # With S > 1 streams every stream gets its own pair; the streams were synchronised just above, so the region runs
+    # from the earliest start to the latest end: region = (the first stream's start event) -> (every stream's end event).
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in flight]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in flight]
     t0 = time.perf_counter()
-    ev0.record()
+    for s_, e in zip(flight, ev0):
+        e.record(s_)
     for k in range(K):
         step(W + k)
-    ev1.record()
+    for s_, e in zip(flight, ev1):
+        e.record(s_)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -376,7 +430,10 @@ def run_rank(args) -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    region_ms = ev0.elapsed_time(ev1) / K
+    region_ms = max(ev0[0].elapsed_time(e) for e in ev1) / K
+    # a launch's own time on its stream (what a per-kernel trace shows: launches of different streams overlap)
+    in_stream_ms = max(a.elapsed_time(b) / max(1, len(range(i, K, n_streams)))
+                       for i, (a, b) in enumerate(zip(ev0, ev1)))
 
     # ---- outside the timed region -------------------------------------------------------------------------------
     def timed_launches(n, fn):
@@ -390,6 +447,8 @@ def run_rank(args) -> int:
 
     # the band kernel alone, back to back (at N = 1 the timed region already is exactly this)
     kernel_ms = region_ms if not distributed else timed_launches(K, lambda: shade(frames[0]))
+    # N = 1: the same K launches on ONE stream, each behind the previous one (how rounds 1 and 2 ran the metric)
+    single_stream_ms = timed_launches(K, lambda: shade(frames[0])) if (not distributed and n_streams > 1) else None
     kernel_ms_max = kernel_ms
     composite_ms = None
     per_rank_kernel_ms = [kernel_ms]
@@ -432,6 +491,8 @@ def run_rank(args) -> int:
     launch_log = [("clock_ramp", clock_ramp_launches), ("warmup", W), ("timed", K)]
     if distributed:
         launch_log.append(("kernel_only", K))
+    if single_stream_ms is not None:
+        launch_log.append(("single_stream", K))
     launch_log += [("percentiles", K), ("launch_sync", 50)]
 
     pixels_rank = (y1 - y0) * fw
@@ -459,12 +520,19 @@ def run_rank(args) -> int:
         for m in scene["materials"]:
             m.transmission_factor = 1.0
         r.upload_materials(scene["materials"])
+        def in_flight(n):
+            for k in range(n):
+                step(k)
+            for s_ in flight[1:]:
+                compute.wait_stream(s_)
         timed_launches(200, lambda: shade(frames[0]))
-        ms = timed_launches(K, lambda: shade(frames[0]))
+        ms = timed_launches(1, lambda: in_flight(K)) / K
         launch_log += [("all_transmissive_ramp", 200), ("all_transmissive", K)]
         variants["all_transmissive"] = {
             "avg_kernel_ms": round(ms, 4), "Mpixels_per_s": round(pixels_rank / ms / 1e3, 1),
             "frac": round(pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_survey_60B": round(pixels_rank * SURVEY_BYTES_PER_PIXEL / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "streams": n_streams,
             "note": "every synthetic material with transmission_factor = 1 (in the headline scene 4 of 16 have 0 and skip "
                     "the refraction taps, LUT and btdf lobes)"}
 
@@ -494,7 +562,9 @@ def run_rank(args) -> int:
                                    + (" (all transmission_factor 1)" if args.all_transmissive else "")
                                    + (f", roughness override {args.roughness_override}" if args.roughness_override is not None else "")
                                    + f", sun + {args.lights} punctual light(s) (DragonAttenuation rig), RGBA16F target, "
-                                     f"{pyr.levels}-level opaque pyramid, ggx_lut.png",
+                                     f"{pyr.levels}-level opaque pyramid, ggx_lut.png"
+                                   + (f", {n_streams} frames in flight (one HIP stream and one colour target each)"
+                                      if n_streams > 1 else ""),
                        "pixels_per_step": pixels_step, "pixels_per_gpu": pixels_rank,
                        "sharding": f"{world} row band(s) of {rows_per_rank} rows (tr_band_rows)",
                        "composite": ("none (one GPU holds the frame)" if not distributed else
@@ -502,13 +572,16 @@ def run_rank(args) -> int:
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "tr::shade_kernel<true, uint2, 0, false>", "avg_kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_pixel": ALGORITHMIC_BYTES_PER_PIXEL,
                          "algorithmic_bytes_per_launch": pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL,
-                         "read_only_frac": round(pixels_rank * READ_BYTES_PER_PIXEL / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
-                         "bytes_needed_per_pixel": NEEDED_BYTES_PER_PIXEL,
-                         "frac_bytes_needed": round(pixels_rank * NEEDED_BYTES_PER_PIXEL / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "60 B/px is SURVEY 8d's figure; this untextured variant never loads the 8 B/px uv plane "
-                                 "(bytes_needed 52 B/px), and tiles of materials with transmission_factor 0 skip the 8 B/px "
-                                 "opaque-colour read (see variants.all_transmissive)"},
+                         "frac_survey_60B": round(pixels_rank * SURVEY_BYTES_PER_PIXEL / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "streams": n_streams,
+                         "kernel_ms_on_its_stream": round(in_stream_ms, 4),
+                         "note": "52 B/px = what this untextured variant moves (16 + 16 + 4 B planes, 8 B opaque colour, 8 B "
+                                 "write; = SURVEY 8d's read-only figure); SURVEY 8d's 60 B/px also counts the 8 B/px uv plane, "
+                                 "which this kernel never loads (frac_survey_60B).  avg_kernel_ms = timed region / K with "
+                                 f"{n_streams} frame(s) in flight; kernel_ms_on_its_stream = the same launches as a per-kernel "
+                                 "trace sees them (they overlap across streams)"},
             "clock_ramp_launches": clock_ramp_launches,
             "launch_sync_p50_ms": round(float(np.percentile(sync_ms, 50)), 4),
             "launch_log": launch_log,
@@ -525,6 +598,13 @@ def run_rank(args) -> int:
                     out["roofline"]["traffic_source"] = tr_.get("source")
             except Exception:
                 pass
+        if single_stream_ms is not None:
+            ss = single_stream_ms * 1e-3
+            out["single_stream"] = {"avg_kernel_ms": round(single_stream_ms, 4),
+                                    "Mpixels_per_s": round(pixels_rank / single_stream_ms / 1e3, 1),
+                                    "frac": round(pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL / ss / 1e9 / HBM_PEAK_GBS, 4),
+                                    "frac_survey_60B": round(pixels_rank * SURVEY_BYTES_PER_PIXEL / ss / 1e9 / HBM_PEAK_GBS, 4),
+                                    "note": "the same K launches on one stream, each behind the previous one"}
         if distributed:
             out["kernel_only"] = {"ms_per_step": round(kernel_ms_max, 4),
                                   "Mpixels_per_s": round(pixels_step / kernel_ms_max / 1e3, 1),

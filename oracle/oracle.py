@@ -315,8 +315,9 @@ def shade_opaque(binding: SceneBinding, g: dict, rect=None, nthreads=1, want_mip
 
 
 def shade_transmission(binding: SceneBinding, g: dict, pyramid_texels: np.ndarray, hdr_f16=None, hdr_f32=None,
-                       rect=None, nthreads=1, fp64=False):
-    """hdr_* are in/out (uncovered pixels keep their content); fresh zero targets if None."""
+                       rect=None, nthreads=1, fp64=False, lib=None):
+    """hdr_* are in/out (uncovered pixels keep their content); fresh zero targets if None.  `lib`: another build of
+    tr_oracle.c with its passes bound (bench.py's -O3 -march=native baseline build)."""
     w, h = _frame_size(binding, g)
     f16 = np.zeros((h, w, 4), dtype=np.float16) if hdr_f16 is None else hdr_f16
     f32_ = np.zeros((h, w, 4), dtype=np.float64 if fp64 else np.float32) if hdr_f32 is None else hdr_f32
@@ -324,8 +325,8 @@ def shade_transmission(binding: SceneBinding, g: dict, pyramid_texels: np.ndarra
     r = _default_rect(g) if rect is None else wire.Rect(*rect)
     gs = gbuffer_struct(g)
     p = pyramid_struct(w, h, pyramid_texels)
-    (load64() if fp64 else load()).o_shade_transmission(C.byref(binding.struct), C.byref(gs), C.byref(p), r,
-                                                        _ptr(f16), _ptr(f32_), nthreads)
+    (lib or (load64() if fp64 else load())).o_shade_transmission(C.byref(binding.struct), C.byref(gs), C.byref(p), r,
+                                                                 _ptr(f16), _ptr(f32_), nthreads)
     return f16, f32_
 
 

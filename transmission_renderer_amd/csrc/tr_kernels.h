@@ -118,9 +118,9 @@ struct alignas(16) tr_dmat {
     // X = diffuse * ((1 - (f0 A + f90 B)) T + bt_a * sum_ta - bt_b * sum_tb), so
     //   out = kd * sum_d + kt * (1 - (f0 A + f90 B)) T + kta * sum_ta - ktb * sum_tb + specular + emission
     float kd[3];           // c_diff * (1 - tf)
-    float _pad1;
+    float f0_max;          // max(f0): the channel whose Fresnel term is the largest at every angle, and
     float kt[3];           // tf^2 * diffuse
-    float _pad2;
+    float df_min;          //   f90 - max(f0)
     float kta[3];          // tf^2 * diffuse * bt_a
     float _pad3;
     float ktb[3];          // tf^2 * diffuse * bt_b
@@ -333,7 +333,8 @@ __device__ __forceinline__ float clamp_eps(float x) {
 // Accumulators of one pixel over its lights.
 struct light_acc {
     f3 d;        // sum I * nol * (1 - max(F))                     (x c_diff/pi at the end)
-    f3 s;        // sum I * nol * D*V * F                          (basic_brdf specular)
+    f3 s;        // sum I * nol * D*V * F                          (basic_brdf specular) — for a material in scalar registers
+    f3 sp;       //   F = f0 + (f90 - f0) p is resolved once per pixel like the btdf lobe: s = sum I nol D*V, sp = sum I nol D*V p
     f3 ta, tb;   // sum I * D'V'/k' and sum I * D'V'/k' * p'       (transmission_btdf: (1 - F') is linear in p', so the
                  //  lobe is resolved once per pixel: bt_a * ta - bt_b * tb; the per-light work has no scalar operand)
 };
@@ -361,6 +362,7 @@ struct pixel_frame {
 // for the compiler (signed zeros), so accumulating into zero-initialised registers costs a move and an add per sum.
 template <bool TRANSMISSIVE, bool FIRST = false, class Mat /* cdmat (scalar registers) or const lane_dmat (per lane) */>
 __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_frame& px, f3 l, f3 I, bool btdf) {
+    constexpr bool SPLIT_F = std::is_same<Mat, cdmat>::value;
     const f3 n = px.n, v = px.v;
     const float nov_raw = px.nov_raw, nov = px.nov;
     const float nl_raw = dot3(n.x, n.y, n.z, l.x, l.y, l.z);
@@ -379,23 +381,47 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         const float sin2 = c2 * (inv_h * inv_h);                   // 1 - (n.h)^2
         const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
         // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal
-        const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(nol * nol, m_oma2(m, 0), m.a2[0])));
+        // (nol^2 (1 - a2) + a2 written as nol^2 + a2 (1 - nol^2): one table operand per instruction — with two the
+        //  compiler first copies one into a vector register, and an instruction with a scalar operand never pairs)
+        const float nol2 = nol * nol;
+        const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(m.a2[0], 1.0f - nol2, nol2)));
         // (g > 0 always: n.l, n.v are clamped to EPSILON and the roots are positive, so v_smith's `denom <= 0`
         //  guard, :125-131, cannot trigger; a NaN propagates like in the reference)
         const float dv = m_k(m, 0) * rcp(f * f * g);
-        const float Fx = fmaf(m_df(m, 0), p, m.f0[0]), Fy = fmaf(m_df(m, 1), p, m.f0[1]), Fz = fmaf(m_df(m, 2), p, m.f0[2]);
-        const float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));  // diffuse_brdf :356-360
         const float ws = nol * dv;                                 // specular_brdf :362-375 (weighted by n.l :414-421)
-        if constexpr (FIRST) {
-            acc.d = {I.x * wd, I.y * wd, I.z * wd};
-            acc.s = {I.x * ws * Fx, I.y * ws * Fy, I.z * ws * Fz};
+        if constexpr (SPLIT_F) {
+            // max(F) = F of the channel with the largest f0 (f90 is a splat and p <= 1: F is monotone in f0)
+            const float wd = nol * (1.0f - fmaf(m.df_min, p, m.f0_max));   // diffuse_brdf :356-360
+            const float wsp = ws * p;
+            if constexpr (FIRST) {
+                acc.d = {I.x * wd, I.y * wd, I.z * wd};
+                acc.s = {I.x * ws, I.y * ws, I.z * ws};
+                acc.sp = {I.x * wsp, I.y * wsp, I.z * wsp};
+            } else {
+                acc.d.x = fmaf(I.x, wd, acc.d.x);
+                acc.d.y = fmaf(I.y, wd, acc.d.y);
+                acc.d.z = fmaf(I.z, wd, acc.d.z);
+                acc.s.x = fmaf(I.x, ws, acc.s.x);
+                acc.s.y = fmaf(I.y, ws, acc.s.y);
+                acc.s.z = fmaf(I.z, ws, acc.s.z);
+                acc.sp.x = fmaf(I.x, wsp, acc.sp.x);
+                acc.sp.y = fmaf(I.y, wsp, acc.sp.y);
+                acc.sp.z = fmaf(I.z, wsp, acc.sp.z);
+            }
         } else {
-            acc.d.x = fmaf(I.x, wd, acc.d.x);
-            acc.d.y = fmaf(I.y, wd, acc.d.y);
-            acc.d.z = fmaf(I.z, wd, acc.d.z);
-            acc.s.x = fmaf(I.x * ws, Fx, acc.s.x);
-            acc.s.y = fmaf(I.y * ws, Fy, acc.s.y);
-            acc.s.z = fmaf(I.z * ws, Fz, acc.s.z);
+            const float Fx = fmaf(m_df(m, 0), p, m.f0[0]), Fy = fmaf(m_df(m, 1), p, m.f0[1]), Fz = fmaf(m_df(m, 2), p, m.f0[2]);
+            const float wd = nol * (1.0f - fmaxf(Fx, fmaxf(Fy, Fz)));  // diffuse_brdf :356-360
+            if constexpr (FIRST) {
+                acc.d = {I.x * wd, I.y * wd, I.z * wd};
+                acc.s = {I.x * ws * Fx, I.y * ws * Fy, I.z * ws * Fz};
+            } else {
+                acc.d.x = fmaf(I.x, wd, acc.d.x);
+                acc.d.y = fmaf(I.y, wd, acc.d.y);
+                acc.d.z = fmaf(I.z, wd, acc.d.z);
+                acc.s.x = fmaf(I.x * ws, Fx, acc.s.x);
+                acc.s.y = fmaf(I.y * ws, Fy, acc.s.y);
+                acc.s.z = fmaf(I.z * ws, Fz, acc.s.z);
+            }
         }
     }
     // ---- lobe 1: transmission_btdf (:200-233): the light mirrored about the surface,
@@ -414,7 +440,8 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
             const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
             const float sin2 = c2 * (inv_h * inv_h);
             const float f = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - sin2, sin2) : 1.0f;
-            const float g = fmaf(nolm, px.g_nov.y, nov * fast_sqrt(fmaf(nolm * nolm, m_oma2(m, 1), m.a2[1])));
+            const float nolm2 = nolm * nolm;
+            const float g = fmaf(nolm, px.g_nov.y, nov * fast_sqrt(fmaf(m.a2[1], 1.0f - nolm2, nolm2)));
             const float r = rcp(f * f * g);                          // D'V' / k[1]; not weighted by n.l (:232)
             const float tx = I.x * r, ty = I.y * r, tz = I.z * r;
             if constexpr (FIRST) {
@@ -920,13 +947,13 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
     // ================= phases 2+3: the sun, then the clustered punctual lights =================
     // The sun writes the accumulators instead of adding to zeros (eval_light<FIRST>).
     light_acc acc;
-    if (TR_ABLATION) acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (TR_ABLATION) acc = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto lights_phase = [&]() {
         claunch* L2 = launder(L);
         const auto m2 = mat_base(launder(m));
         {
-            const v2f ra = pk_fma(splat(nov * nov), v2f{m_oma2(*m2, 0), m_oma2(*m2, 1)}, v2f{m2->a2[0], m2->a2[1]});
-            px.g_nov = v2f{fast_sqrt(ra.x), TRANSMISSIVE ? fast_sqrt(ra.y) : 0.0f};
+            const float nov2 = nov * nov, onov2 = 1.0f - nov2;
+            px.g_nov = v2f{fast_sqrt(fmaf(m2->a2[0], onov2, nov2)), TRANSMISSIVE ? fast_sqrt(fmaf(m2->a2[1], onov2, nov2)) : 0.0f};
         }
         // sun (lighting.rs:37-53 / 171-177)
         if (!TR_ABLATE(L2, 4u))
@@ -970,7 +997,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
             // the material's composite constants with transmission_factor folded in (tr_dmat::kd ...)
             // (the opaque pass, `fragment`, knows no transmission: plain c_diff)
             const TR_CONSTANT float* kd = TRANSMISSIVE ? m4->kd : m4->c_diff;
-            out = {fmaf(kd[0], acc.d.x, acc.s.x), fmaf(kd[1], acc.d.y, acc.s.y), fmaf(kd[2], acc.d.z, acc.s.z)};
+            out = {fmaf(m4->df[0], acc.sp.x, m4->f0[0] * acc.s.x), fmaf(m4->df[1], acc.sp.y, m4->f0[1] * acc.s.y),
+                   fmaf(m4->df[2], acc.sp.z, m4->f0[2] * acc.s.z)};                  // specular: sum I nol D*V F
+            out = {fmaf(kd[0], acc.d.x, out.x), fmaf(kd[1], acc.d.y, out.y), fmaf(kd[2], acc.d.z, out.z)};
             if (transmits) {
                 // ---- ibl_volume_refraction, part 2 (:337-353)
                 f3 T = pyramid_resolve(pf);
@@ -1725,7 +1754,9 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
     }
     d.lut_line = i * lut_stride;
     d._pad = 0u;
-    d._pad1 = d._pad2 = d._pad3 = d._pad4 = 0.0f;
+    d._pad3 = d._pad4 = 0.0f;
+    d.f0_max = fmaxf(d.f0[0], fmaxf(d.f0[1], d.f0[2]));
+    d.df_min = d.f90 - d.f0_max;
     const float tf = mi.transmission_factor, tf2 = tf * tf;
     for (int k = 0; k < 3; ++k) {
         d.kd[k] = d.c_diff[k] * (1.0f - tf);
