@@ -1,10 +1,14 @@
 """The HIP passes against the reference's OWN compiled shaders (run with -m gpu on an MI355X).
 
-tests/golden/spirv_case_{a,b,c}.npz hold the outputs of compiled-shaders/normal/fragment_transmission.spv and
+tests/golden/spirv_case_{a,b,c,d,e}.npz hold the outputs of compiled-shaders/normal/fragment_transmission.spv and
 fragment.spv executed instruction by instruction on seeded inputs (tools/make_golden_spirv.py): a = 2 punctual lights,
 b = 4 lights + spotlights + ragged cluster lists + roughness override 0.25, c = every material-texture slot, sRGB /
-UNORM, normal mapping through OpDPdx / OpDPdy, holes.  Here the same inputs go through libtr_shade.so and every pixel
-the fixture holds is compared with the SPIR-V result — no pixel is excluded:
+UNORM, normal mapping through OpDPdx / OpDPdy, holes; d, e = 2 000 sampled pixels each of the BENCHMARK'S OWN 3840x2160
+frames (d: the headline scene, sun + 1 light; e: BASELINE config 3, sun + 4 lights, roughness override 0.25).  The fixed
+function the shaders delegate to Vulkan was answered by a numpy statement of the Vulkan specification
+(oracle/spirv_ref/vk_sampling.py): no output of the C oracle is in a fixture.  Here the same inputs go through
+libtr_shade.so — for d / e the whole 4K frame is shaded — and every pixel the fixture holds is compared with the SPIR-V
+result; no pixel is excluded:
 
   * RGBA32F target: per-channel RMSE of (gpu - spirv) / max(|spirv|, 1) <= 1e-4   (north_star's bound; values reach
     60 .. 1.6e4 in these cases, so the difference is relative above 1; the raw RMSE is printed)
@@ -23,9 +27,7 @@ torch = pytest.importorskip("torch")
 
 from oracle import oracle  # noqa: E402
 from test_gpu_parity import _display, _norm_err  # noqa: E402
-from test_oracle_vs_spirv import _scene_from_fixture  # noqa: E402
-
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spirv_case_*.npz")))
+from test_oracle_vs_spirv import GOLDEN, GOLDEN_SAMPLED, _scene_from_fixture, sampled_scene  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -88,3 +90,58 @@ def test_hip_passes_match_the_compiled_shaders(renderer, path):
                 assert norm.max() <= 1e-4, (key, str(dt), norm)
     finally:
         r.upload_textures([])
+
+
+@pytest.mark.parametrize("path", GOLDEN_SAMPLED, ids=[os.path.basename(p) for p in GOLDEN_SAMPLED])
+def test_hip_passes_match_the_compiled_shaders_at_4k(renderer, path):
+    """Cases d / e: the full-size launches of the benchmark's own frames against the reference binary on the sampled pixels
+    (framebuffer-size-dependent terms: lod = log2(3840) * r over the 12-level pyramid, 240x135-pixel clusters)."""
+    import hashlib
+    from transmission_renderer_amd import synthetic
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    assert len(GOLDEN_SAMPLED) == 2, "fixtures missing"
+    r = renderer
+    z = np.load(path)
+    scene, w, h = sampled_scene(z)
+    assert (w, h) == (3840, 2160)
+    g = synthetic.make_gbuffer(w, h)
+    ys, xs = z["pixels"][:, 0], z["pixels"][:, 1]
+    assert len(ys) == 2000
+    for k in ("pos_depth", "nrm_scale", "uv", "material_id"):   # the frame shaded here IS the frame the fixture sampled
+        assert g[k][ys, xs].tobytes() == z[k].tobytes(), k
+    mip0 = synthetic.make_opaque_mip0(w, h)
+    assert hashlib.sha256(mip0.tobytes()).digest() == z["opaque_mip0_sha256"].tobytes()
+    r.upload_materials(scene["materials"])
+    r.upload_lights(scene["lights"])
+    r.upload_textures([])
+    r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(r.device),
+                         torch.from_numpy(scene["light_indices"].view(np.int32)).to(r.device))
+    planes = GBufferPlanes.from_numpy(g, r.device)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.level(0).copy_(torch.from_numpy(mip0).to(r.device))
+    r.generate_mips(pyr)        # (bit-identical to the specification's blit chain: tests/test_gpu_parity.py + test_vk_sampling.py)
+    iy, ix = torch.from_numpy(ys.astype(np.int64)).to(r.device), torch.from_numpy(xs.astype(np.int64)).to(r.device)
+    for dt in (torch.float32, torch.float16):
+        t = torch.zeros((h, w, 4), dtype=dt, device=r.device)
+        o = torch.zeros((h, w, 4), dtype=dt, device=r.device)
+        r.shade_transmission(planes, scene["uniforms"], scene["push"], pyr, t)
+        r.shade_opaque(planes, scene["uniforms"], scene["push"], o, None)
+        torch.cuda.synchronize()
+        for got_t, key in ((t, "spirv_fragment_transmission"), (o, "spirv_fragment_hdr")):
+            want = z[key]
+            assert np.isfinite(want).all()
+            got = got_t[iy, ix].cpu().numpy()
+            if dt == torch.float16:
+                want16 = want.astype(np.float16)
+                assert np.isfinite(want16.astype(np.float32)).all()
+                p0 = np.sqrt(((_display(got[None]) - _display(want16[None])) ** 2).mean(axis=(0, 1)))
+                assert p0.max() <= 1e-4, (key, "display-referred", p0)
+                got, want = got.astype(np.float32), want16.astype(np.float32)
+            assert np.isfinite(got).all(), key
+            assert (got[:, 3] == 1.0).all()
+            norm = _rmse_rows(_norm_err(got, want))
+            raw = _rmse_rows(got.astype(np.float64) - want.astype(np.float64))
+            print(f"[golden 4K] {os.path.basename(path)} {key} {dt}: normalised RMSE {norm.max():.2e}, raw {raw.max():.2e}, "
+                  f"|ref| max {np.abs(want).max():.3g}")
+            assert norm.max() <= 1e-4, (key, str(dt), norm)
+        del t, o

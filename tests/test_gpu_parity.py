@@ -94,14 +94,22 @@ def _check_against_oracles(got32, got16, o32, o64, o16_64, what, o16_32=None):
             o16_32 = o32.astype(np.float16)
     p0 = np.sqrt(((_display(got16) - _display(o16_32)) ** 2).mean(axis=(0, 1)))
     assert p0.max() <= 1e-4, (what, "P0 display-referred RMSE vs oracle32", p0)
-    # P1: the HDR attachment against the pinned fp32 oracle, all pixels
-    p1 = _rmse(_norm_err(got32, o32)).max()
-    noise = _rmse(_norm_err(o32, o64)).max()      # the reference's own fp32 rounding noise on this input
-    print(f"[parity] {what}: P0 {p0.max():.2e}  P1 rmse(gpu, oracle32) {p1:.2e}  rmse(oracle32, oracle64) {noise:.2e}")
-    if noise <= 5e-5:
-        assert p1 <= 1e-4, (what, "P1 all-pixel RMSE vs oracle32", p1)
-    else:   # an ill-conditioned input: the fp32 reference is not reproducible to 1e-4 by any other evaluation order
-        assert p1 <= noise + 1e-5, (what, "P1 (ill-conditioned reference)", p1, noise)
+    # P1: the HDR attachment against the pinned fp32 oracle: RMSE <= 1e-4 over all pixels but an explicit, COUNTED set —
+    # the pixels where the reference's own fp32 formulas are ill-conditioned (d_ggx at low roughness,
+    # glam-pbr/src/lib.rs:101-109: 1 - noh^2 to ~1e-9 in fp32), identified without the GPU: the pinned fp32 oracle
+    # departs there from the SAME formulas evaluated in fp64 by more than 1e-3 (normalised).  No evaluation order other
+    # than the reference's own reproduces such a pixel to 1e-4; on them the GPU must be no further from the fp64 value
+    # than the fp32 reference is (T3 below).  The set is at most 0.05 % of the frame (measured 0 ... 0.013 %).
+    n32 = _norm_err(o32, o64)
+    ill = np.abs(n32[..., :3]).max(axis=2) > 1e-3
+    assert ill.mean() <= 5e-4, (what, "ill-conditioned pixels", int(ill.sum()), "of", ill.size)
+    e32_all = _norm_err(got32, o32)
+    p1_all = _rmse(e32_all).max()
+    p1 = np.sqrt((e32_all[~ill][:, :3] ** 2).mean(axis=0)).max()
+    noise = _rmse(n32).max()      # the reference's own fp32 rounding noise on this input
+    print(f"[parity] {what}: P0 {p0.max():.2e}  P1 rmse(gpu, oracle32) {p1:.2e} outside {int(ill.sum())} ill-conditioned "
+          f"pixels of {ill.size} ({p1_all:.2e} over all)  rmse(oracle32, oracle64) {noise:.2e}")
+    assert p1 <= 1e-4, (what, "P1 RMSE vs oracle32", p1, "ill-conditioned pixels excluded:", int(ill.sum()))
     e64 = _norm_err(got32, o64)
     assert _rmse(e64).max() <= 1e-4, (what, "T1", _rmse(e64))
     assert np.abs(e64).max() <= 5e-3, (what, "T1 max", np.abs(e64).max())
@@ -122,6 +130,20 @@ def _check_against_oracles(got32, got16, o32, o64, o16_64, what, o16_32=None):
     if bad.any():
         gpu_off = np.abs(e64).max(axis=2)[bad]
         assert (gpu_off <= noise[bad] + 1e-4).all(), (what, "T3 ill-conditioned pixels")
+
+
+def _p1_against_pinned(got, o32, o64, what, covered=None, max_ill_fraction=5e-4):
+    """P1 on any set of pixels (rows of a big frame, a whole small frame): RMSE of (gpu - oracle32) / max(|oracle32|, 1)
+    <= 1e-4 against the PINNED fp32 oracle, outside the counted ill-conditioned set (where oracle32 departs from the same
+    formulas in fp64 by more than 1e-3, see _check_against_oracles); arrays (..., 4)."""
+    got, o32, o64 = (np.asarray(a).reshape(-1, np.asarray(a).shape[-1]) for a in (got, o32, o64))
+    keep = np.ones(len(got), bool) if covered is None else np.asarray(covered).reshape(-1)
+    ill = (np.abs(_norm_err(o32, o64)[:, :3]).max(axis=1) > 1e-3) & keep
+    assert ill.sum() <= max(max_ill_fraction * keep.sum(), 2), (what, "ill-conditioned pixels", int(ill.sum()), "of", int(keep.sum()))
+    e = _norm_err(got, o32)[keep & ~ill]
+    p1 = np.sqrt((e[:, :3] ** 2).mean(axis=0)).max()
+    print(f"[parity] {what}: P1 rmse(gpu, oracle32) {p1:.2e} over {int((keep & ~ill).sum())} pixels, {int(ill.sum())} ill-conditioned excluded")
+    assert p1 <= 1e-4, (what, "P1 vs the pinned fp32 oracle", p1)
 
 
 CASES = [
@@ -306,6 +328,12 @@ def test_full_frame_pipeline_and_band_sharding_agree(renderer, ggx_lut):
     oracle.generate_mips(w, h, tex)
     oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=o16, nthreads=8, fp64=True)
     assert _rmse(_norm_err(full.astype(np.float32), o16.astype(np.float32))).max() <= 1e-4
+    # ... and the same chain through the PINNED fp32 oracle (its own mip 0, its own pyramid)
+    p16, _, pmip0 = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8)
+    ptex = oracle.new_pyramid(w, h, pmip0)
+    oracle.generate_mips(w, h, ptex)
+    oracle.shade_transmission(b, scene["gbuffer"], ptex, hdr_f16=p16, nthreads=8)
+    _p1_against_pinned(full.astype(np.float32), p16.astype(np.float32), o16.astype(np.float32), "end to end, RGBA16F, vs oracle32")
 
 
 def test_error_paths(renderer, ggx_lut):
@@ -378,14 +406,18 @@ def test_4k_properties(renderer, ggx_lut):
     bind = oracle.SceneBinding(scene, ggx_lut)
     tex = pyr.texels.cpu().numpy()
     got = a.cpu().numpy()
-    errs = []
+    errs, rows32, rows64, rows_got = [], [], [], []
     for y in np.linspace(0, h - 1, 12).astype(int):
         band = synthetic.make_gbuffer(w, h, rows=(int(y), int(y) + 1))
         ref = np.zeros((h, w, 4), dtype=np.float64)
         oracle.shade_transmission(bind, band, tex, hdr_f32=ref, fp64=True)
         errs.append(_norm_err(got[y], ref[y]))
+        ref32 = np.zeros((h, w, 4), dtype=np.float32)
+        oracle.shade_transmission(bind, band, tex, hdr_f32=ref32)
+        rows32.append(ref32[y].copy()); rows64.append(ref[y].copy()); rows_got.append(got[y])
     e = np.stack(errs)
     assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (_rmse(e), np.abs(e).max())
+    _p1_against_pinned(np.stack(rows_got), np.stack(rows32), np.stack(rows64), "4K headline frame, 12 rows")
 
 
 def _oracle_rows(bind, scene_size, rows, tex, fp64=True, opaque=False):
@@ -431,12 +463,16 @@ def test_config2_1080p_opaque_mips_transmissive_end_to_end(renderer, ggx_lut):
     r.shade_opaque(g, scene["uniforms"], scene["push"], o32, None)
     r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
     torch.cuda.synchronize()
-    for got, refs, what in ((o32.cpu().numpy(), _oracle_rows(bind, (w, h), rows, tex, opaque=True), "opaque"),
-                            (t32.cpu().numpy(), _oracle_rows(bind, (w, h), rows, tex), "transmissive")):
+    for got, refs, refs32, what in ((o32.cpu().numpy(), _oracle_rows(bind, (w, h), rows, tex, opaque=True),
+                                     _oracle_rows(bind, (w, h), rows, tex, fp64=False, opaque=True), "opaque"),
+                                    (t32.cpu().numpy(), _oracle_rows(bind, (w, h), rows, tex),
+                                     _oracle_rows(bind, (w, h), rows, tex, fp64=False), "transmissive")):
         covered = scene["gbuffer"]["material_id"][rows] != wire.NOT_COVERED
         e = np.stack([_norm_err(got[y], refs[int(y)]) for y in rows])
         e = np.where(covered[..., None], e, 0.0)
         assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (what, _rmse(e), np.abs(e).max())
+        _p1_against_pinned(np.stack([got[y] for y in rows]), np.stack([refs32[int(y)] for y in rows]),
+                           np.stack([refs[int(y)] for y in rows]), f"config 2 (1080p) {what}, 10 rows", covered=covered)
     # (4) deterministic, and 4 row bands of 270 rows reproduce the frame
     hdr2 = torch.zeros_like(hdr)
     pyr2 = OpaquePyramid(w, h, r.device)
@@ -480,9 +516,9 @@ def test_config3_4k_four_lights_roughness_override(renderer, ggx_lut):
     got = a.cpu().numpy()
     e = np.stack([_norm_err(got[y], refs[int(y)]) for y in rows])
     assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (_rmse(e), np.abs(e).max())
-    refs32 = _oracle_rows(bind, (w, h), rows, tex, fp64=False)                      # the pinned fp32 oracle, all pixels
-    e32 = np.stack([_norm_err(got[y], refs32[int(y)]) for y in rows])
-    assert _rmse(e32).max() <= 1e-4, _rmse(e32)
+    refs32 = _oracle_rows(bind, (w, h), rows, tex, fp64=False)                      # the pinned fp32 oracle
+    _p1_against_pinned(np.stack([got[y] for y in rows]), np.stack([refs32[int(y)] for y in rows]),
+                       np.stack([refs[int(y)] for y in rows]), "config 3 (4K, 4 lights, r = 0.25), 8 rows")
     # lights x 2 (the sun off): the punctual-light part of the frame doubles
     scene["uniforms"].sun_intensity = (C.c_float * 3)(0.0, 0.0, 0.0)
     dark = OpaquePyramid(w, h, r.device)      # a black backdrop and no emission: only the lights are left
@@ -586,9 +622,14 @@ def test_many_lights_long_and_ragged_lists(renderer, ggx_lut):
     torch.cuda.synchronize()
     _, want_t = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8, fp64=True)
     _, want_o, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
-    for got, want, what in ((t32.cpu().numpy(), want_t, "transmission"), (o32.cpu().numpy(), want_o, "opaque")):
+    _, pin_t = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8)
+    _, pin_o, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8)
+    for got, want, pin, what in ((t32.cpu().numpy(), want_t, pin_t, "transmission"), (o32.cpu().numpy(), want_o, pin_o, "opaque")):
         e = _norm_err(got, want)                 # every pixel: the cluster index is bit-exact, so the lists agree
         assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (what, _rmse(e), np.abs(e).max())
+        # (a hundred lights per pixel: a hundred highlight peaks per pixel — the ill-conditioned set grows with the
+        #  number of light evaluations: 0.2 % of this frame)
+        _p1_against_pinned(got, pin, want, f"many lights, assigned lists: {what}", max_ill_fraction=5e-3)
 
 
 def test_borrowed_tables_counting_past_the_list_capacity(renderer, ggx_lut):
@@ -623,9 +664,12 @@ def test_borrowed_tables_counting_past_the_list_capacity(renderer, ggx_lut):
     b = oracle.SceneBinding(clamped, ggx_lut)
     _, want_t = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8, fp64=True)
     _, want_o, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
-    for got, want, what in ((t32.cpu().numpy(), want_t, "transmission"), (o32.cpu().numpy(), want_o, "opaque")):
+    _, pin_t = oracle.shade_transmission(b, scene["gbuffer"], tex, nthreads=8)
+    _, pin_o, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8)
+    for got, want, pin, what in ((t32.cpu().numpy(), want_t, pin_t, "transmission"), (o32.cpu().numpy(), want_o, pin_o, "opaque")):
         e = _norm_err(got, want)
         assert _rmse(e).max() <= 1e-4 and np.abs(e).max() <= 5e-3, (what, _rmse(e), np.abs(e).max())
+        _p1_against_pinned(got, pin, want, f"borrowed tables past the capacity: {what}")
 
 
 def test_8k_frame_bands_and_oracle_rows(renderer, ggx_lut):
@@ -657,11 +701,15 @@ def test_8k_frame_bands_and_oracle_rows(renderer, ggx_lut):
     bind = oracle.SceneBinding(scene, ggx_lut)
     tex = pyr.texels.cpu().numpy()
     got = a.cpu().numpy().astype(np.float32)
-    errs = []
+    errs, rows32, rows64, rows_got = [], [], [], []
+    ref = np.zeros((h, w, 4), dtype=np.float16)
+    ref32 = np.zeros((h, w, 4), dtype=np.float16)
     for y in (0, 1234, 2159, 2160, 3333, 4319):
         band = synthetic.make_gbuffer(w, h, rows=(y, y + 1))
-        ref = np.zeros((h, w, 4), dtype=np.float16)
         oracle.shade_transmission(bind, band, tex, hdr_f16=ref, fp64=True)
         errs.append(_norm_err(got[y], ref[y].astype(np.float32)))
+        oracle.shade_transmission(bind, band, tex, hdr_f16=ref32)            # the pinned fp32 oracle, RTNE to RGBA16F
+        rows32.append(ref32[y].astype(np.float32)); rows64.append(ref[y].astype(np.float32)); rows_got.append(got[y])
     e = np.stack(errs)
     assert _rmse(e).max() <= 1e-4 and (np.abs(e) > 2e-3).mean() < 1e-4, (_rmse(e), np.abs(e).max())
+    _p1_against_pinned(np.stack(rows_got), np.stack(rows32), np.stack(rows64), "8K frame (RGBA16F), 6 rows")

@@ -99,6 +99,23 @@ def test_layers_bit_exact(renderer, w, h, cam):
           f"alpha-rim pixels {n0} + {n1}")
 
 
+def test_layers_bit_exact_1080p(renderer):
+    """BASELINE config 2's frame size: both rasterised layers (coverage, ids, depth, every attribute) against the oracle's,
+    bit for bit (alpha-clip rims counted as above)."""
+    w, h = 1920, 1080
+    view = wire.default_camera()[1]
+    geo = meshes.make_mesh_scene()
+    sc = _scene(w, h, view)
+    (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    got_o, got_t = _gpu_layers(renderer, geo, sc, w, h, culling)
+    budget = w * h // 20000
+    n0 = _compare(got_o, want_o, alpha_materials=(2,), max_rim_pixels=budget)
+    n1 = _compare(got_t, want_t, alpha_materials=(7, 2), max_rim_pixels=budget)
+    cov = want_o["material_id"] != wire.NOT_COVERED
+    assert cov.mean() > 0.2, cov.mean()
+    print(f"1080p: coverage {cov.mean():.2f} / {(want_t['material_id'] != wire.NOT_COVERED).mean():.2f}, alpha-rim pixels {n0} + {n1}")
+
+
 def test_layers_without_alpha_clip_are_bit_exact_everywhere(renderer):
     """Cutoff 0 switches every kill off: then there is no tolerance at all."""
     w, h = 512, 288
@@ -174,6 +191,15 @@ def test_rasterize_then_shade_end_to_end(renderer, ggx_lut):
     # pass flips ~25 texels of mip 0 by one half-precision step, everything downstream follows the oracle)
     assert rmse <= 1e-4, rmse
     assert np.quantile(np.abs(e), 0.999) <= 2e-3
+    # ... and the same chain through the PINNED fp32 oracle (its own mip 0 and pyramid), the ill-conditioned pixels counted
+    from test_gpu_parity import _p1_against_pinned
+    p16, _, pmip0 = oracle.shade_opaque(b, want_o, nthreads=8)
+    ptex = oracle.new_pyramid(w, h, pmip0)
+    oracle.generate_mips(w, h, ptex)
+    oracle.shade_transmission(b, want_t, ptex, hdr_f16=p16, nthreads=8)
+    pin = p16.astype(np.float64)
+    ok = fin & np.isfinite(pin).all(axis=2)
+    _p1_against_pinned(got, pin, want, "geometry -> frame (RGBA16F) vs oracle32", covered=ok)
 
 
 def test_raster_error_paths(ggx_lut):
@@ -352,3 +378,45 @@ def test_record_frame_from_visibility_words_untextured(ggx_lut):
         want = _stepwise_frame(r, sc, culling, view, q, aabbs, w, h)
         assert torch.equal(hdr.view(torch.int16), want.view(torch.int16))
         assert (hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
+
+
+@pytest.mark.parametrize("w,h", [(3840, 2160), (7680, 4320)])
+def test_record_frame_equals_the_stepwise_sequence_at_4k_and_8k(ggx_lut, tmp_path, w, h):
+    """BASELINE configs 4 / 5's frame sizes through the frame recorder (culling -> rasteriser -> visibility-word shading ->
+    mips -> transmissive -> tonemap in one native call) on the demo glTF: bit for bit the stepwise sequence through the
+    TGB-v1 planes (each step of which the other tests hold against the oracle)."""
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1] / "tools"))
+    import make_demo_gltf
+    from transmission_renderer_amd import gltf
+    from transmission_renderer_amd.renderer import OpaquePyramid, TransmissionRenderer
+    glb = str(tmp_path / "demo.glb")
+    make_demo_gltf.main(glb)
+    loaded = gltf.load_gltf(glb, base_transform=meshes.Similarity(np.array([0.0, 2.0, 0.0], np.float32), 1.0))
+    geo = loaded.geometry()
+    r = TransmissionRenderer(0)
+    try:
+        r.upload_ggx_lut(ggx_lut)
+        view = wire.default_camera()[1]
+        sc = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False)
+        sc["materials"], sc["textures"] = loaded.materials, loaded.textures
+        q = wire.view_rotation_inverse(view)
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+        r.upload_materials(sc["materials"])
+        r.upload_textures(sc["textures"])
+        r.upload_lights(sc["lights"])
+        r.upload_geometry(geo)
+        aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+        work = r.new_frame_buffers(w, h)
+        for _ in range(2):      # (the second frame starts from what the first left behind)
+            hdr, _ldr = r.record_frame(sc["uniforms"], sc["push"], culling, view, q, aabbs, work)
+            torch.cuda.synchronize()
+        got = hdr.clone()
+        del work, hdr, _ldr
+        torch.cuda.empty_cache()
+        want = _stepwise_frame(r, sc, culling, view, q, aabbs, w, h, torch.float16)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+        assert (got[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
+    finally:
+        r.close()
+        torch.cuda.empty_cache()

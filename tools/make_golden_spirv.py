@@ -1,14 +1,25 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/spirv_*.npz: outputs of the REFERENCE'S OWN compiled shaders
+"""Generates tests/golden/spirv_case_*.npz: outputs of the REFERENCE'S OWN compiled shaders
 (/root/reference/compiled-shaders/normal/{fragment,fragment_transmission}.spv) executed by
 oracle/spirv_ref/spirv_interp.py on seeded synthetic inputs.  Run in the authoring container only (the GPU box
 has no /root/reference); the committed fixtures hold inputs and expected outputs, never shader text or binaries.
 
-Fixed-function steps that the SPIR-V delegates to the Vulkan implementation (OpImageSample*) are answered by the
-oracle's restatement (o_sample_pyramid / o_sample_lut), so what the fixtures pin is everything else: every
-arithmetic instruction, its order, the control flow (cluster light loop) and the buffer layouts.
-Transcendentals go through the same libm the C oracle links (powf/logf/expf/log2f), so agreement is expected to
-be bit-exact when the operation order is the same.
+NO OUTPUT OF THE C ORACLE ENTERS A FIXTURE.  The fixed-function steps the SPIR-V delegates to the Vulkan implementation
+(OpImageSample*: texel filtering, implicit LOD) and the mip chains the samplers read are answered by
+oracle/spirv_ref/vk_sampling.py — a numpy fp32 statement of the Vulkan specification's equations, written from the
+specification, with the choices the specification leaves open (operation order, weight precision, half rounding) listed
+in its header — and OpDPdx / OpDPdy by the 2x2-quad differences below (Vulkan 1.3 "Derivative Operations", fine
+derivatives of a fully covered quad).  So a fixture is "the reference's binary + the Vulkan specification";
+tests/test_vk_sampling.py checks separately that the oracle's samplers are bit-identical to vk_sampling.
+Transcendentals go through glibc (powf/logf/expf/log2f), the library the reference's CPU-side Rust would call.
+
+cases a, b, c: every pixel of a 48x32 frame (2 lights; 4 lights + spotlights + ragged lists + roughness override;
+               every texture slot with holes).
+cases d, e:    2 000 random pixels of the BENCHMARK'S OWN frames at 3840x2160 — d: the headline scene (sun + 1 light),
+               e: BASELINE config 3 (sun + 4 lights, roughness override 0.25) — whose framebuffer-size-dependent terms
+               (lod = log2(3840) * r over a 12-level pyramid, 240x135-pixel clusters) the small frames never reach.  The
+               fixture holds the sampled pixels' inputs and outputs; the GPU test shades the whole 4K frame and compares
+               those pixels (tests/test_gpu_golden.py).
 """
 from __future__ import annotations
 
@@ -22,8 +33,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from oracle import oracle  # noqa: E402
 from oracle.spirv_ref import spirv_interp as si  # noqa: E402
+from oracle.spirv_ref import vk_sampling as vk  # noqa: E402
 from transmission_renderer_amd import synthetic, wire  # noqa: E402
 from transmission_renderer_amd.png import read_png_rgba8  # noqa: E402
 
@@ -78,32 +89,27 @@ def quad_derivs(g, x, y, eye):
     return d
 
 
-def run_module(name, scene, g, tex, lut, pixels, binding=None):
+def run_module(name, scene, g, levels, lut, pixels, textures=()):
+    """One invocation of entry point `name` per pixel.  levels: the opaque pyramid (vk.blit_chain_rgba16f); textures:
+    [(mip chain, srgb)] of the bindless array."""
     mod = si.Module(os.path.join(REF, name + ".spv"))
-    L = oracle.load()
-    w, h = g["width"], g["height"]
-    pyr = oracle.pyramid_struct(w, h, tex)
-    lut_p = lut.ctypes.data_as(C.c_void_p)
     lut_index = int(scene["uniforms"].ggx_lut_texture_index)
     cur = {}
 
     def sample(kind, image, sampler, coord, lod):
-        if image[0] == (3, 0):      # the opaque pyramid (set 3 binding 0), sample_by_lod
+        if image[0] == (3, 0):      # the opaque pyramid (set 3 binding 0), sample_by_lod through clamp_sampler
             assert kind == "lod"
-            v = L.o_sample_pyramid(C.byref(pyr), float(coord[0]), float(coord[1]), float(lod))
-            return [v.x, v.y, v.z, 1.0]
+            v = vk.sample_pyramid(levels, coord[0], coord[1], lod)
+            return [v[0], v[1], v[2], 1.0]
         assert image[0] == (0, 0) and kind == "implicit", (kind, image)
         if image[1] == lut_index and sampler[0] == (0, 4):   # clamp_sampler: the GGX LUT (single level)
-            v = L.o_sample_lut(lut_p, lut.shape[1], lut.shape[0], float(coord[0]), float(coord[1]))
-            return [v.x, v.y, 0.0, 1.0]
+            v = vk.sample_lut(lut, coord[0], coord[1])
+            return [v[0], v[1], 0.0, 1.0]
         # a material texture through `sampler` (set 0 binding 1): implicit LOD from the quad's uv derivatives
         assert sampler[0] == (0, 1), sampler
-        out = (C.c_float * 4)()
         d = cur["d"]
-        L.o_sample_texture(C.byref(binding.texture_structs[image[1]]), float(coord[0]), float(coord[1]),
-                           oracle.Vec2(float(d["duv_dx"][0]), float(d["duv_dx"][1])),
-                           oracle.Vec2(float(d["duv_dy"][0]), float(d["duv_dy"][1])), C.byref(out))
-        return list(out)
+        chain, srgb = textures[image[1]]
+        return list(vk.sample_texture(chain, srgb, coord[0], coord[1], d["duv_dx"], d["duv_dy"]))
 
     def derivative(op, value):
         d = cur["d"]
@@ -127,6 +133,60 @@ def run_module(name, scene, g, tex, lut, pixels, binding=None):
     return {k: np.stack(v) for k, v in outs.items()}, steps
 
 
+def scene_arrays(scene):
+    return dict(
+        materials=np.frombuffer(b"".join(bytes(m) for m in scene["materials"]), dtype=np.uint8),
+        lights=np.frombuffer(b"".join(bytes(l) for l in scene["lights"]), dtype=np.uint8),
+        uniforms=np.frombuffer(bytes(scene["uniforms"]), dtype=np.uint8),
+        push=np.frombuffer(bytes(scene["push"]), dtype=np.uint8),
+        cluster_counts=scene["cluster_counts"],
+        light_list=scene["light_indices"].reshape(-1, wire.MAX_LIGHTS_PER_CLUSTER)[0].copy())   # same in every cluster
+
+
+def sampled_4k_case(tag, lut, num_point_lights, roughness_override, n_pixels=2000):
+    """cases d / e: n random pixels of a benchmark frame at 3840x2160 (+ the frame's corners and a few pixels either side
+    of material and cluster borders), through both entry points."""
+    w, h = 3840, 2160
+    scene = synthetic.make_scene(w, h, num_point_lights=num_point_lights, roughness_override=roughness_override)
+    g = scene["gbuffer"]
+    mip0 = synthetic.make_opaque_mip0(w, h)
+    t0 = time.time()
+    levels = vk.blit_chain_rgba16f(mip0)
+    print(f"case {tag}: {len(levels)}-level pyramid of {w}x{h} in {time.time() - t0:.1f} s")
+    rng = np.random.default_rng({"d": 0xD, "e": 0xE}[tag])
+    ys = rng.integers(0, h, n_pixels - 40)
+    xs = rng.integers(0, w, n_pixels - 40)
+    pix = list(zip(ys.tolist(), xs.tolist()))
+    pix += [(0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1)]
+    mid = g["material_id"]
+    bx = np.argwhere(mid[:, 1:] != mid[:, :-1])                      # material borders: both sides
+    for k in rng.integers(0, len(bx), 9):
+        y, x = bx[k]
+        pix += [(int(y), int(x)), (int(y), int(x) + 1)]
+    for k in range(9):                                               # cluster borders in x (240 px wide at 4K): both sides
+        x = 240 * (k + 1)
+        y = int(rng.integers(0, h))
+        pix += [(y, x - 1), (y, x)]
+    pix = pix[:n_pixels]
+    t0 = time.time()
+    out_t, steps = run_module("fragment_transmission", scene, g, levels, lut, pix)
+    out_o, _ = run_module("fragment", scene, g, levels, lut, pix)
+    print(f"case {tag}: {len(pix)} px of {w}x{h}, {steps / len(pix):.0f} SPIR-V instructions / px (transmission), "
+          f"{time.time() - t0:.1f} s")
+    py = np.array([p[0] for p in pix]), np.array([p[1] for p in pix])
+    import hashlib
+    np.savez_compressed(
+        os.path.join(OUT, f"spirv_case_{tag}.npz"),
+        width=w, height=h, num_point_lights=num_point_lights,
+        roughness_override=np.float32(-1.0 if roughness_override is None else roughness_override),
+        pixels=np.array(pix, dtype=np.int32),
+        # the sampled pixels' inputs (the test regenerates the whole G-buffer with synthetic.make_gbuffer and checks these)
+        pos_depth=g["pos_depth"][py], nrm_scale=g["nrm_scale"][py], uv=g["uv"][py], material_id=g["material_id"][py],
+        opaque_mip0_sha256=np.frombuffer(hashlib.sha256(mip0.tobytes()).digest(), dtype=np.uint8),
+        spirv_fragment_transmission=out_t[0], spirv_fragment_hdr=out_o[0], spirv_fragment_opaque_sampled=out_o[1],
+        **scene_arrays(scene))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     lut = read_png_rgba8(os.path.join(ROOT, "transmission_renderer_amd", "assets", "ggx_lut.png"))
@@ -144,7 +204,7 @@ def main():
         if tag == "c":   # textures repeat a few times across the frame; the GGX LUT is texture 8 of the bindless array
             scene["gbuffer"]["uv"] *= np.float32(0.75)
             scene["uniforms"].ggx_lut_texture_index = len(scene["textures"])
-        binding = oracle.SceneBinding(scene, lut)
+        textures = [(vk.blit_chain_rgba8(img, srgb), srgb) for img, srgb in scene.get("textures", [])]
         if tag == "b":   # the reference's spotlight rig in the opaque pass; per-cluster lists of different length
             scene["lights"] = wire.default_lights(spotlights=True)
             counts, idx = synthetic.all_lights_cluster_tables(4)
@@ -152,25 +212,18 @@ def main():
             counts[:] = rng.integers(0, 5, counts.size)
             scene["cluster_counts"], scene["light_indices"] = counts, idx
         g = scene["gbuffer"]
-        tex = oracle.new_pyramid(w, h, synthetic.make_opaque_mip0(w, h))
-        oracle.generate_mips(w, h, tex)
+        levels = vk.blit_chain_rgba16f(synthetic.make_opaque_mip0(w, h))
         pixels = [(y, x) for y in range(h) for x in range(w)]
         t0 = time.time()
         if tag == "c":
             pixels = [(y, x) for (y, x) in pixels if g["material_id"][y, x] != wire.NOT_COVERED]
-        out_t, steps = run_module("fragment_transmission", scene, g, tex, lut, pixels, binding)
-        out_o, _ = run_module("fragment", scene, g, tex, lut, pixels, binding)
+        out_t, steps = run_module("fragment_transmission", scene, g, levels, lut, pixels, textures)
+        out_o, _ = run_module("fragment", scene, g, levels, lut, pixels, textures)
         print(f"case {tag}: {len(pixels)} px, {steps / len(pixels):.0f} SPIR-V instructions / px (transmission), "
               f"{time.time() - t0:.1f} s")
         np.savez_compressed(
             os.path.join(OUT, f"spirv_case_{tag}.npz"),
             width=w, height=h,
-            materials=np.frombuffer(b"".join(bytes(m) for m in scene["materials"]), dtype=np.uint8),
-            lights=np.frombuffer(b"".join(bytes(l) for l in scene["lights"]), dtype=np.uint8),
-            uniforms=np.frombuffer(bytes(scene["uniforms"]), dtype=np.uint8),
-            push=np.frombuffer(bytes(scene["push"]), dtype=np.uint8),
-            cluster_counts=scene["cluster_counts"],
-            light_list=scene["light_indices"].reshape(-1, wire.MAX_LIGHTS_PER_CLUSTER)[0].copy(),  # same in every cluster
             pos_depth=g["pos_depth"], nrm_scale=g["nrm_scale"], uv=g["uv"], material_id=g["material_id"],
             opaque_mip0=synthetic.make_opaque_mip0(w, h),
             pixels=np.array(pixels, dtype=np.int32),
@@ -179,7 +232,12 @@ def main():
             spirv_fragment_transmission=out_t[0],
             spirv_fragment_hdr=out_o[0],
             spirv_fragment_opaque_sampled=out_o[1],
+            **scene_arrays(scene),
         )
+    if not only or "d" in only:
+        sampled_4k_case("d", lut, 1, None)
+    if not only or "e" in only:
+        sampled_4k_case("e", lut, 4, 0.25)
 
 
 if __name__ == "__main__":

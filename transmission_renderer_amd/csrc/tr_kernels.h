@@ -1022,6 +1022,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
             }
             out = {out.x + m4->emission[0], out.y + m4->emission[1], out.z + m4->emission[2]};
         } else {
+            if constexpr (SCALAR_MATERIAL)   // (the lite class: its lights ran against the scalar record, see eval_light)
+                acc.s = {fmaf(m4->df[0], acc.sp.x, m4->f0[0] * acc.s.x), fmaf(m4->df[1], acc.sp.y, m4->f0[1] * acc.s.y),
+                         fmaf(m4->df[2], acc.sp.z, m4->f0[2] * acc.s.z)};
             f3 diffuse = {acc.d.x * mat_c_diff(mo, 0), acc.d.y * mat_c_diff(mo, 1), acc.d.z * mat_c_diff(mo, 2)};
             if (transmits) {
                 // ---- ibl_volume_refraction, part 2 (:337-353)
