@@ -224,6 +224,8 @@ struct tr_launch {
     const uint2* pyramid;
     void* hdr;
     uint2* mip0;
+    uint2* mip1;                        // optional (opaque launches of the frame recorder, even frame sizes): level 1 of the
+                                        // opaque pyramid, written from the 2x2 quads of the values this launch stores
     // textured materials only (shade_kernel<.., TEXTURED = true>)
     const float2* uv;
     const tr_material_info* materials;  // the raw records: factors and texture ids
@@ -1329,12 +1331,13 @@ struct tile_regs {
     uint32_t cover_front;                             // (scalar) VIS opaque: the transmissive layer's word of the tile
 };
 
-// The untextured transmissive variant fed from visibility words (67 registers left to itself) fits 64 without a spill
-// once the allocator is told that eight waves are wanted; every other variant is left to itself (forced up, the RGBA32F
-// variant and the textured classes spill, and scratch costs more than the waves give: DESIGN.md 3.1;
-// tests/test_kernel_resources.py holds the line).
+// Occupancy targets for the register allocator.  The untextured transmissive variant fed from visibility words fits 64
+// registers (8 waves) once told that eight waves are wanted; the full-class transmissive variant (97-100 left to itself:
+// 4 waves) fits 96 = 5 waves without a spill on planes, with two spilled registers when fed from visibility words.  Every
+// other variant is left to itself: forced up, the textured classes spill, and scratch costs more than the waves give
+// (tests/test_kernel_resources.py holds the line).
 #ifndef TR_WAVES_ATTR
-#define TR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((TEX == kTexNone && TRANSMISSIVE && VIS) ? 8 : 1)))
+#define TR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((TEX == kTexNone && TRANSMISSIVE && VIS) ? 8 : (TEX == kTexFull && TRANSMISSIVE && !VIS) ? 5 : 1)))
 #endif
 // TEX: which material classes the launch shades (the host launches what the uploaded materials need, see tr_shade.hip):
 //   0  no uploaded material has a texture slot: every material through the scalar record;
@@ -1621,6 +1624,35 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                     if (front != 0ull && !(__uint_as_float((uint32_t)(front >> 32)) > cur.pd.w))
                         st<unsigned long long>(V->vis_front, at, 0ull);
                 }
+            }
+        }
+        if constexpr (!TRANSMISSIVE && sizeof(OutT) == 8) {
+            // Level 1 of the opaque pyramid straight from the values being stored: for even sizes a LINEAR blit is the
+            // 2x2 box of the ROUNDED level-0 texels, (q00/4 + q10/4) + (q01/4 + q11/4) (box4 / the oracle), and a wave
+            // tile holds whole quads — the mip chain then never reads level 0 (66 of its 88 MB at 4K).  Tiles that also
+            // hold full-class fragments are left to the TEX = 2 launch, which reads the other lanes' texels back.
+            claunch* M = launder(L);
+            uint2* const mip1 = M->mip1;
+            bool tile_mine = mip1 != nullptr;
+            if constexpr (TEX == kTexLite) tile_mine = tile_mine && (cur.cover & 2u) == 0u;
+            if (tile_mine) {
+#pragma clang fp contract(off)
+                uint2 q = pack_rgba16f(out.x, out.y, out.z, 1.0f);
+                if constexpr (TEX == kTexFull) {
+                    const bool mine = ((shaded >> lane) & 1ull) != 0ull;
+                    if (!M->fp.solo_full && !mine && inside) q = ld<uint2>(M->mip0, mad24(cur.py, M->fp.width, cur.px) * 8u);
+                }
+                const float c[4] = {h2f_lo(q.x), h2f_hi(q.x), h2f_lo(q.y), h2f_hi(q.y)};
+                float s4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float partner = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c[k]), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]: lane ^ 1
+                    const float hsum = c[k] * 0.25f + partner * 0.25f;
+                    const float below = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(hsum), 0x401F));               // lane ^ 16
+                    s4[k] = hsum + below;
+                }
+                if ((lane & 17u) == 0u && inside)
+                    st<uint2>(mip1, mad24(cur.py >> 1, M->fp.width >> 1, cur.px >> 1) * 8u, pack_rgba16f(s4[0], s4[1], s4[2], s4[3]));
             }
         }
         if (write && !(TR_ABLATE(S, 128u) && out.x != 12345.0f)) {  // bit7: profiling, no stores

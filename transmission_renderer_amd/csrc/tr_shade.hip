@@ -103,6 +103,7 @@ struct tr_context {
     unsigned long long* vis_front_hint = nullptr;      // opaque VIS launches: the transmissive layer's words and coverage map
     const uint32_t* cover_front_hint = nullptr;        //   (a transmissive winner behind the opaque surface is zeroed there)
     const uint32_t* list_count_hint = nullptr;
+    void* mip1_hint = nullptr;                         // ... and level 1 of the opaque pyramid, for the opaque launches to write
     uint32_t* d_tile_list_counts = nullptr;            // (inside the d_vis allocation, cleared with the coverage maps)
     uint32_t* d_tile_list[2] = {nullptr, nullptr};     // per layer: the tiles
     size_t vis_pixels = 0;
@@ -501,6 +502,7 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.pyramid = nullptr;
     L.hdr = nullptr;
     L.mip0 = nullptr;
+    L.mip1 = nullptr;
     L.uv = (const float2*)g->uv;
     L.materials = ctx->d_materials_raw;
     L.textures = ctx->d_textures;
@@ -1309,6 +1311,7 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
         fill_launch(L, ctx, fp, g);
         L.hdr = hdr_out;
         L.mip0 = (uint2*)opaque_mip0_out;
+        L.mip1 = (L.vis && L.mip0 && format == TR_FORMAT_RGBA16F) ? (uint2*)ctx->mip1_hint : nullptr;   // (the frame recorder)
         const bool half = format == TR_FORMAT_RGBA16F;
         if (ctx->any_textured) {   // one launch per material class (see launch_textured)
             const tr_status ls = launch_textured<false>(ctx, L, g, half, grid, block, stream);
@@ -1321,12 +1324,16 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     return TR_OK;
 }
 
-tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* p, void* stream_) {
+}   // extern "C"
+namespace {
+// Levels first .. levels - 1 of the pyramid from level first - 1 (tr_generate_mips: first = 1; the frame recorder, whose
+// opaque launches have written level 1 themselves: first = 2).
+tr_status generate_mips_from(tr_context* ctx, const tr_pyramid* p, uint32_t first, void* stream_) {
     if (!ctx || !p || !p->texels || p->levels == 0 || p->levels > TR_MAX_MIP_LEVELS) return TR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     uint2* base = (uint2*)p->texels;
-    uint32_t l = 1;
+    uint32_t l = first;
     // (1) leading levels whose parent has even sizes: exact 2x2 boxes, up to five levels per launch from LDS
     while (l < p->levels) {
         const uint32_t ws = level_dim(p->width, l - 1), hs = level_dim(p->height, l - 1);
@@ -1378,6 +1385,10 @@ tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* p, void* stream_) 
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
+}  // namespace
+extern "C" {
+
+tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* p, void* stream) { return generate_mips_from(ctx, p, 1u, stream); }
 
 tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u,
                                 const tr_push_constants* pc, const tr_pyramid* p, void* hdr_inout, tr_format format,
@@ -1865,6 +1876,9 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         layers[k].origin_x = layers[k].origin_y = 0;
     }
     const tr_rect whole = {0u, 0u, w, h};
+    // Level 1 of the opaque pyramid comes out of the opaque launches themselves when they shade from visibility words and
+    // both frame sizes are even (then the blit is the 2x2 box of a wave tile's own quads): the mip chain starts at level 2.
+    const bool fused_level1 = use_vis && f->pyramid.levels >= 2u && (w & 1u) == 0u && (h & 1u) == 0u;
     {
         zone_scope z(rec, "main opaque");
         ctx->cover_hint = ctx->d_tile_cover[0];
@@ -1874,7 +1888,9 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->records_hint = ctx->d_records;
         ctx->vis_front_hint = use_vis ? ctx->d_vis[1] : nullptr;
         ctx->cover_front_hint = ctx->d_tile_cover[1];
+        ctx->mip1_hint = fused_level1 ? (void*)((uint2*)f->pyramid.texels + f->pyramid.level_offset[1]) : nullptr;
         st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
+        ctx->mip1_hint = nullptr;
         ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
         ctx->vis_hint = nullptr;
         ctx->records_hint = nullptr;
@@ -1884,7 +1900,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (st != TR_OK) return st;
     {
         zone_scope z(rec, "opaque framebuffer mipchain");
-        st = tr_generate_mips(ctx, &f->pyramid, stream);
+        st = generate_mips_from(ctx, &f->pyramid, fused_level1 ? 2u : 1u, stream);
     }
     if (st != TR_OK) return st;
     {
