@@ -5,7 +5,8 @@ metric   shaded Mpixels/s (+ p50 frame ms) of the 4K transmissive pass: `fragmen
          (shader/src/lib.rs:37-162) over a fully covered synthetic TGB-v1 G-buffer, DragonAttenuation's
          light rig (sun + 1 punctual light), RGBA16F target, inputs resident in HBM.
 step     one transmissive pass over one 3840x2160 frame (tr_shade_transmission) — at N > 1 followed by the
-         composite (tr_allgather_frame: RCCL all-gather of the row bands).
+         composite (tr_allgather_frame: RCCL all-gather of the row bands; by default of the frame AS PRESENTED: every
+         rank tonemaps its band to RGBA8 inside the step, `--composite-format rgba16f` gathers the HDR target instead).
 frames in flight (N = 1)   `--streams S` (default 2): the K frames of the timed region are independent (a renderer has
          S frames in flight: S colour targets), so step k is issued on HIP stream k mod S into target k mod S and the
          hardware starts frame k+1's waves in the wave slots frame k's stragglers leave empty — on ONE stream a launch
@@ -64,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--composite", choices=("overlap", "serial", "none"), default="overlap",
                     help="N > 1: how the composite all-gather enters the timed step")
+    ap.add_argument("--composite-format", choices=("rgba8", "rgba16f"), default="rgba8",
+                    help="N > 1: what is composited — rgba8: the frame as it is presented (every rank tonemaps its band with "
+                         "tr_tonemap inside the step, the 4 B/px bands are gathered); rgba16f: the HDR target itself (8 B/px)")
     ap.add_argument("--streams", type=int, default=2,
                     help="N = 1: frames in flight — step k goes to HIP stream k mod S and colour target k mod S (1: every "
                          "launch behind the previous one on one stream)")
@@ -347,6 +351,12 @@ def run_rank(args) -> int:
               for _ in range(2 if composite == "overlap" else n_streams)]
     uniforms, push = scene["uniforms"], scene["push"]
     rect = (0, y0, fw, y1)
+    # N > 1: what crosses the links.  rgba8 (default): the presented frame — the band is tonemapped (fragment_tonemap,
+    # shader/src/lib.rs:683-697, what the reference's last pass does before the swapchain) inside the step and the 8-bit
+    # bands are gathered: half the bytes per link of the RGBA16F target.
+    present_ldr = distributed and composite != "none" and args.composite_format == "rgba8"
+    ldr_frames = [torch.zeros((padded, fw, 4), dtype=torch.uint8, device=dev) for _ in frames] if present_ldr else None
+    tonemap_params = r.baked_tonemap_params() if present_ldr else None
     comp = sharded.Compositor(world, rank, renderer=r, single_rank_comm=args.rehearse_distributed) if distributed else None
     torch.cuda.synchronize()
 
@@ -362,6 +372,14 @@ def run_rank(args) -> int:
             r.shade_transmission(g, uniforms, push, pyr, buf, rect)
         launches["count"] += 1
 
+    def present(i):
+        """The band as it is presented: tonemapped into this rank's rows of the 8-bit frame; returns what is gathered."""
+        if not present_ldr:
+            return frames[i]
+        if y1 > y0:
+            r.tonemap(frames[i][y0:y1], tonemap_params, out=ldr_frames[i][y0:y1])
+        return ldr_frames[i]
+
     def step(k):
         """One step of the metric: this rank's band of the frame (+ the composite, N > 1)."""
         i = k % len(frames)
@@ -370,10 +388,11 @@ def run_rank(args) -> int:
             if gathered[i] is not None:
                 compute.wait_event(gathered[i])        # the buffer's previous composite has left it
             shade(buf)
+            out_buf = present(i)
             shaded[i].record(compute)
             with torch.cuda.stream(comm):
                 comm.wait_event(shaded[i])
-                comp.allgather_rows(buf)
+                comp.allgather_rows(out_buf)
                 ev = torch.cuda.Event()
                 ev.record(comm)
                 gathered[i] = ev
@@ -383,7 +402,7 @@ def run_rank(args) -> int:
         else:
             shade(buf)
             if composite == "serial":
-                comp.allgather_rows(buf)
+                comp.allgather_rows(present(i))
 
     # Untimed warm-up: W steps — and before them, as many band launches as it takes to have kept the GPU busy for
     # 50 ms: its clocks ramp over the first ~10 ms of load (the first ~70 back-to-back 4K launches run 10-15 % slow),
@@ -568,7 +587,11 @@ def run_rank(args) -> int:
                        "pixels_per_step": pixels_step, "pixels_per_gpu": pixels_rank,
                        "sharding": f"{world} row band(s) of {rows_per_rank} rows (tr_band_rows)",
                        "composite": ("none (one GPU holds the frame)" if not distributed else
-                                     f"{composite}: {comp.backend}")},
+                                     f"{composite}: {comp.backend}"
+                                     + ("" if composite == "none" else
+                                        ", of the frame as presented: every rank tonemaps its band (tr_tonemap) inside the step and "
+                                        "the RGBA8 bands (4 B/px) are gathered" if present_ldr else
+                                        ", of the RGBA16F HDR target (8 B/px)"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "tr::shade_kernel<true, uint2, 0, false>", "avg_kernel_ms": round(kernel_ms, 4),

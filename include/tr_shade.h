@@ -576,6 +576,24 @@ int32_t   tr_comm_last_error(const tr_comm* comm);
 tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame_dev, uint32_t width, uint32_t rows_per_rank,
                              tr_format format, void* stream);
 
+/* Rank-interleaved strips, for frames whose cost is uneven over the screen (sky above, geometry below: contiguous bands
+ * leave the ranks of the sky idle): the frame is cut into strips of `strip_rows` rows (a multiple of 4; 64 is a good
+ * size), strip s belongs to rank s % nranks.  After tr_set_strips, tr_shade_opaque / tr_shade_transmission called with a
+ * rect that spans the whole frame height (and G-buffer planes that cover it) shade THIS RANK'S STRIPS in one launch
+ * each, in place: colour targets are whole-frame buffers and every strip lands at its own rows.  tr_set_strips(ctx, 0,
+ * 1, 0) turns it off.  Not combined with full-class textured materials' plane launches or tr_record_frame
+ * (TR_ERR_UNSUPPORTED).  SURVEY.md 8e; the reference is single-GPU (src/main.rs:243). */
+tr_status tr_set_strips(tr_context* ctx, uint32_t strip_rows, uint32_t nranks, uint32_t rank);
+/* Host only: rows [*y0, *y1) of the k-th strip of `rank` (strip k * nranks + rank of the frame), clipped to the frame;
+ * y0 == y1 once the rank has no k-th strip. */
+tr_status tr_strip_of_rank(uint32_t height, uint32_t strip_rows, uint32_t nranks, uint32_t rank, uint32_t k, uint32_t* y0,
+                           uint32_t* y1);
+/* The composite (and the level-0 exchange) of a strip-sharded frame: `frame_dev` is the whole frame (`height` rows of
+ * `width` pixels of `format`), every rank has written its own strips in place; on return (stream order) every strip is
+ * everywhere.  One RCCL group of in-place broadcasts, one per strip, rooted at the strip's rank.  Call it on every rank. */
+tr_status tr_allgather_strips(tr_context* ctx, tr_comm* comm, void* frame_dev, uint32_t width, uint32_t height,
+                              uint32_t strip_rows, tr_format format, void* stream);
+
 /* ------------------------------------------------------------------ tonemap */
 
 /* Host only: Lottes' curve constants from the un-baked parameters (what colstodian's

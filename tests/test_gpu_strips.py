@@ -1,0 +1,190 @@
+"""Rank-interleaved strips ("interleaved 64-row strips") on the one GPU of the test box (run with -m gpu):
+tr_set_strips makes whole-frame tr_shade_opaque / tr_shade_transmission calls shade one rank's strips in place; every
+"rank" is played in turn by the same context on the same frame buffers, and the result must be the single-launch frame
+bit for bit, each rank touching nothing but its own strips.  The N-process exchange is covered on CPU over gloo
+(tests/test_sharding_cpu.py); tr_allgather_strips runs here through a one-rank RCCL communicator."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from transmission_renderer_amd import sharded, synthetic, wire  # noqa: E402
+from test_gpu_parity import _upload_scene  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def renderer(ggx_lut):
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device: the -m gpu tests must run on the GPU box")
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    r = TransmissionRenderer(0)
+    r.upload_ggx_lut(ggx_lut)
+    yield r
+    r.close()
+
+
+def _whole_frame(r, scene, g, w, h):
+    from transmission_renderer_amd.renderer import OpaquePyramid
+    pyr = OpaquePyramid(w, h, r.device)
+    hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+    r.record(g, g, scene["uniforms"], scene["push"], hdr, pyr)
+    torch.cuda.synchronize()
+    return hdr, pyr
+
+
+@pytest.mark.parametrize("w,h,world,strip_rows,coverage", [
+    (256, 200, 3, 16, "holes"),     # short last strip (200 = 12 * 16 + 8), uneven strip counts per rank
+    (320, 136, 2, 64, "full"),      # 3 strips on 2 ranks, the last one 8 rows
+    (130, 44, 8, 4, "holes"),       # ragged right edge, strips of one tile row, ranks 3..7 own a single strip
+    (64, 12, 8, 4, "full"),         # more ranks than strips: ranks 3..7 own nothing
+])
+def test_strips_in_place_equal_whole_frame(renderer, w, h, world, strip_rows, coverage):
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    scene = synthetic.make_scene(w, h, num_point_lights=2, coverage=coverage)
+    _upload_scene(r, scene)
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    full, full_pyr = _whole_frame(r, scene, g, w, h)
+
+    sentinel = -7.0
+    hdr = torch.full((h, w, 4), sentinel, dtype=torch.float16, device=r.device)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.level(0).fill_(sentinel)
+    rect = (0, 0, w, h)
+    owner = np.full(h, -1)
+    for rank in range(world):
+        for y0, y1 in sharded.strips_of_rank(h, strip_rows, world, rank):
+            owner[y0:y1] = rank
+    assert (owner >= 0).all()
+    try:
+        for rank in range(world):                                           # the opaque pass of every "rank"
+            r.set_strips(strip_rows, world, rank)
+            before = hdr.clone()
+            if sharded.strips_of_rank(h, strip_rows, world, rank):
+                r.shade_opaque(g, scene["uniforms"], scene["push"], hdr, pyr, rect)
+            torch.cuda.synchronize()
+            other = torch.from_numpy(owner != rank).to(r.device)
+            assert torch.equal(hdr[other].view(torch.int16), before[other].view(torch.int16)), f"rank {rank} wrote outside its strips"
+            assert bool((hdr[~other] != sentinel).any()) or not bool((~other).any())
+        r.set_strips(0, 1, 0)
+        assert torch.equal(pyr.level(0).view(torch.int16), full_pyr.level(0).view(torch.int16))   # = the level-0 exchange's result
+        r.generate_mips(pyr)
+        for rank in range(world):
+            r.set_strips(strip_rows, world, rank)
+            if sharded.strips_of_rank(h, strip_rows, world, rank):
+                r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr, rect)
+    finally:
+        r.set_strips(0, 1, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(hdr.cpu().numpy().view(np.uint16), full.cpu().numpy().view(np.uint16))
+
+
+def test_strips_4k_eight_ranks(renderer):
+    """BASELINE config 4's frame cut into 64-row strips for 8 ranks: the transmissive pass of every rank in place ==
+    the whole-frame launch, bit for bit."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    w, h = 3840, 2160
+    scene = synthetic.make_scene(w, h, num_point_lights=1)
+    _upload_scene(r, scene)
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.level(0).copy_(torch.rand((h, w, 4), device=r.device).to(torch.float16))
+    r.generate_mips(pyr)
+    base = torch.rand((h, w, 4), device=r.device).to(torch.float16)
+    full = base.clone()
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, full)
+    got = base.clone()
+    try:
+        for rank in range(8):
+            r.set_strips(64, 8, rank)
+            r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, got, (0, 0, w, h))
+    finally:
+        r.set_strips(0, 1, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), full.view(torch.int16))
+
+
+def test_strips_lite_textured_and_refusals(ggx_lut):
+    """Strips work for the lite textured class (quads stay whole: strips are multiples of 4 rows); the full-class tile
+    list numbers the rect's tiles, so full-class materials are refused, and so is a rect that is not the frame."""
+    from transmission_renderer_amd import _lib
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer
+    r = TransmissionRenderer(0)
+    r.upload_ggx_lut(ggx_lut)
+    w, h = 192, 104
+    scene = synthetic.make_scene(w, h, num_point_lights=2, coverage="holes", textured=True)
+    scene["gbuffer"]["uv"] *= np.float32(1.5)
+    r.upload_textures(synthetic.make_textures())
+    full_class = list(scene["materials"])
+    lite = []
+    for m in full_class:                           # keep the base colour only, dielectric: the lite class
+        m2 = type(m).from_buffer_copy(bytes(m))
+        m2.metallic_factor = 0.0
+        t = m2.textures
+        t.metallic_roughness = t.normal_map = t.emissive = t.occlusion = t.transmission = t.thickness = -1
+        t.specular = t.specular_colour = -1
+        lite.append(m2)
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    try:
+        for mats, ok in ((lite, True), (full_class, False)):
+            scene["materials"] = mats
+            _upload_scene(r, scene)
+            full, _ = _whole_frame(r, scene, g, w, h)
+            hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
+            pyr = OpaquePyramid(w, h, r.device)
+            if not ok:
+                r.set_strips(8, 2, 0)
+                with pytest.raises(_lib.TrError) as e:
+                    r.shade_opaque(g, scene["uniforms"], scene["push"], hdr, pyr, (0, 0, w, h))
+                assert e.value.status == 6            # TR_ERR_UNSUPPORTED
+                r.set_strips(0, 1, 0)
+                continue
+            for rank in range(3):
+                r.set_strips(8, 3, rank)
+                r.shade_opaque(g, scene["uniforms"], scene["push"], hdr, pyr, (0, 0, w, h))
+            r.set_strips(0, 1, 0)
+            r.generate_mips(pyr)
+            for rank in range(3):
+                r.set_strips(8, 3, rank)
+                r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr, (0, 0, w, h))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(hdr.cpu().numpy().view(np.uint16), full.cpu().numpy().view(np.uint16))
+            r.set_strips(8, 3, 1)
+            with pytest.raises(_lib.TrError) as e:      # with strips in force the rect is the whole frame height
+                r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr, (0, 8, w, h))
+            assert e.value.status == 1
+            r.set_strips(0, 1, 0)
+        with pytest.raises(_lib.TrError):               # strips are whole tile rows; the rank is below the world size
+            r.set_strips(6, 2, 0)
+        with pytest.raises(_lib.TrError):
+            r.set_strips(8, 2, 2)
+    finally:
+        r.set_strips(0, 1, 0)
+        r.close()
+
+
+def test_allgather_strips_one_rank_communicator():
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    r = TransmissionRenderer(0)
+    lib = r.lib
+    ident = (C.c_uint8 * 128)()
+    assert lib.tr_comm_unique_id(C.byref(ident)) == 0
+    comm = C.c_void_p()
+    assert lib.tr_comm_create(r._ctx, C.byref(ident), 1, 0, C.byref(comm)) == 0 and comm.value
+    rng = np.random.default_rng(3)
+    stream = torch.cuda.current_stream().cuda_stream
+    for dt, fmt in ((torch.float16, wire.FORMAT_RGBA16F), (torch.float32, wire.FORMAT_RGBA32F)):
+        frame = torch.from_numpy(rng.random((42, 40, 4), dtype=np.float32)).to(r.device).to(dt)
+        want = frame.clone()
+        assert lib.tr_allgather_strips(r._ctx, comm, frame.data_ptr(), 40, 42, 8, fmt, stream) == 0   # 6 strips, the last 2 rows
+        torch.cuda.synchronize()
+        assert torch.equal(frame, want)
+    assert lib.tr_allgather_strips(r._ctx, comm, None, 40, 42, 8, wire.FORMAT_RGBA16F, stream) == 1
+    assert lib.tr_allgather_strips(r._ctx, comm, frame.data_ptr(), 40, 42, 0, wire.FORMAT_RGBA16F, stream) == 1
+    assert lib.tr_comm_destroy(comm) == 0
+    r.close()

@@ -32,6 +32,21 @@ def test_band_rows():
         sharded.band_rows(100, 4, 4)
 
 
+def test_strips_of_rank():
+    # strip s of the frame belongs to rank s % world; the last strip of the frame may be short
+    assert sharded.strips_of_rank(2160, 64, 8, 0) == [(0, 64), (512, 576), (1024, 1088), (1536, 1600), (2048, 2112)]
+    assert sharded.strips_of_rank(2160, 64, 8, 1)[-1] == (2112, 2160)             # 2160 = 33 * 64 + 48
+    assert sharded.strips_of_rank(2160, 64, 8, 2)[-1] == (1664, 1728) and len(sharded.strips_of_rank(2160, 64, 8, 7)) == 4
+    for h in (1, 5, 42, 130, 1080, 2160):
+        for rows in (4, 16, 64):
+            for n in (1, 2, 3, 8):
+                got = sorted(s for r in range(n) for s in sharded.strips_of_rank(h, rows, n, r))
+                assert got[0][0] == 0 and got[-1][1] == h and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+                assert all(y1 - y0 == rows for y0, y1 in got[:-1])
+    with pytest.raises(ValueError):
+        sharded.strips_of_rank(100, 16, 4, 4)
+
+
 def test_synthetic_scene_is_deterministic_and_band_sliceable():
     a = synthetic.make_gbuffer(160, 90)
     b = synthetic.make_gbuffer(160, 90)
@@ -68,6 +83,10 @@ class _OraclePyramid:
     def level0_padded(self):
         return self.level0
 
+    def level(self, k):
+        assert k == 0
+        return self.level0[:self.h]
+
 
 class _OracleRenderer:
     """Stands in for TransmissionRenderer in sharded.record_sharded: the same three calls, answered by the CPU
@@ -76,10 +95,30 @@ class _OracleRenderer:
     def __init__(self, binding):
         self.binding = binding
         self.calls = []
+        self.strips = None
+
+    def set_strips(self, strip_rows, world, rank):
+        self.strips = (strip_rows, world, rank) if strip_rows and world > 1 else None
+
+    def _rects(self, rect):
+        """What a whole-frame call shades: the rect, or with tr_set_strips in force this rank's strips of it."""
+        if self.strips is None:
+            return [rect]
+        assert rect[1] == 0
+        return [(rect[0], y0, rect[2], y1) for y0, y1 in sharded.strips_of_rank(rect[3], *self.strips)]
 
     def shade_opaque(self, g, uniforms, push, hdr, pyramid, rect):
+        if self.strips is not None:
+            self.calls.append(("opaque", rect))
+            for r in self._rects(rect):
+                self._shade_opaque(g, hdr, pyramid, r)
+            return
+        self._shade_opaque(g, hdr, pyramid, rect, log=True)
+
+    def _shade_opaque(self, g, hdr, pyramid, rect, log=False):
         from oracle import oracle
-        self.calls.append(("opaque", rect))
+        if log:
+            self.calls.append(("opaque", rect))
         hdr16, _, mip0 = oracle.shade_opaque(self.binding, g, rect=rect)
         y0, y1 = rect[1], rect[3]
         hdr[y0:y1] = torch.from_numpy(hdr16[y0:y1])
@@ -95,10 +134,11 @@ class _OracleRenderer:
         from oracle import oracle
         self.calls.append(("transmission", rect))
         frame = hdr[:pyramid.h].numpy()                                   # shares memory: shaded in place (LOAD)
-        oracle.shade_transmission(self.binding, g, pyramid.tex, hdr_f16=frame, rect=rect)
+        for r in self._rects(rect):
+            oracle.shade_transmission(self.binding, g, pyramid.tex, hdr_f16=frame, rect=r)
 
 
-def _worker(rank, world, port, w, h, out_dir):
+def _worker(rank, world, port, w, h, out_dir, strip_rows=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -109,6 +149,20 @@ def _worker(rank, world, port, w, h, out_dir):
         lut = read_png_rgba8(os.path.join(root, "transmission_renderer_amd", "assets", "ggx_lut.png"))
         scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False)
         binding = oracle.SceneBinding(scene, lut)
+        if strip_rows:                                                    # rank-interleaved strips of whole-frame buffers
+            g = synthetic.make_gbuffer(w, h)
+            hdr = torch.full((h, w, 4), -7.0, dtype=torch.float16)        # (a sentinel no pass writes)
+            pyr = _OraclePyramid(w, h, h)
+            fake = _OracleRenderer(binding)
+            comp = sharded.Compositor(world, rank)
+            sharded.record_sharded_strips(fake, g, g, scene["uniforms"], scene["push"], hdr, pyr, comp, strip_rows=strip_rows,
+                                          composite=True)
+            assert fake.strips is None                                    # switched off again
+            mine = sharded.strips_of_rank(h, strip_rows, world, rank)
+            assert [c[0] for c in fake.calls] == (["opaque", "mips", "transmission"] if mine else ["mips"])
+            np.save(os.path.join(out_dir, f"frame_{rank}.npy"), hdr.numpy())
+            np.save(os.path.join(out_dir, f"mip0_{rank}.npy"), pyr.level0[:h].numpy())
+            return
         rows, y0, y1 = sharded.band_rows(h, world, rank)
         band = synthetic.make_gbuffer(w, h, rows=(y0, y1))            # this rank's tile only
         hdr = torch.zeros((rows * world, w, 4), dtype=torch.float16)  # padded: equal bands for the gathers
@@ -140,6 +194,28 @@ def test_record_sharded_over_gloo_matches_single_rank(tmp_path, ggx_lut, w, h, w
     binding = oracle.SceneBinding(scene, ggx_lut)
     hdr16, _, mip0 = oracle.shade_opaque(binding, scene["gbuffer"])
     np.testing.assert_array_equal(np.load(tmp_path / "mip0_0.npy").view(np.uint16), mip0.view(np.uint16))
+    tex = oracle.new_pyramid(w, h, mip0)
+    oracle.generate_mips(w, h, tex)
+    oracle.shade_transmission(binding, scene["gbuffer"], tex, hdr_f16=hdr16)
+    np.testing.assert_array_equal(frames[0].view(np.uint16), hdr16.view(np.uint16))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("w,h,world,strip_rows", [(64, 40, 2, 8), (48, 42, 3, 4), (40, 10, 3, 8)])
+def test_record_sharded_strips_over_gloo_matches_single_rank(tmp_path, ggx_lut, w, h, world, strip_rows):
+    """sharded.record_sharded_strips on `world` gloo ranks: strip s shaded by rank s % world in place, level 0 and the
+    frame exchanged strip by strip; every rank ends with the single-rank frame bit for bit (incl. a short last strip and
+    a rank with no strip at all)."""
+    from oracle import oracle
+    mp.spawn(_worker, args=(world, _free_port(), w, h, str(tmp_path), strip_rows), nprocs=world, join=True)
+    frames = [np.load(tmp_path / f"frame_{r}.npy") for r in range(world)]
+    for f in frames[1:]:
+        np.testing.assert_array_equal(frames[0].view(np.uint16), f.view(np.uint16))
+    scene = synthetic.make_scene(w, h, num_point_lights=2)
+    binding = oracle.SceneBinding(scene, ggx_lut)
+    hdr16, _, mip0 = oracle.shade_opaque(binding, scene["gbuffer"])
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"mip0_{r}.npy").view(np.uint16), mip0.view(np.uint16))
     tex = oracle.new_pyramid(w, h, mip0)
     oracle.generate_mips(w, h, tex)
     oracle.shade_transmission(binding, scene["gbuffer"], tex, hdr_f16=hdr16)

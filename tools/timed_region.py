@@ -7,6 +7,8 @@ import csv, json, statistics as st, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "shade_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+t0s = [int(r["Start_Timestamp"]) / 1e3 for r in rows]
+t1s = [int(r["End_Timestamp"]) / 1e3 for r in rows]
 b = json.load(open(sys.argv[2]))
 r = lambda x: round(x, 2)
 out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py (tools/prof_round.sh), kernel tr::shade_kernel<true, uint2, 0, false>; durations in us",
@@ -15,9 +17,15 @@ out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py (tools/pr
 pos = 0
 for phase, count in b["launch_log"]:
     seg = d[pos:pos + count]
-    pos += count
     if seg:
-        out["phases"][phase] = {"launches": len(seg), "avg": r(st.mean(seg)), "p50": r(st.median(seg)), "min": r(min(seg)), "max": r(max(seg))}
+        # span_per_launch: (last end - first start) / launches of the phase — with S frames in flight the launches of
+        # different streams overlap, a launch's own start-to-end duration ("avg") is then ~S x the time per frame
+        span = (max(t1s[pos:pos + count]) - min(t0s[pos:pos + count])) / len(seg)
+        out["phases"][phase] = {"launches": len(seg), "avg": r(st.mean(seg)), "p50": r(st.median(seg)), "min": r(min(seg)), "max": r(max(seg)),
+                                "span_per_launch": r(span)}
+    pos += count
 out["timed_region"] = dict(out["phases"].get("timed", {}), note="the K back-to-back launches bench.py times (dispatch latency of a dependent launch is inside these durations)")
-out["bench_line"] = {"avg_kernel_ms": b["roofline"]["avg_kernel_ms"], "frac": b["roofline"]["frac"], "value": b["value"]}
+out["bench_line"] = {"avg_kernel_ms": b["roofline"]["avg_kernel_ms"], "frac": b["roofline"]["frac"], "value": b["value"],
+                     "streams": b["roofline"].get("streams", 1), "kernel_ms_on_its_stream": b["roofline"].get("kernel_ms_on_its_stream"),
+                     "single_stream_avg_kernel_ms": b.get("single_stream", {}).get("avg_kernel_ms")}
 print(json.dumps(out, indent=1))

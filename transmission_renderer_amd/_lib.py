@@ -24,7 +24,7 @@ SYMBOLS = (
     "tr_basic_brdf", "tr_transmission_btdf", "tr_ibl_volume_refraction", "tr_light_direction_and_attenuation", "tr_d_ggx",
     "tr_v_smith_ggx_correlated", "tr_fresnel_schlick", "tr_compute_f0", "tr_get_depth_slice", "tr_depth_slice_thresholds",
     "tr_band_rows", "tr_comm_unique_id", "tr_comm_create", "tr_comm_from_nccl", "tr_comm_destroy", "tr_comm_last_error",
-    "tr_allgather_frame",
+    "tr_allgather_frame", "tr_set_strips", "tr_strip_of_rank", "tr_allgather_strips",
 )
 
 _lib = None
@@ -139,6 +139,12 @@ def load() -> C.CDLL:
     lib.tr_comm_last_error.argtypes = [vp]
     lib.tr_allgather_frame.restype = i32
     lib.tr_allgather_frame.argtypes = [vp, vp, vp, u32, u32, i32, vp]
+    lib.tr_set_strips.restype = i32
+    lib.tr_set_strips.argtypes = [vp, u32, u32, u32]
+    lib.tr_strip_of_rank.restype = i32
+    lib.tr_strip_of_rank.argtypes = [u32, u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+    lib.tr_allgather_strips.restype = i32
+    lib.tr_allgather_strips.argtypes = [vp, vp, vp, u32, u32, u32, i32, vp]
     lib.tr_ibl_volume_refraction.restype = i32
     lib.tr_ibl_volume_refraction.argtypes = [vp, vp, u32, C.POINTER(wire.Pyramid), vp, vp]
     if lib.tr_abi_version() != 1:

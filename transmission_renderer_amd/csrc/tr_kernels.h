@@ -118,15 +118,21 @@ struct alignas(16) tr_dmat {
     // X = diffuse * ((1 - (f0 A + f90 B)) T + bt_a * sum_ta - bt_b * sum_tb), so
     //   out = kd * sum_d + kt * (1 - (f0 A + f90 B)) T + kta * sum_ta - ktb * sum_tb + specular + emission
     float kd[3];           // c_diff * (1 - tf)
-    float f0_max;          // max(f0): the channel whose Fresnel term is the largest at every angle, and
+    float omf0_max;        // 1 - max(f0): the channel whose Fresnel term is the largest at every angle, and
     float kt[3];           // tf^2 * diffuse
-    float df_min;          //   f90 - max(f0)
+    float ndf_min;         //   -(f90 - max(f0)):  1 - max(F) = omf0_max + ndf_min * p
     float kta[3];          // tf^2 * diffuse * bt_a
     float _pad3;
     float ktb[3];          // tf^2 * diffuse * bt_b
     float _pad4;
+    // The basic_brdf lobe is accumulated without its constant k[0] = a2 / 2 pi, like the btdf lobe (bt_a, bt_b): the
+    // per-pixel resolve  specular = f0 * sum(I nol D*V) + (f90 - f0) * sum(I nol D*V p)  reads k[0] folded into both
+    float ks_f0[3];        // k[0] * f0
+    float _pad5;
+    float ks_df[3];        // k[0] * (f90 - f0)
+    float _pad6;
 };
-static_assert(sizeof(tr_dmat) == 240, "digested material is 240 B");
+static_assert(sizeof(tr_dmat) == 272, "digested material is 272 B");
 
 // Light as the kernels read it: the reference's 48-byte record (shared-structs/src/lib.rs:70-78)
 // with the per-light constants of spotlight_factor (:129-138) digested at upload.
@@ -186,6 +192,9 @@ struct tr_frame_params {
     uint32_t tiles_x_magic;      // floor(2^32 / tiles_x): tile / tiles_x on the scalar unit (one fix-up step)
     uint32_t stripe_tiles;       // VIS launches: block tiles per stripe of kStripeTileRows tile rows, and
     uint32_t stripe_magic;       // floor(2^32 / stripe_tiles)
+    // Rank-interleaved strips (tr_set_strips; 0 tile rows = off): the rect is the frame, tile row r of the launch is the
+    // frame's tile row ((r / T) * world + rank) * T + r % T — strip k of this rank is strip k * world + rank of the frame
+    uint32_t strip_tile_rows, strip_magic /* floor(2^32 / T) */, strip_world, strip_rank;
     float lut_wf;                // (float)lut_width
     uint32_t lut_stride;         // pair-table stride in entries (= lut_width + 2)
     uint32_t lut_height;
@@ -331,6 +340,21 @@ __device__ __forceinline__ float clamp_eps(float x) {
     return r;
 }
 
+// -max(-x, eps) = min(x, -eps): the clamped dot product of the mirrored light with its sign left on (one instruction; the
+// negation is a free source modifier where the value is used)
+__device__ __forceinline__ float neg_clamp_eps(float x) {
+    float r;
+    asm("v_min_f32_e32 %0, 0xb4000000, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// 1 - max(a * b, eps) = min(1 - a * b, 1 - eps)  (1 - 2^-23 is a float): one fused multiply-add and one min instead of
+// multiply, max, subtract; NaN gives 1 - eps on both sides
+__device__ __forceinline__ float one_minus_clamped(float a, float b) {
+    float r;
+    const float t = fmaf(-a, b, 1.0f);
+    asm("v_min_f32_e32 %0, 0x3f7ffffe, %1" : "=v"(r) : "v"(t));
+    return r;
+}
 // ------------------------------------------------------------------------ one light
 // Accumulators of one pixel over its lights.
 struct light_acc {
@@ -377,9 +401,9 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
     // |v+l|^2 = 2 + 2 v.l (|v| = |l| = 1) vanishes where v = -l; rounding can push it below zero: floor it.
     {
         const float inv_h = rsq(fmaxf(fmaf(2.0f, vl, 2.0f), 1e-12f));
-        const float voh = clamp_eps((1.0f + vl) * inv_h);          // Dot::new clamps to EPSILON (:93-98)
+        const float omv = one_minus_clamped(1.0f + vl, inv_h);     // 1 - v.h, v.h clamped to EPSILON by Dot::new (:93-98)
         const float nol = clamp_eps(nl_raw);
-        const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;   // fresnel_schlick :137-139
+        const float omv2 = omv * omv, p = omv2 * omv2 * omv;       // fresnel_schlick :137-139
         const float sin2 = c2 * (inv_h * inv_h);                   // 1 - (n.h)^2
         const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
         // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal
@@ -389,11 +413,12 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(m.a2[0], 1.0f - nol2, nol2)));
         // (g > 0 always: n.l, n.v are clamped to EPSILON and the roots are positive, so v_smith's `denom <= 0`
         //  guard, :125-131, cannot trigger; a NaN propagates like in the reference)
-        const float dv = m_k(m, 0) * rcp(f * f * g);
+        // (a scalar-record material's k[0] is folded into the constants of the per-pixel resolve: tr_dmat::ks_f0)
+        const float dv = SPLIT_F ? rcp(f * f * g) : m_k(m, 0) * rcp(f * f * g);
         const float ws = nol * dv;                                 // specular_brdf :362-375 (weighted by n.l :414-421)
         if constexpr (SPLIT_F) {
             // max(F) = F of the channel with the largest f0 (f90 is a splat and p <= 1: F is monotone in f0)
-            const float wd = nol * (1.0f - fmaf(m.df_min, p, m.f0_max));   // diffuse_brdf :356-360
+            const float wd = nol * fmaf(m.ndf_min, p, m.omf0_max); // diffuse_brdf :356-360: 1 - max(F)
             const float wsp = ws * p;
             if constexpr (FIRST) {
                 acc.d = {I.x * wd, I.y * wd, I.z * wd};
@@ -437,25 +462,26 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         if (btdf) {
             const float vlm = fmaf(-2.0f * nl_raw, nov_raw, vl);
             const float inv_h = rsq(fmaxf(fmaf(2.0f, vlm, 2.0f), 1e-12f));
-            const float voh = clamp_eps((vlm + 1.0f) * inv_h);
-            const float nolm = clamp_eps(-nl_raw);
-            const float omv = 1.0f - voh, omv2 = omv * omv, p = omv2 * omv2 * omv;
+            const float omv = one_minus_clamped(vlm + 1.0f, inv_h);
+            const float neg_nolm = neg_clamp_eps(nl_raw);            // -max(-(n.l), EPSILON): the sign rides on its uses
+            const float omv2 = omv * omv, p = omv2 * omv2 * omv;
             const float sin2 = c2 * (inv_h * inv_h);
             const float f = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - sin2, sin2) : 1.0f;
-            const float nolm2 = nolm * nolm;
-            const float g = fmaf(nolm, px.g_nov.y, nov * fast_sqrt(fmaf(m.a2[1], 1.0f - nolm2, nolm2)));
+            const float nolm2 = neg_nolm * neg_nolm;
+            const float g = fmaf(-neg_nolm, px.g_nov.y, nov * fast_sqrt(fmaf(m.a2[1], 1.0f - nolm2, nolm2)));
             const float r = rcp(f * f * g);                          // D'V' / k[1]; not weighted by n.l (:232)
-            const float tx = I.x * r, ty = I.y * r, tz = I.z * r;
             if constexpr (FIRST) {
+                const float tx = I.x * r, ty = I.y * r, tz = I.z * r;
                 acc.ta = {tx, ty, tz};
                 acc.tb = {tx * p, ty * p, tz * p};
             } else {
-                acc.ta.x += tx;
-                acc.ta.y += ty;
-                acc.ta.z += tz;
-                acc.tb.x = fmaf(tx, p, acc.tb.x);
-                acc.tb.y = fmaf(ty, p, acc.tb.y);
-                acc.tb.z = fmaf(tz, p, acc.tb.z);
+                const float rp = r * p;
+                acc.ta.x = fmaf(I.x, r, acc.ta.x);
+                acc.ta.y = fmaf(I.y, r, acc.ta.y);
+                acc.ta.z = fmaf(I.z, r, acc.ta.z);
+                acc.tb.x = fmaf(I.x, rp, acc.tb.x);
+                acc.tb.y = fmaf(I.y, rp, acc.tb.y);
+                acc.tb.z = fmaf(I.z, rp, acc.tb.z);
             }
         } else if constexpr (FIRST) {
             acc.ta = acc.tb = {0.f, 0.f, 0.f};
@@ -999,8 +1025,8 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
             // the material's composite constants with transmission_factor folded in (tr_dmat::kd ...)
             // (the opaque pass, `fragment`, knows no transmission: plain c_diff)
             const TR_CONSTANT float* kd = TRANSMISSIVE ? m4->kd : m4->c_diff;
-            out = {fmaf(m4->df[0], acc.sp.x, m4->f0[0] * acc.s.x), fmaf(m4->df[1], acc.sp.y, m4->f0[1] * acc.s.y),
-                   fmaf(m4->df[2], acc.sp.z, m4->f0[2] * acc.s.z)};                  // specular: sum I nol D*V F
+            out = {fmaf(m4->ks_df[0], acc.sp.x, m4->ks_f0[0] * acc.s.x), fmaf(m4->ks_df[1], acc.sp.y, m4->ks_f0[1] * acc.s.y),
+                   fmaf(m4->ks_df[2], acc.sp.z, m4->ks_f0[2] * acc.s.z)};            // specular: sum I nol D*V F
             out = {fmaf(kd[0], acc.d.x, out.x), fmaf(kd[1], acc.d.y, out.y), fmaf(kd[2], acc.d.z, out.z)};
             if (transmits) {
                 // ---- ibl_volume_refraction, part 2 (:337-353)
@@ -1025,8 +1051,8 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
             out = {out.x + m4->emission[0], out.y + m4->emission[1], out.z + m4->emission[2]};
         } else {
             if constexpr (SCALAR_MATERIAL)   // (the lite class: its lights ran against the scalar record, see eval_light)
-                acc.s = {fmaf(m4->df[0], acc.sp.x, m4->f0[0] * acc.s.x), fmaf(m4->df[1], acc.sp.y, m4->f0[1] * acc.s.y),
-                         fmaf(m4->df[2], acc.sp.z, m4->f0[2] * acc.s.z)};
+                acc.s = {fmaf(m4->ks_df[0], acc.sp.x, m4->ks_f0[0] * acc.s.x), fmaf(m4->ks_df[1], acc.sp.y, m4->ks_f0[1] * acc.s.y),
+                         fmaf(m4->ks_df[2], acc.sp.z, m4->ks_f0[2] * acc.s.z)};
             f3 diffuse = {acc.d.x * mat_c_diff(mo, 0), acc.d.y * mat_c_diff(mo, 1), acc.d.z * mat_c_diff(mo, 2)};
             if (transmits) {
                 // ---- ibl_volume_refraction, part 2 (:337-353)
@@ -1418,6 +1444,15 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             txi -= F->fp.tiles_x;
             ++tyi;
         }
+        if (F->fp.strip_tile_rows != 0u) {   // (scalar) this rank's strips of a frame shared with other ranks
+            const uint32_t T = F->fp.strip_tile_rows;
+            uint32_t k = __umulhi(tyi, F->fp.strip_magic), r = tyi - k * T;
+            if (r >= T) {
+                r -= T;
+                ++k;
+            }
+            tyi = (k * F->fp.strip_world + F->fp.strip_rank) * T + r;
+        }
         txi = txi * 4u + (j & 3u);
         t.px = F->fp.rect_x0 + txi * kWaveTileW + lx;
         t.py = F->fp.rect_y0 + tyi * kWaveTileH + ly;
@@ -1789,9 +1824,14 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
     }
     d.lut_line = i * lut_stride;
     d._pad = 0u;
-    d._pad3 = d._pad4 = 0.0f;
-    d.f0_max = fmaxf(d.f0[0], fmaxf(d.f0[1], d.f0[2]));
-    d.df_min = d.f90 - d.f0_max;
+    d._pad3 = d._pad4 = d._pad5 = d._pad6 = 0.0f;
+    const float f0_max = fmaxf(d.f0[0], fmaxf(d.f0[1], d.f0[2]));
+    d.omf0_max = 1.0f - f0_max;
+    d.ndf_min = -(d.f90 - f0_max);
+    for (int k = 0; k < 3; ++k) {
+        d.ks_f0[k] = d.k[0] * d.f0[k];
+        d.ks_df[k] = d.k[0] * d.df[k];
+    }
     const float tf = mi.transmission_factor, tf2 = tf * tf;
     for (int k = 0; k < 3; ++k) {
         d.kd[k] = d.c_diff[k] * (1.0f - tf);

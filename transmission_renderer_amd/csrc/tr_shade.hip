@@ -111,6 +111,7 @@ struct tr_context {
     uint32_t vis_w = 0, vis_h = 0;                     // the frame size they are laid out for
     bool counts_clean = false;                         // d_instance_counts is all zero (stream order): the fused frame path
     uint32_t num_cus = 256;
+    uint32_t strip_rows = 0, strip_world = 1, strip_rank = 0;   // tr_set_strips: whole-frame shading calls take this rank's strips
     bool occupancy_fallback = false;     // the occupancy query failed: the grid was sized for 8 waves per SIMD
     bool mip_tail_attr_set = false;      // hipFuncSetAttribute(mip_tail_kernel, 160 KiB of LDS) done on this context's device
 
@@ -406,6 +407,20 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     fp->rect_y1 = rect.y1;
     fp->tiles_x = (rect.x1 - rect.x0 + kBlockTileW - 1u) / kBlockTileW;
     fp->tiles_y = (rect.y1 - rect.y0 + kBlockTileH - 1u) / kBlockTileH;
+    if (ctx->strip_rows != 0u && ctx->strip_world > 1u) {
+        // rank-interleaved strips: the rect must be the whole frame height; the launch sweeps this rank's tile rows only
+        if (rect.y0 != 0u || rect.y1 != fh) return TR_ERR_INVALID_ARGUMENT;
+        const uint32_t T = ctx->strip_rows / kBlockTileH;
+        const uint32_t frame_tile_rows = fp->tiles_y, strips = (frame_tile_rows + T - 1u) / T;
+        const uint32_t owned = ctx->strip_rank < strips ? (strips - 1u - ctx->strip_rank) / ctx->strip_world + 1u : 0u;
+        uint32_t rows = owned * T;
+        if (owned != 0u && (strips - 1u) % ctx->strip_world == ctx->strip_rank) rows -= strips * T - frame_tile_rows;   // the frame's last strip is short
+        fp->tiles_y = rows;
+        fp->strip_tile_rows = T;
+        fp->strip_magic = (uint32_t)((1ull << 32) / T);
+        fp->strip_world = ctx->strip_world;
+        fp->strip_rank = ctx->strip_rank;
+    }
     fp->tiles_x_magic = (uint32_t)(0x100000000ull / fp->tiles_x > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->tiles_x);
     fp->stripe_tiles = fp->tiles_x * kStripeTileRows;
     fp->stripe_magic = (uint32_t)(0x100000000ull / fp->stripe_tiles > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->stripe_tiles);
@@ -464,6 +479,7 @@ void free_geometry(tr_context* ctx) {
 // Passes that shade textured materials differentiate inside 2x2 pixel quads: the rect must hold whole quads.
 tr_status check_textured_launch(const tr_context* ctx, const tr_gbuffer* g, const tr_frame_params& fp) {
     if (!ctx->any_textured) return TR_OK;
+    if (fp.strip_tile_rows != 0u && ctx->any_full_textured) return TR_ERR_UNSUPPORTED;   // (the full-class tile list numbers the rect's tiles)
     if (!g->uv) return TR_ERR_INVALID_ARGUMENT;
     if (ctx->max_texture_id >= (int32_t)ctx->num_textures) return TR_ERR_INVALID_ARGUMENT;
     if ((fp.rect_x0 & 1u) || (fp.rect_y0 & 1u)) return TR_ERR_INVALID_ARGUMENT;
@@ -1556,6 +1572,9 @@ struct rccl_api {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     bool ok = false;
 };
 // Loaded once.  By soname first: a process that already mapped an RCCL (a framework's bundled copy has the same
@@ -1572,7 +1591,10 @@ const rccl_api& rccl() {
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
         a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
-        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather;
+        a.Broadcast = (decltype(a.Broadcast))dlsym(a.handle, "ncclBroadcast");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.Broadcast && a.GroupStart && a.GroupEnd;
         return a;
     }();
     return api;
@@ -1666,6 +1688,55 @@ tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame, uint32
     // in place: this rank's band already sits at its slot of the receive buffer
     const ncclResult_t r = rccl().AllGather(base + (size_t)comm->rank * band_bytes, base, band_bytes, ncclUint8, comm->comm,
                                             (hipStream_t)stream_);
+    if (r != ncclSuccess) {
+        comm->last_error = (int32_t)r;
+        return TR_ERR_COMM;
+    }
+    return TR_OK;
+}
+
+tr_status tr_set_strips(tr_context* ctx, uint32_t strip_rows, uint32_t nranks, uint32_t rank) {
+    if (!ctx) return TR_ERR_INVALID_ARGUMENT;
+    if (strip_rows == 0u || nranks <= 1u) {   // off
+        ctx->strip_rows = 0;
+        ctx->strip_world = 1;
+        ctx->strip_rank = 0;
+        return TR_OK;
+    }
+    if (strip_rows % kBlockTileH != 0u || rank >= nranks) return TR_ERR_INVALID_ARGUMENT;
+    ctx->strip_rows = strip_rows;
+    ctx->strip_world = nranks;
+    ctx->strip_rank = rank;
+    return TR_OK;
+}
+
+tr_status tr_strip_of_rank(uint32_t height, uint32_t strip_rows, uint32_t nranks, uint32_t rank, uint32_t k, uint32_t* y0,
+                           uint32_t* y1) {
+    if (!y0 || !y1 || height == 0 || strip_rows == 0 || nranks == 0 || rank >= nranks) return TR_ERR_INVALID_ARGUMENT;
+    const uint64_t a = ((uint64_t)k * nranks + rank) * strip_rows, b = a + strip_rows;
+    *y0 = (uint32_t)(a < height ? a : height);
+    *y1 = (uint32_t)(b < height ? b : height);
+    return TR_OK;
+}
+
+tr_status tr_allgather_strips(tr_context* ctx, tr_comm* comm, void* frame, uint32_t width, uint32_t height, uint32_t strip_rows,
+                              tr_format format, void* stream_) {
+    if (!ctx || !comm || !frame || width == 0 || height == 0 || strip_rows == 0) return TR_ERR_INVALID_ARGUMENT;
+    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F && format != TR_FORMAT_RGBA8) return TR_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return TR_ERR_COMM;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t row_bytes = (size_t)width * (format == TR_FORMAT_RGBA16F ? 8u : format == TR_FORMAT_RGBA32F ? 16u : 4u);
+    char* base = static_cast<char*>(frame);
+    // every strip is broadcast in place from the rank that shaded it; one group: RCCL schedules the strips of all roots
+    // together (each xGMI link carries the strips of one peer in each direction, like the band all-gather)
+    ncclResult_t r = rccl().GroupStart();
+    for (uint32_t s = 0, y = 0; r == ncclSuccess && y < height; ++s, y += strip_rows) {
+        const size_t bytes = (size_t)((height - y < strip_rows) ? height - y : strip_rows) * row_bytes;
+        char* at = base + (size_t)y * row_bytes;
+        r = rccl().Broadcast(at, at, bytes, ncclUint8, (int)(s % comm->nranks), comm->comm, (hipStream_t)stream_);
+    }
+    const ncclResult_t e = rccl().GroupEnd();
+    if (r == ncclSuccess) r = e;
     if (r != ncclSuccess) {
         comm->last_error = (int32_t)r;
         return TR_ERR_COMM;
@@ -1796,6 +1867,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (f->pyramid.width != w || f->pyramid.height != h) return TR_ERR_INVALID_ARGUMENT;
     if (w == 0 || h == 0 || w > 65535u || h > 65535u) return TR_ERR_INVALID_ARGUMENT;
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
+    if (ctx->strip_rows != 0u) return TR_ERR_UNSUPPORTED;   // (the frame recorder renders whole frames)
     ctx->cover_cleared = false;
     // RGBA16F frames are shaded straight from the rasteriser's visibility words (shade_kernel's VIS launches): no resolve,
     // the work planes of the descriptor stay untouched.  RGBA32F frames go through the planes.

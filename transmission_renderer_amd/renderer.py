@@ -331,6 +331,11 @@ class TransmissionRenderer:
                                                    self._rect(g, rect), self._stream()),
                     "tr_shade_transmission")
 
+    def set_strips(self, strip_rows: int, world: int, rank: int) -> None:
+        """Rank-interleaved strips (tr_set_strips): whole-frame shade_opaque / shade_transmission calls then shade this
+        rank's strips only, in place; set_strips(0, 1, 0) turns it off."""
+        self._check(self.lib.tr_set_strips(self._ctx, int(strip_rows), int(world), int(rank)), "tr_set_strips")
+
     def baked_tonemap_params(self, lottes: Optional[wire.LottesParams] = None) -> wire.TonemapParams:
         if lottes is None:
             lottes = wire.LottesParams()
@@ -339,12 +344,16 @@ class TransmissionRenderer:
         self._check(self.lib.tr_bake_lottes_params(C.byref(lottes), C.byref(out)), "tr_bake_lottes_params")
         return out
 
-    def tonemap(self, hdr: torch.Tensor, params: Optional[wire.TonemapParams] = None, bgra: bool = False) -> torch.Tensor:
-        """"tonemapping": fragment_tonemap (shader/src/lib.rs:683-697) -> (H, W, 4) uint8, sRGB encoded."""
+    def tonemap(self, hdr: torch.Tensor, params: Optional[wire.TonemapParams] = None, bgra: bool = False,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """"tonemapping": fragment_tonemap (shader/src/lib.rs:683-697) -> (H, W, 4) uint8, sRGB encoded (into `out` when
+        given: e.g. a rank's rows of the whole 8-bit frame; the operator is pointwise, so a row band is a frame of its own)."""
         assert hdr.dtype == torch.float16 and hdr.is_cuda and hdr.is_contiguous() and hdr.shape[-1] == 4
         h, w = int(hdr.shape[0]), int(hdr.shape[1])
         params = params or self.baked_tonemap_params()
-        out = torch.empty((h, w, 4), dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((h, w, 4), dtype=torch.uint8, device=self.device)
+        assert out.dtype == torch.uint8 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (h, w, 4)
         self._check(self.lib.tr_tonemap(self._ctx, hdr.data_ptr(), w, h, C.byref(params), out.data_ptr(), int(bgra),
                                         self._stream()), "tr_tonemap")
         return out

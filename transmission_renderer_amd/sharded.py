@@ -45,6 +45,20 @@ def padded_rows(height: int, world: int) -> int:
     return band_rows(height, world, 0)[0] * world
 
 
+def strips_of_rank(height: int, strip_rows: int, world: int, rank: int):
+    """[(y0, y1), ...]: the strips of `rank` (tr_strip_of_rank): strip s of the frame belongs to rank s % world."""
+    out, k = [], 0
+    y0, y1 = C.c_uint32(), C.c_uint32()
+    while True:
+        st = _lib.load().tr_strip_of_rank(int(height), int(strip_rows), int(world), int(rank), k, C.byref(y0), C.byref(y1))
+        if st != 0:
+            raise ValueError(f"tr_strip_of_rank({height}, {strip_rows}, {world}, {rank}, {k}): status {st}")
+        if y0.value == y1.value:
+            return out
+        out.append((y0.value, y1.value))
+        k += 1
+
+
 class Compositor:
     """In-place all-gather of equal row bands of a (rows_per_rank * world, W, C) device or host tensor."""
 
@@ -108,6 +122,53 @@ class Compositor:
             dist.all_gather(outs, mine.clone(), group=self.group)
         else:
             dist.all_gather_into_tensor(flat, mine, group=self.group)
+
+
+def allgather_strips(comp: "Compositor", frame: torch.Tensor, strip_rows: int) -> None:
+    """The composite of a strip-sharded frame: `frame` is (H, W, C), every rank has written its own strips in place.
+    tr_allgather_strips on a GPU (one RCCL group of per-strip broadcasts); per-strip torch.distributed broadcasts
+    otherwise (gloo on host tensors in the tests)."""
+    if comp.world == 1 and not comp._comm.value:
+        return
+    assert frame.is_contiguous()
+    h, w = int(frame.shape[0]), int(frame.shape[1])
+    if comp._comm.value:
+        fmt = {torch.float16: wire.FORMAT_RGBA16F, torch.float32: wire.FORMAT_RGBA32F, torch.uint8: wire.FORMAT_RGBA8}[frame.dtype]
+        st = comp.renderer.lib.tr_allgather_strips(comp.renderer._ctx, comp._comm, frame.data_ptr(), w, h, int(strip_rows), fmt,
+                                                   torch.cuda.current_stream().cuda_stream)
+        if st != 0:
+            raise _lib.TrError(st, "tr_allgather_strips", comp.renderer.lib.tr_comm_last_error(comp._comm))
+        return
+    works = []
+    for s, y in enumerate(range(0, h, strip_rows)):
+        works.append(dist.broadcast(frame[y:min(y + strip_rows, h)], src=dist.get_global_rank(comp.group, s % comp.world)
+                                    if comp.group is not None else s % comp.world, group=comp.group, async_op=True))
+    for wk in works:
+        wk.wait()
+
+
+def record_sharded_strips(renderer, opaque, transmissive, uniforms, push, hdr, pyramid, compositor: "Compositor",
+                          strip_rows: int = 64, composite: bool = True) -> None:
+    """record_sharded with rank-interleaved strips instead of one row band per rank (frames whose cost is uneven over
+    the screen): `opaque` / `transmissive` cover the whole frame, `hdr` and `pyramid` are whole-frame buffers; every rank
+    shades strips rank, rank + world, ... in place (one launch per pass), level 0 of the pyramid and the frame are
+    exchanged strip by strip."""
+    world, rank = compositor.world, compositor.rank
+    fw, fh = int(push.framebuffer_size[0]), int(push.framebuffer_size[1])
+    renderer.set_strips(strip_rows if world > 1 else 0, world, rank)
+    try:
+        mine = world == 1 or bool(strips_of_rank(fh, strip_rows, world, rank))
+        if mine:
+            renderer.shade_opaque(opaque, uniforms, push, hdr, pyramid, (0, 0, fw, fh))
+        if world > 1:
+            allgather_strips(compositor, pyramid.level(0), strip_rows)
+        renderer.generate_mips(pyramid)
+        if mine:
+            renderer.shade_transmission(transmissive, uniforms, push, pyramid, hdr, (0, 0, fw, fh))
+        if world > 1 and composite:
+            allgather_strips(compositor, hdr, strip_rows)
+    finally:
+        renderer.set_strips(0, 1, 0)
 
 
 def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid, compositor: Compositor,
