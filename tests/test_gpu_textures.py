@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 
 from oracle import oracle  # noqa: E402
 from transmission_renderer_amd import synthetic, wire  # noqa: E402
-from test_gpu_parity import _check_against_oracles, _norm_err, _rmse, _upload_scene  # noqa: E402
+from test_gpu_parity import _check_against_oracles, _norm_err, _p1_against_pinned, _rmse, _upload_scene  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -147,6 +147,65 @@ def test_textured_opaque_pass_parity(renderer, ggx_lut, w, h, coverage, uv_scale
     got32, o32, o64 = _masked(ok, got32, o32, o64)
     got16, o16_64 = _masked(ok, got16, o16_64)
     _check_against_oracles(got32, got16, o32, o64, o16_64, f"textured opaque {w}x{h}")
+
+
+def _usual_gltf_set(scene):
+    """Every textured material keeps its base-colour, metallic-roughness and normal-map slots only: the material set
+    the full-class launch has a build of its own for (shade_kernel's TEX = 3: the other five factors stay scalar)."""
+    for m in scene["materials"]:
+        t = m.textures
+        t.emissive = t.transmission = t.thickness = t.specular = t.specular_colour = -1
+    return scene
+
+
+@pytest.mark.parametrize("w,h,nl,coverage,uv_scale", [(256, 192, 2, "full", 1.0), (250, 130, 3, "holes", 3.0)])
+def test_usual_gltf_texture_set_build_parity(renderer, ggx_lut, monkeypatch, w, h, nl, coverage, uv_scale):
+    """Both passes through the TEX = 3 build against the oracles, and against the general full-class build (TR_NO_MID_CLASS
+    makes the host launch that one): the same per-pixel arithmetic on the same values, so the frames agree to rounding."""
+    from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
+    r = renderer
+    scene = _usual_gltf_set(_textured_scene(w, h, nl, coverage, uv_scale))
+    assert any(m.textures.normal_map != -1 for m in scene["materials"]) and any(m.textures.metallic_roughness != -1 for m in scene["materials"])
+    _upload_scene(r, scene)
+    r.upload_textures(scene["textures"])
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    b = oracle.SceneBinding(scene, ggx_lut)
+    tex = oracle.new_pyramid(w, h, synthetic.make_opaque_mip0(w, h))
+    oracle.generate_mips(w, h, tex)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.texels.copy_(torch.from_numpy(tex).to(r.device))
+    base = np.full((h, w, 4), 0.125, dtype=np.float32)
+
+    def run():
+        t32 = torch.from_numpy(base).to(r.device)
+        t16 = torch.from_numpy(base.astype(np.float16)).to(r.device)
+        o32 = torch.full((h, w, 4), 9.0, dtype=torch.float32, device=r.device)
+        r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
+        r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t16)
+        r.shade_opaque(g, scene["uniforms"], scene["push"], o32, None)
+        torch.cuda.synchronize()
+        return t32.cpu().numpy(), t16.cpu().numpy(), o32.cpu().numpy()
+
+    got32, got16, gop = run()
+    monkeypatch.setenv("TR_NO_MID_CLASS", "1")
+    full32, full16, fop = run()
+    monkeypatch.delenv("TR_NO_MID_CLASS")
+    ok = ~_degenerate(scene["materials"], scene["gbuffer"]["material_id"])
+    assert ok.mean() >= 0.99
+    for a, c in ((got32, full32), (gop, fop)):
+        a, c = _masked(ok, a, c)
+        assert np.abs(_norm_err(a, c)).max() <= 2e-6, "the two builds of the full-class launch disagree"
+    o16, o32 = oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=base.astype(np.float16), hdr_f32=base.copy(), nthreads=8)
+    o16_64, o64 = oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=base.astype(np.float16),
+                                            hdr_f32=base.astype(np.float64), nthreads=8, fp64=True)
+    m32, mo32, mo64 = _masked(ok, got32, o32, o64)
+    m16, mo16_64 = _masked(ok, got16, o16_64)
+    _check_against_oracles(m32, m16, mo32, mo64, mo16_64, f"usual glTF set, transmission {w}x{h}", t3_outliers=1)
+    _, p32, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8)
+    _, p64, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
+    mop, mp32, mp64 = _masked(ok, gop, p32, p64)
+    assert _rmse(_norm_err(mop, mp64)).max() <= 1e-4
+    _p1_against_pinned(mop, mp32, mp64, f"usual glTF set, opaque {w}x{h}", max_ill_fraction=2e-3)
 
 
 # (the textured golden case — the reference's compiled shaders on tests/golden/spirv_case_c.npz — runs in

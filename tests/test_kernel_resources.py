@@ -78,5 +78,7 @@ def test_textured_launch_classes_keep_their_occupancy(kernels):
         assert _shade(kernels, True, "uint2", 1, vis)["vgpr"] <= 80    # lite class, transmissive: 6 waves
         assert _shade(kernels, False, "uint2", 2, vis)["vgpr"] <= 96   # full class, opaque: 5 waves (LDS-parked front end)
         assert _shade(kernels, True, "uint2", 2, vis)["vgpr"] <= 128   # full class, transmissive: 4 waves
+        assert _shade(kernels, False, "uint2", 3, vis)["vgpr"] <= 80   # ... its base-colour + metallic-roughness + normal build: 6 waves
+        assert _shade(kernels, True, "uint2", 3, vis)["vgpr"] <= 96    #     transmissive: 5 waves
         # five one-wave workgroups per SIMD = 20 per CU must fit the CU's 160 KB of LDS
         assert _shade(kernels, False, "uint2", 2, vis)["lds"] * 20 <= 160 * 1024

@@ -25,7 +25,9 @@ from transmission_renderer_amd import synthetic, wire
 from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer
 w, h, nl = 3840, 2160, int(os.environ.get("TR_AB_LIGHTS", "1"))
 r = TransmissionRenderer(0)
-scene = synthetic.make_scene(w, h, num_point_lights=nl)
+scene = synthetic.make_scene(w, h, num_point_lights=nl, roughness_override=float(os.environ["TR_AB_ROUGHNESS"]) if os.environ.get("TR_AB_ROUGHNESS") else None)
+if os.environ.get("TR_AB_ALLT"):
+    for m in scene["materials"]: m.transmission_factor = 1.0
 r.upload_ggx_lut(); r.upload_materials(scene["materials"]); r.upload_lights(scene["lights"])
 r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(r.device), torch.from_numpy(scene["light_indices"].view(np.int32)).to(r.device))
 g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)

@@ -54,7 +54,11 @@ namespace tr {
 #ifndef TR_ABLATION
 #define TR_ABLATION 0
 #endif
+#ifdef TR_PROBE_MASK   // register-pressure probes (tools/kernel_stats.py -DTR_PROBE_MASK=n): a phase compiled out
+#define TR_ABLATE(L, bit) (((TR_PROBE_MASK) & (bit)) != 0)
+#else
 #define TR_ABLATE(L, bit) (TR_ABLATION && ((L)->fp.ablate & (bit)))
+#endif
 // Profiling builds (-DTR_TIMING=1, tools/ab_kernel.py): every wave adds the cycles it spent waiting for (0) the G-buffer
 // planes, (1) the cluster lists, (2) the refraction taps + LUT, and (3) its total loop time, (4) tiles, into
 // tr_timing_counters (read back with tr_debug_read_timing).  The waits are forced at the measuring points.
@@ -105,7 +109,9 @@ struct alignas(16) tr_dmat {
     uint32_t lut_row1;
     uint32_t flags;        // bit0: finite attenuation distance; bit1: transmission_factor != 0;
                            // bit2: the material has texture slots (shaded by the per-pixel material path);
-                           // bit3: ... of the lite class (lite_dmat)
+                           // bit3: ... of the lite class (lite_dmat);
+                           // bit4: kd is zero in every channel (transmission_factor == 1 or metallic == 1): the
+                           //       transmissive pass needs no diffuse sum; bit5: c_diff is (metallic == 1): nor the opaque
     float ior_clamp;       // clamp(2 ior - 2, 0, 1)
     float f0_dielectric;   // ((ior - 1) / (ior + 1))^2
     float bt_a[3];         // k[1] * (1 - f0): the btdf lobe is accumulated as sum(I D'V') and sum(I D'V' p') and
@@ -387,10 +393,12 @@ struct pixel_frame {
 // FIRST: the pixel's first light (the sun) writes the accumulators instead of adding to zeros — `0 + x` is not `x`
 // for the compiler (signed zeros), so accumulating into zero-initialised registers costs a move and an add per sum.
 template <bool TRANSMISSIVE, bool FIRST = false, class Mat /* cdmat (scalar registers) or const lane_dmat (per lane) */>
-__device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_frame& px, f3 l, f3 I, bool btdf) {
+__device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_frame& px, f3 l, f3 I, bool btdf,
+                                           bool diffuse = true /* (scalar) acc.d is wanted: see tr_dmat::flags bit 4 */) {
     constexpr bool SPLIT_F = std::is_same<Mat, cdmat>::value;
     const f3 n = px.n, v = px.v;
     const float nov_raw = px.nov_raw, nov = px.nov;
+    const float a2_0 = m.a2[0], a2_1 = m.a2[1];
     const float nl_raw = dot3(n.x, n.y, n.z, l.x, l.y, l.z);
     const float vl = dot3(v.x, v.y, v.z, l.x, l.y, l.z);
     const float hx = v.x + l.x, hy = v.y + l.y, hz = v.z + l.z;
@@ -405,12 +413,12 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         const float nol = clamp_eps(nl_raw);
         const float omv2 = omv * omv, p = omv2 * omv2 * omv;       // fresnel_schlick :137-139
         const float sin2 = c2 * (inv_h * inv_h);                   // 1 - (n.h)^2
-        const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(m.a2[0], 1.0f - sin2, sin2) : 1.0f;
+        const float f = (nov_raw + nl_raw) > 0.0f ? fmaf(a2_0, 1.0f - sin2, sin2) : 1.0f;
         // v_smith_ggx_correlated (:114-133) and D*V with one reciprocal
         // (nol^2 (1 - a2) + a2 written as nol^2 + a2 (1 - nol^2): one table operand per instruction — with two the
         //  compiler first copies one into a vector register, and an instruction with a scalar operand never pairs)
         const float nol2 = nol * nol;
-        const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(m.a2[0], 1.0f - nol2, nol2)));
+        const float g = fmaf(nol, px.g_nov.x, nov * fast_sqrt(fmaf(a2_0, 1.0f - nol2, nol2)));
         // (g > 0 always: n.l, n.v are clamped to EPSILON and the roots are positive, so v_smith's `denom <= 0`
         //  guard, :125-131, cannot trigger; a NaN propagates like in the reference)
         // (a scalar-record material's k[0] is folded into the constants of the per-pixel resolve: tr_dmat::ks_f0)
@@ -418,16 +426,23 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
         const float ws = nol * dv;                                 // specular_brdf :362-375 (weighted by n.l :414-421)
         if constexpr (SPLIT_F) {
             // max(F) = F of the channel with the largest f0 (f90 is a splat and p <= 1: F is monotone in f0)
-            const float wd = nol * fmaf(m.ndf_min, p, m.omf0_max); // diffuse_brdf :356-360: 1 - max(F)
+            // (scalar branch: a material whose diffuse constant is zero — transmission_factor 1, or a metal — never reads
+            //  the diffuse sum: six instructions per light, four of them with a scalar operand)
+            if (diffuse) {
+                const float wd = nol * fmaf(m.ndf_min, p, m.omf0_max); // diffuse_brdf :356-360: 1 - max(F)
+                if constexpr (FIRST) {
+                    acc.d = {I.x * wd, I.y * wd, I.z * wd};
+                } else {
+                    acc.d.x = fmaf(I.x, wd, acc.d.x);
+                    acc.d.y = fmaf(I.y, wd, acc.d.y);
+                    acc.d.z = fmaf(I.z, wd, acc.d.z);
+                }
+            }
             const float wsp = ws * p;
             if constexpr (FIRST) {
-                acc.d = {I.x * wd, I.y * wd, I.z * wd};
                 acc.s = {I.x * ws, I.y * ws, I.z * ws};
                 acc.sp = {I.x * wsp, I.y * wsp, I.z * wsp};
             } else {
-                acc.d.x = fmaf(I.x, wd, acc.d.x);
-                acc.d.y = fmaf(I.y, wd, acc.d.y);
-                acc.d.z = fmaf(I.z, wd, acc.d.z);
                 acc.s.x = fmaf(I.x, ws, acc.s.x);
                 acc.s.y = fmaf(I.y, ws, acc.s.y);
                 acc.s.z = fmaf(I.z, ws, acc.s.z);
@@ -466,9 +481,9 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
             const float neg_nolm = neg_clamp_eps(nl_raw);            // -max(-(n.l), EPSILON): the sign rides on its uses
             const float omv2 = omv * omv, p = omv2 * omv2 * omv;
             const float sin2 = c2 * (inv_h * inv_h);
-            const float f = (nov_raw - nl_raw) > 0.0f ? fmaf(m.a2[1], 1.0f - sin2, sin2) : 1.0f;
+            const float f = (nov_raw - nl_raw) > 0.0f ? fmaf(a2_1, 1.0f - sin2, sin2) : 1.0f;
             const float nolm2 = neg_nolm * neg_nolm;
-            const float g = fmaf(-neg_nolm, px.g_nov.y, nov * fast_sqrt(fmaf(m.a2[1], 1.0f - nolm2, nolm2)));
+            const float g = fmaf(-neg_nolm, px.g_nov.y, nov * fast_sqrt(fmaf(a2_1, 1.0f - nolm2, nolm2)));
             const float r = rcp(f * f * g);                          // D'V' / k[1]; not weighted by n.l (:232)
             if constexpr (FIRST) {
                 const float tx = I.x * r, ty = I.y * r, tz = I.z * r;
@@ -493,7 +508,7 @@ __device__ __forceinline__ void eval_light(light_acc& acc, Mat& m, const pixel_f
 
 template <bool TRANSMISSIVE, class Mat>
 __device__ __forceinline__ void eval_punctual(light_acc& acc, Mat& m, cdlight& L, f3 pos, const pixel_frame& px,
-                                              bool btdf) {
+                                              bool btdf, bool diffuse = true) {
     // light_direction_and_attenuation (glam-pbr/src/lib.rs:12-23): bare 1/d^2
     float dx = L.pos[0] - pos.x, dy = L.pos[1] - pos.y, dz = L.pos[2] - pos.z;
     float inv_d = rsq(dot3(dx, dy, dz, dx, dy, dz));
@@ -508,7 +523,7 @@ __device__ __forceinline__ void eval_punctual(light_acc& acc, Mat& m, cdlight& L
         }
     }
     f3 I = {L.colour[0] * att, L.colour[1] * att, L.colour[2] * att};
-    eval_light<TRANSMISSIVE, false>(acc, m, px, l, I, btdf);
+    eval_light<TRANSMISSIVE, false>(acc, m, px, l, I, btdf, diffuse);
 }
 
 // ------------------------------------------------------------------ opaque pyramid taps
@@ -935,6 +950,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
     // transmission_factor == 0 (scalar): lib.rs:157-159 multiplies the whole transmission term by zero, so the
     // refraction taps, the LUT and the btdf lobes are skipped for such materials
     const bool transmits = TRANSMISSIVE && (mat_base(m)->flags & 2u);
+    // (scalar) the diffuse sum is read: always for a per-lane or lite record; for a scalar record unless its diffuse
+    // constant (kd in the transmissive pass, c_diff in the opaque one) is zero in every channel
+    const bool diffuse_on = !std::is_same<MatP, cdmat*>::value || TR_ABLATION || !(mat_base(m)->flags & (TRANSMISSIVE ? 16u : 32u));
     auto issue_taps = [&]() {
     if (transmits) {
         const auto mb = mat_base(m);
@@ -986,7 +1004,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
         // sun (lighting.rs:37-53 / 171-177)
         if (!TR_ABLATE(L2, 4u))
             eval_light<TRANSMISSIVE, !TR_ABLATION>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
-                                     {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, transmits);
+                                     {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, transmits, diffuse_on);
         tile_phase<1>();
     };
     // punctual lights (lighting.rs:55-92 / 179-217): count, list and lights all through the scalar unit.  One trip of
@@ -1009,7 +1027,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
 #pragma clang loop unroll(disable)   // (left alone the first two trips are peeled: three copies of the light evaluation)
                 for (uint32_t i = 0; i < n; ++i) {
                     const uint32_t idx = (cl.uniform && i == 0u) ? cl.s_l0 : (cl.uniform && i == 1u) ? cl.s_l1 : list[i];
-                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[idx], pos, px, transmits);
+                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[idx], pos, px, transmits, diffuse_on);
                 }
                 if constexpr (!TRANSMISSIVE) lights_walked = n;
             }
@@ -1027,7 +1045,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
             const TR_CONSTANT float* kd = TRANSMISSIVE ? m4->kd : m4->c_diff;
             out = {fmaf(m4->ks_df[0], acc.sp.x, m4->ks_f0[0] * acc.s.x), fmaf(m4->ks_df[1], acc.sp.y, m4->ks_f0[1] * acc.s.y),
                    fmaf(m4->ks_df[2], acc.sp.z, m4->ks_f0[2] * acc.s.z)};            // specular: sum I nol D*V F
-            out = {fmaf(kd[0], acc.d.x, out.x), fmaf(kd[1], acc.d.y, out.y), fmaf(kd[2], acc.d.z, out.z)};
+            if (diffuse_on) out = {fmaf(kd[0], acc.d.x, out.x), fmaf(kd[1], acc.d.y, out.y), fmaf(kd[2], acc.d.z, out.z)};
             if (transmits) {
                 // ---- ibl_volume_refraction, part 2 (:337-353)
                 f3 T = pyramid_resolve(pf);
@@ -1126,7 +1144,7 @@ struct quad_derivs {
 // 190-194; lighting.rs:222-313): the (scalar) material record says which slots are bound, the taps of every bound
 // texture are issued together, then the sampled factors are digested per lane and the pixel continues through
 // the same shade_pixel as an untextured one.
-template <bool TRANSMISSIVE>
+template <bool TRANSMISSIVE, uint32_t SLOTS /* the slots a material of this launch may bind: kSlotsAll / kSlotsMid */>
 __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material, cdmat* dm, float4 pd, float4 ns,
                                                    float2 uv, const quad_derivs& qd, uint32_t lane,
                                                    const cluster_list& cl_in, const float* __restrict__ lds_srgb,
@@ -1145,11 +1163,13 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     const TR_CONSTANT tr_material_info* mi = as_constant(L->materials) + material;
     cdtex* tex = as_constant(L->textures);
     const uint32_t* __restrict__ arena = L->tex_arena;
-    const int32_t id_diffuse = mi->textures.diffuse, id_mr = mi->textures.metallic_roughness;
-    const int32_t id_normal = mi->textures.normal_map, id_emissive = mi->textures.emissive;
-    const int32_t id_transmission = TRANSMISSIVE ? mi->textures.transmission : -1;
-    const int32_t id_thickness = TRANSMISSIVE ? mi->textures.thickness : -1;
-    const int32_t id_specular = mi->textures.specular, id_spec_colour = mi->textures.specular_colour;
+    constexpr auto may = [](int k) { return ((SLOTS >> k) & 1u) != 0u; };
+    const int32_t id_diffuse = may(0) ? mi->textures.diffuse : -1, id_mr = may(1) ? mi->textures.metallic_roughness : -1;
+    const int32_t id_normal = may(2) ? mi->textures.normal_map : -1, id_emissive = may(3) ? mi->textures.emissive : -1;
+    const int32_t id_transmission = TRANSMISSIVE && may(4) ? mi->textures.transmission : -1;
+    const int32_t id_thickness = TRANSMISSIVE && may(5) ? mi->textures.thickness : -1;
+    const int32_t id_specular = may(6) ? mi->textures.specular : -1, id_spec_colour = may(7) ? mi->textures.specular_colour : -1;
+    // (what a slot that cannot be bound would modulate is never parked: it stays the record's scalar value)
 
     // Sampling geometry (LOD, level pair, wrapped tap coordinates, weights) depends on the texture's size only, and a
     // material's textures usually share one size: it is computed for the first bound slot and kept while the following
@@ -1211,7 +1231,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(scx), "+v"(scy), "+v"(scz));
         slot_done();
     }
-    put(11, scx); put(12, scy); put(13, scz);
+    if constexpr (may(7)) { put(11, scx); put(12, scy); put(13, scz); }
     slot_done();
     float specular_factor = mi->specular_factor;
     if (id_specular != -1) {
@@ -1219,7 +1239,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(specular_factor));
         slot_done();
     }
-    put(14, specular_factor);
+    if constexpr (may(6)) put(14, specular_factor);
     slot_done();
     // get_emission (lighting.rs:303-313)
     lm.emission[0] = mi->emissive_factor[0];
@@ -1230,7 +1250,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(lm.emission[0]), "+v"(lm.emission[1]), "+v"(lm.emission[2]));
         slot_done();
     }
-    put(15, lm.emission[0]); put(16, lm.emission[1]); put(17, lm.emission[2]);
+    if constexpr (may(3)) { put(15, lm.emission[0]); put(16, lm.emission[1]); put(17, lm.emission[2]); }
     slot_done();
     lm.transmission_factor = mi->transmission_factor;               // lib.rs:71-77
     if (id_transmission != -1) {
@@ -1238,7 +1258,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(lm.transmission_factor));
         slot_done();
     }
-    put(18, lm.transmission_factor);
+    if constexpr (may(4)) put(18, lm.transmission_factor);
     slot_done();
     lm.thickness = mi->thickness_factor;                            // lib.rs:120-124
     if (id_thickness != -1) {
@@ -1246,7 +1266,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(lm.thickness));
         slot_done();
     }
-    put(19, lm.thickness);
+    if constexpr (may(5)) put(19, lm.thickness);
     slot_done();
     lm.eta = dm->eta;
     lm.neg_atten_log2[0] = dm->neg_atten_log2[0];
@@ -1284,11 +1304,11 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     slot_done();
     dr = get(6); dg = get(7); db = get(8);
     metallic = get(9); rough = get(10);
-    scx = get(11); scy = get(12); scz = get(13);
-    specular_factor = get(14);
-    lm.emission[0] = get(15); lm.emission[1] = get(16); lm.emission[2] = get(17);
-    lm.transmission_factor = get(18);
-    lm.thickness = get(19);
+    if constexpr (may(7)) { scx = get(11); scy = get(12); scz = get(13); }
+    if constexpr (may(6)) specular_factor = get(14);
+    if constexpr (may(3)) { lm.emission[0] = get(15); lm.emission[1] = get(16); lm.emission[2] = get(17); }
+    if constexpr (may(4)) lm.transmission_factor = get(18);
+    if constexpr (may(5)) lm.thickness = get(19);
     lm.flags = (dm->flags & 1u) | (lm.transmission_factor != 0.0f ? 2u : 0u);
     digest_factors<false>(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
                           L->fp.lut_height, L->fp.lut_stride);
@@ -1373,7 +1393,12 @@ struct tile_regs {
 // A frame with textured materials is one launch of TEX = 1 (which also writes the opaque pass's clear colour) plus, when
 // a full-class material is uploaded, one of TEX = 2: the common materials do not pay for the registers of the eight-slot
 // sampling front end (120 VGPRs = 4 waves per SIMD; TEX = 1 holds 7-8).
-constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2;
+constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2, kTexMid = 3;
+//   3  the FULL class again, for material sets whose full-class materials bind nothing but the base-colour, the
+//      metallic-roughness and the normal-map slot (the usual glTF set; the host knows: tr_upload_materials): what the other
+//      five slots would modulate stays the material record's scalar value instead of a per-lane one — fewer vector
+//      registers across the light loop, one more wave per SIMD
+constexpr uint32_t kSlotsAll = 0xFFu, kSlotsMid = 0x07u;   // bit k: slot k of shade_pixel_textured's `ids` may be bound
 
 // VIS (the frame recorder's launches): a pixel's inputs are interpolated here from the rasteriser's visibility word and
 // triangle record (vis_interpolate, the resolve's own arithmetic) instead of being read from TGB-v1 planes, which the
@@ -1386,7 +1411,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
     __shared__ float lds_srgb[TEXTURED ? 256 : 1];
-    __shared__ float lds_park[TEX == kTexFull ? kParkedValues * 64u : 64u];
+    __shared__ float lds_park[TEX >= kTexFull ? kParkedValues * 64u : 64u];
     const uint32_t lane = threadIdx.x;   // one wave per workgroup
     if constexpr (TEXTURED) {
         for (uint32_t i = lane; i < 256u; i += 64u) lds_srgb[i] = L->srgb_to_linear[i];
@@ -1404,7 +1429,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // A TEX = 2 launch inside the frame recorder walks the resolve's list of the block tiles that hold fragments of its
     // class instead of the rect: a whole-frame sweep that skips nearly every tile still pays the scalar round trips of
     // each (75 us at 4K for the demo frame's one small full-class object at 4 waves per SIMD).
-    const bool listed = TEX == kTexFull && L->tile_list != nullptr;
+    const bool listed = TEX >= kTexFull && L->tile_list != nullptr;
     const uint32_t listed_tiles = listed ? as_constant(L->tile_list_count)[0] : 0u;
     // VIS launches (real frames, where whole screen regions are empty or cheap): the XCDs are dealt STRIPES of
     // kStripeTileRows tile rows in turn instead of one contiguous band each, so that every XCD gets its share of the
@@ -1468,7 +1493,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             if (F->list_build && (cover & 2u) && cover != 0xFFFFFFFFu && (j & 3u) == 0u && lane == 0u)
                 F->list_build[atomicAdd(F->list_build_count, 1u)] = tile;
         }
-        if (cover == 0u || (TEX == kTexFull && !(cover & 2u))) {
+        if (cover == 0u || (TEX >= kTexFull && !(cover & 2u))) {
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
             t.uv = float2{0.f, 0.f};
@@ -1507,7 +1532,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
             return;
         }
-        if (TEX == kTexFull && !listed && !F->fp.solo_full) {
+        if (TEX >= kTexFull && !listed && !F->fp.solo_full) {
             // (a FULL-class launch beside a TEX = 1 launch without a tile list — the host always provides one, this is
             //  the safety net: material ids (4 B per pixel) and their class first, the other planes (40 B per pixel)
             //  only where one of the tile's pixels is this launch's to shade)
@@ -1597,7 +1622,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                             nvz = -(S->fp.view_position[2] - cur.pd.z);
                 auto ddx = [&](float v) { const float d = (swz_x(v) - v) * sgn_x; return cov_x ? d : 0.0f; };
                 auto ddy = [&](float v) { const float d = (swz_y(v) - v) * sgn_y; return cov_y ? d : 0.0f; };
-                if constexpr (TEX == kTexFull) {   // (only normal mapping differentiates the view vector)
+                if constexpr (TEX >= kTexFull) {   // (only normal mapping differentiates the view vector)
                     qd.dp_dx = {ddx(nvx), ddx(nvy), ddx(nvz)};
                     qd.dp_dy = {ddy(nvx), ddy(nvy), ddy(nvz)};
                 }
@@ -1615,9 +1640,9 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                     shaded |= group;
                 }
                 if (key == mk) {
-                    if constexpr (TEX == kTexFull) {
-                        out = shade_pixel_textured<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb,
-                                                                 lds_park TR_TIMER_ARG);
+                    if constexpr (TEX >= kTexFull) {
+                        out = shade_pixel_textured<TRANSMISSIVE, TEX == kTexMid ? kSlotsMid : kSlotsAll>(
+                            L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb, lds_park TR_TIMER_ARG);
                     } else if constexpr (TEX == kTexLite) {
                         if (dmats[m0].flags & 8u)
                             out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane, cl, lds_srgb TR_TIMER_ARG);
@@ -1673,7 +1698,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             if (tile_mine) {
 #pragma clang fp contract(off)
                 uint2 q = pack_rgba16f(out.x, out.y, out.z, 1.0f);
-                if constexpr (TEX == kTexFull) {
+                if constexpr (TEX >= kTexFull) {
                     const bool mine = ((shaded >> lane) & 1ull) != 0ull;
                     if (!M->fp.solo_full && !mine && inside) q = ld<uint2>(M->mip0, mad24(cur.py, M->fp.width, cur.px) * 8u);
                 }
@@ -1818,6 +1843,15 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
                       t.transmission == -1 && t.thickness == -1 && t.specular == -1 && t.specular_colour == -1 &&
                       mi.metallic_factor == 0.0f;
     d.flags = (has_atten ? 1u : 0u) | (mi.transmission_factor != 0.0f ? 2u : 0u) | (textured ? 4u : 0u) | (lite ? 8u : 0u);
+    {   // bits 4, 5: the diffuse constant of the pass is +-0 in every channel (never for NaN factors: those must propagate)
+        const float omtf = 1.0f - mi.transmission_factor;
+        bool kd0 = true, cd0 = true;
+        for (int k = 0; k < 3; ++k) {
+            kd0 = kd0 && d.c_diff[k] * omtf == 0.0f;
+            cd0 = cd0 && d.c_diff[k] == 0.0f;
+        }
+        d.flags |= (kd0 ? 16u : 0u) | (cd0 ? 32u : 0u);
+    }
     for (int k = 0; k < 3; ++k) {
         float coeff = -logf(mi.attenuation_colour[k]) / mi.attenuation_distance;  // :284
         d.neg_atten_log2[k] = has_atten ? (-coeff) * kLog2e : 0.0f;

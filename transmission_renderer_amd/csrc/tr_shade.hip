@@ -63,6 +63,7 @@ struct tr_context {
     bool any_textured = false;      // some material has a texture slot: the TEX = 1 launch (untextured + lite class) runs
     bool any_full_textured = false; // ... outside the lite class: the TEX = 2 launch runs as well
     bool any_plain_or_lite = false; // some material is untextured or of the lite class (else the TEX = 2 launch runs alone)
+    uint32_t full_slots = 0;        // the texture slots bound by any full-class material (bit k: slot k of the kernels' `ids`)
     uint32_t* d_class_list = nullptr;   // TEX = 2 launches outside the frame recorder: [0] count, [1..] block tiles
     size_t class_list_cap = 0;
     int32_t max_texture_id = -1;    // largest texture id a material refers to
@@ -543,6 +544,9 @@ void launch_shade(const tr_launch& L, bool half, dim3 grid, dim3 block, hipStrea
 template <bool TRANSMISSIVE>
 tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bool half, dim3 grid, dim3 block,
                           hipStream_t stream) {
+    // the full-class launch: its kTexMid build when no full-class material binds a slot beyond base colour,
+    // metallic-roughness and normal map (the transmission / thickness slots do not exist for the opaque pass)
+    const bool mid = (ctx->full_slots & ~(TRANSMISSIVE ? kSlotsMid : (kSlotsMid | 0x30u))) == 0u && !std::getenv("TR_NO_MID_CLASS");
     if (ctx->any_plain_or_lite) {
         if (ctx->any_full_textured && L.tile_list) {   // (the frame recorder's buffers) the TEX = 1 launch lists the tiles itself
             L.list_build = const_cast<uint32_t*>(L.tile_list);
@@ -580,12 +584,14 @@ tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bo
         }
         // as many waves as the chip holds of this kernel (4-5 per SIMD), each striding over the list
         const dim3 grid2(ctx->num_cus * 20u);
-        launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid2, block, stream);
+        if (mid) launch_shade<TRANSMISSIVE, kTexMid>(L, half, grid2, block, stream);
+        else launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid2, block, stream);
         return TR_OK;
     }
     L.fp.solo_full = 1u;
     L.tile_list = L.tile_list_count = nullptr;
-    launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid, block, stream);
+    if (mid) launch_shade<TRANSMISSIVE, kTexMid>(L, half, grid, block, stream);
+    else launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid, block, stream);
     return TR_OK;
 }
 
@@ -723,6 +729,7 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     bool any_textured = false, any_full = false, any_other = false;
+    uint32_t full_slots = 0;
     int32_t max_id = -1;
     for (uint32_t i = 0; i < count; ++i) {
         const tr_textures& t = materials_host[i].textures;
@@ -730,11 +737,13 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
         const int32_t ids[8] = {t.diffuse, t.metallic_roughness, t.normal_map, t.emissive,
                                 t.transmission, t.thickness, t.specular, t.specular_colour};
         bool textured = false, only_diffuse = true;
+        uint32_t slots = 0;
         for (int k = 0; k < 8; ++k) {
             const int32_t id = ids[k];
             if (id < -1) return TR_ERR_INVALID_ARGUMENT;
             if (id != -1) {
                 textured = true;
+                slots |= 1u << k;
                 if (k != 0) only_diffuse = false;
             }
             if (id > max_id) max_id = id;
@@ -744,10 +753,12 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
         const bool full = textured && !(only_diffuse && materials_host[i].metallic_factor == 0.0f);
         any_full |= full;
         any_other |= !full;
+        if (full) full_slots |= slots;
     }
     ctx->any_textured = any_textured;
     ctx->any_full_textured = any_full;
     ctx->any_plain_or_lite = any_other;
+    ctx->full_slots = full_slots;
     ctx->max_texture_id = max_id;
     if (count > ctx->cap_materials) {
         (void)hipFree(ctx->d_materials_raw);
