@@ -221,13 +221,17 @@ def cpu_baseline(scene, lut, width, height, budget_s=12.0):
 
 
 def frame_pipeline_time(width, height):
-    """us per frame of tr_record_frame on the procedural `meshes` scene (own context; see run_rank)."""
+    """us per frame of tr_record_frame on the procedural `meshes` scene (own contexts; see run_rank): every frame behind
+    the previous one, and with two frames in flight — two contexts (each its own work buffers and targets) on two HIP
+    streams, frame k recorded into context k mod 2, like a renderer with a swapchain: a frame is a dependent chain of
+    ~13 launches, five of them latency-bound, and a second frame fills their gaps."""
     import numpy as np
     import torch
     from transmission_renderer_amd import meshes, synthetic, wire
     from transmission_renderer_amd.renderer import TransmissionRenderer
-    r = TransmissionRenderer(0)
-    try:
+
+    def make_context():
+        r = TransmissionRenderer(0)
         scene = synthetic.make_scene(width, height, num_point_lights=2, with_gbuffer=False, textured=True)
         geometry = meshes.make_mesh_scene(extra_instances=True)
         scene["materials"][2].alpha_clipping_cutoff = 0.75
@@ -242,29 +246,43 @@ def frame_pipeline_time(width, height):
         culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(width, height), view)
         work = r.new_frame_buffers(width, height)
         q = wire.view_rotation_inverse(view)
-        frame = lambda: r.record_frame(scene["uniforms"], scene["push"], culling, view, q, aabbs, work)   # noqa: E731
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 0.2:
-            for _ in range(4):
-                frame()
-            torch.cuda.synchronize()
-        ts = []
-        for _ in range(8):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(20):
-                frame()
-            b.record()
-            b.synchronize()
-            ts.append(a.elapsed_time(b) / 20)
-        t = float(np.median(ts))
-        return {"us_per_frame": round(t * 1e3, 1), "frames_per_s": round(1e3 / t, 1),
-                "scene": f"procedural `meshes` scene, {len(geometry['index']) // 3} triangles, textured + alpha-clipped + transmissive "
+        return r, (lambda: r.record_frame(scene["uniforms"], scene["push"], culling, view, q, aabbs, work)), len(geometry["index"]) // 3
+
+    ctxs = []
+    try:
+        ctxs = [make_context(), make_context()]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+
+        def run(n, in_flight):
+            for k in range(n):
+                with torch.cuda.stream(streams[k % in_flight]):
+                    ctxs[k % in_flight][1]()
+
+        out = {}
+        for in_flight in (1, 2):
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.2:
+                run(8, in_flight)
+                torch.cuda.synchronize()
+            ts = []
+            for _ in range(8):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run(40, in_flight)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) / 40)
+            out[in_flight] = float(np.median(ts))
+        return {"us_per_frame": round(out[1] * 1e6, 1), "frames_per_s": round(1.0 / out[1], 1),
+                "two_frames_in_flight": {"us_per_frame": round(out[2] * 1e6, 1), "frames_per_s": round(1.0 / out[2], 1),
+                                         "note": "two contexts on two HIP streams, frame k recorded into context k mod 2"},
+                "scene": f"procedural `meshes` scene, {ctxs[0][2]} triangles, textured + alpha-clipped + transmissive "
                          f"materials, sun + 2 punctual lights, {width}x{height}, RGBA16F + tonemapped RGBA8 out",
                 "stages": "culling | light assignment -> demultiplex -> visibility-buffer rasteriser (2 layers) -> opaque -> "
-                          "mip chain -> transmissive -> tonemap; one tr_record_frame call per frame, 160 frames back to back"}
+                          "mip chain -> transmissive -> tonemap; one tr_record_frame call per frame, 320 frames back to back"}
     finally:
-        r.close()
+        for c in ctxs:
+            c[0].close()
 
 
 def selftest_cpu(args, world, rank):
