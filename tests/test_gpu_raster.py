@@ -420,3 +420,45 @@ def test_record_frame_equals_the_stepwise_sequence_at_4k_and_8k(ggx_lut, tmp_pat
     finally:
         r.close()
         torch.cuda.empty_cache()
+
+
+def test_two_contexts_with_frames_in_flight_are_independent(ggx_lut):
+    """Two contexts (each its own work buffers) recording frames on two HIP streams at once — how a renderer keeps two
+    frames in flight (bench.py's frame_pipeline.two_frames_in_flight): each context's frames are bit for bit the frames
+    it renders alone, i.e. the library shares no mutable state between contexts."""
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    w, h = 514, 290
+    geo = meshes.make_mesh_scene(extra_instances=True)
+    views = (wire.default_camera()[1], wire.look_at_rh((3.5, 2.0, -6.0), (0.0, 1.2, -3.0), (0.0, 1.0, 0.0)))
+    ctxs = []
+    for view in views:                       # (a different camera per context: a mix-up cannot go unnoticed)
+        r = TransmissionRenderer(0)
+        r.upload_ggx_lut(ggx_lut)
+        sc = _scene(w, h, view)
+        r.upload_materials(sc["materials"])
+        r.upload_textures(sc["textures"])
+        r.upload_lights(sc["lights"])
+        r.upload_geometry(geo)
+        q = wire.view_rotation_inverse(view)
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+        aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+        work = r.new_frame_buffers(w, h)
+        frame = (lambda r=r, sc=sc, culling=culling, view=view, q=q, aabbs=aabbs, work=work:
+                 r.record_frame(sc["uniforms"], sc["push"], culling, view, q, aabbs, work))
+        hdr, ldr = frame()
+        torch.cuda.synchronize()
+        ctxs.append((r, frame, hdr.clone(), ldr.clone()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(3):
+        outs = []
+        for k in range(8):
+            with torch.cuda.stream(streams[k % 2]):
+                outs.append(ctxs[k % 2][1]())
+        torch.cuda.synchronize()
+        for k in (6, 7):                     # (a context's targets are its own: the last frame of each is what they hold)
+            hdr, ldr = outs[k]
+            assert torch.equal(hdr.view(torch.int16), ctxs[k % 2][2].view(torch.int16))
+            assert torch.equal(ldr, ctxs[k % 2][3])
+    assert not torch.equal(ctxs[0][2], ctxs[1][2])
+    for c in ctxs:
+        c[0].close()
