@@ -484,6 +484,19 @@ def run_rank(args) -> int:
 
     # the band kernel alone, back to back (at N = 1 the timed region already is exactly this)
     kernel_ms = region_ms if not distributed else timed_launches(K, lambda: shade(frames[0]))
+    # ... and with two frames in flight on two streams, like the N = 1 metric: a band of 1/N frame is mostly its own fill
+    # and drain (tools/gpu_band_timing.py), which the next frame's band overlaps
+    kernel_in_flight_ms = None
+    if distributed and len(frames) >= 2:
+        ko = [compute, torch.cuda.Stream()]
+
+        def two_in_flight(n):
+            for k in range(n):
+                with torch.cuda.stream(ko[k % 2]):
+                    shade(frames[k % 2])
+            compute.wait_stream(ko[1])
+        timed_launches(1, lambda: two_in_flight(32))
+        kernel_in_flight_ms = timed_launches(1, lambda: two_in_flight(K)) / K
     # N = 1: the same K launches on ONE stream, each behind the previous one (how rounds 1 and 2 ran the metric)
     single_stream_ms = timed_launches(K, lambda: shade(frames[0])) if (not distributed and n_streams > 1) else None
     kernel_ms_max = kernel_ms
@@ -496,6 +509,10 @@ def run_rank(args) -> int:
         per_rank_kernel_ms = [float(e[0].item()) for e in every]
         per_rank_pixels = [float(e[1].item()) for e in every]
         kernel_ms_max = max(per_rank_kernel_ms)
+        if kernel_in_flight_ms is not None:
+            t = torch.tensor([kernel_in_flight_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            kernel_in_flight_ms = float(t.item())
         dist.barrier()
         composite_ms = timed_launches(max(10, K // 4), lambda: comp.allgather_rows(frames[0]))
         t = torch.tensor([composite_ms], dtype=torch.float64, device=dev)
@@ -539,6 +556,7 @@ def run_rank(args) -> int:
     ms_per_step = elapsed / K * 1e3
 
     single_gpu_ms = None
+    single_gpu_in_flight_ms = None
     if distributed and strong and not args.no_single_gpu_reference:
         if rank == 0:                          # the same frame on ONE GPU, same run: the denominator of the speed-ups
             gw = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh), dev)
@@ -548,6 +566,18 @@ def run_rank(args) -> int:
             while time.perf_counter() - t_r < 0.05:
                 timed_launches(16, fn)
             single_gpu_ms = timed_launches(K, fn)
+            if kernel_in_flight_ms is not None:
+                whole2 = torch.zeros((fh, fw, 4), dtype=torch.float16, device=dev)
+                ko2 = [compute, torch.cuda.Stream()]
+
+                def whole_in_flight(n):
+                    for k in range(n):
+                        with torch.cuda.stream(ko2[k % 2]):
+                            r.shade_transmission(gw, uniforms, push, pyr, whole if k % 2 == 0 else whole2)
+                    compute.wait_stream(ko2[1])
+                timed_launches(1, lambda: whole_in_flight(64))
+                single_gpu_in_flight_ms = timed_launches(1, lambda: whole_in_flight(K)) / K
+                del whole2
             del gw, whole
         dist.barrier()
 
@@ -653,12 +683,19 @@ def run_rank(args) -> int:
                                   "per_rank_roofline_frac": [round(px_ * ALGORITHMIC_BYTES_PER_PIXEL / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                              if ms > 0 else None for ms, px_ in zip(per_rank_kernel_ms, per_rank_pixels)],
                                   "note": "the band kernels alone, max over ranks, no composite"}
+            if kernel_in_flight_ms is not None:
+                out["kernel_only"]["two_frames_in_flight"] = {
+                    "ms_per_step": round(kernel_in_flight_ms, 4),
+                    "Mpixels_per_s": round(pixels_step / kernel_in_flight_ms / 1e3, 1),
+                    "note": "the same with consecutive frames' bands on two HIP streams (max over ranks)"}
             out["composite_allgather_ms"] = round(composite_ms, 4)
             out["composite_rgba8_allgather_ms"] = round(composite_ldr_ms, 4)
             if single_gpu_ms is not None:
                 out["single_gpu_ms"] = round(single_gpu_ms, 4)
                 out["speedup_vs_1gpu"] = {"kernel_only": round(single_gpu_ms / kernel_ms_max, 3),
                                           "with_composite": round(single_gpu_ms / ms_per_step, 3)}
+                if kernel_in_flight_ms is not None:   # (both sides with two frames in flight)
+                    out["speedup_vs_1gpu"]["kernel_only_two_frames_in_flight"] = round(single_gpu_in_flight_ms / kernel_in_flight_ms, 3)
         if variants:
             out["variants"] = variants
         if frame_pipeline:

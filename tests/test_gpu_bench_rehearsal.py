@@ -30,3 +30,4 @@ def test_distributed_bench_path_on_one_gpu(fmt):
     assert out["kernel_only"]["per_rank_kernel_ms"][0] > 0 and 0 < out["kernel_only"]["per_rank_roofline_frac"][0] < 1
     assert out["composite_allgather_ms"] > 0 and out["composite_rgba8_allgather_ms"] > 0
     assert out["single_gpu_ms"] > 0 and out["speedup_vs_1gpu"]["kernel_only"] > 0.5
+    assert out["kernel_only"]["two_frames_in_flight"]["ms_per_step"] > 0 and out["speedup_vs_1gpu"]["kernel_only_two_frames_in_flight"] > 0.5

@@ -17,7 +17,8 @@ r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to
 pyr = OpaquePyramid(w, h, dev)
 pyr.level(0).copy_(bench.make_mip0_torch(w, h, dev))
 r.generate_mips(pyr)
-base = None
+base = base2 = None
+second = torch.cuda.Stream()
 for n in (1, 2, 4, 8):
     rows, y0, y1 = sharded.band_rows(h, n, 0)
     g = GBufferPlanes.from_numpy(synthetic.make_gbuffer(w, h, rows=(y0, y1)), dev)
@@ -33,4 +34,19 @@ for n in (1, 2, 4, 8):
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / 400 * 1e3
     base = base or us
-    print(f"band 0 of {n}: {y1 - y0} rows, {us:7.1f} us per launch back to back -> kernel-only speed-up {base / us:4.2f}x of {n}")
+    # the same with consecutive frames' bands on two streams (two targets): a band's fill and drain overlap the next one's
+    hdr2 = torch.zeros_like(hdr)
+    cur = torch.cuda.current_stream()
+
+    def in_flight(k):
+        for i in range(k):
+            with torch.cuda.stream(second if i & 1 else cur):
+                r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr2 if i & 1 else hdr, (0, y0, w, y1))
+        cur.wait_stream(second)
+    in_flight(64); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); in_flight(400); b.record(); torch.cuda.synchronize()
+    us2 = a.elapsed_time(b) / 400 * 1e3
+    base2 = base2 or us2
+    print(f"band 0 of {n}: {y1 - y0} rows, {us:7.1f} us per launch back to back -> kernel-only speed-up {base / us:4.2f}x of {n};"
+          f"  two frames in flight {us2:6.1f} us -> {base2 / us2:4.2f}x")
