@@ -76,8 +76,13 @@ def parse_args(argv=None):
                          "the refraction taps; the default run reports this variant beside the headline number")
     ap.add_argument("--no-variants", action="store_true", help="N = 1: skip the extra reported variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="N = 1: do not measure roofline.traffic live (two short child runs of this script under "
+                         "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`); the committed profiles/pmc_traffic.json is used instead")
     ap.add_argument("--no-single-gpu-reference", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--ramp-s", type=float, default=None, help="seconds of back-to-back launches before the warm-up (clock ramp; "
+                                                               "default 0.05, 0.15 with several frames in flight)")
     ap.add_argument("--launch-timeout-s", type=float, default=1500.0)
     ap.add_argument("--rehearse-distributed", action="store_true",
                     help="N = 1 only: run the N > 1 code path on one GPU (process group of one rank, the library's RCCL "
@@ -218,6 +223,53 @@ def cpu_baseline(scene, lut, width, height, budget_s=12.0):
     return {"value": rows_total * width / dt / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": f"oracle/tr_oracle.c o_shade_transmission ({how}), {reps} x {rows} rows x {width} px of the same "
                       f"frame ({rows_total * width / 1e6:.1f} Mpx) in {dt:.1f} s, {cores} threads"}
+
+
+def measure_traffic(args):
+    """HBM bytes per launch of the transmissive kernel from the PMC counters, measured NOW: two child runs of this script
+    (a few untimed launches, one stream) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — the
+    counters in separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled (gfx950 tallies
+    the 128-byte requests of 16 B/lane streaming reads at 64 B), KiB -> bytes.  Returns None when rocprofv3 is missing,
+    this process already runs under it, or anything fails (the committed profiles/pmc_traffic.json is used then)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="tr_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--streams", "1", "--no-cpu-baseline",
+                   "--no-variants", "--no-traffic", "--ramp-s", "0.0", "--width", str(args.width), "--height", str(args.height),
+                   "--lights", str(args.lights)] + (["--roughness-override", str(args.roughness_override)] if args.roughness_override is not None else []) \
+                  + (["--all-transmissive"] if args.all_transmissive else [])
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "shade_kernel<true" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if len(vals) < 4:
+                return None
+            vals.sort()
+            out[counter] = vals[len(vals) // 2] * 1024.0      # median over the launches, KiB -> bytes
+        return {"hbm_bytes_per_launch": int(round(2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"])),
+                "fetch_size_bytes_raw": int(round(out["FETCH_SIZE"])), "write_size_bytes": int(round(out["WRITE_SIZE"])),
+                "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child "
+                          "passes of this script (--steps 6 --streams 1; median over the kernel's launches), KiB -> bytes; FETCH_SIZE "
+                          "doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of 16 B/lane streaming reads at 64 B)"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def frame_pipeline_time(width, height):
@@ -429,7 +481,7 @@ def run_rank(args) -> int:
     #  launches after a second hardware queue comes into use run ~6 % slow, tools/gpu_overlap_probe.py — for 150 ms)
     t_ramp = time.perf_counter()
     ramp_k = 0
-    while time.perf_counter() - t_ramp < (0.15 if n_streams > 1 else 0.05):
+    while time.perf_counter() - t_ramp < (args.ramp_s if args.ramp_s is not None else (0.15 if n_streams > 1 else 0.05)):
         for _ in range(16):
             if n_streams > 1:
                 step(ramp_k)
@@ -657,18 +709,23 @@ def run_rank(args) -> int:
             "launch_sync_p50_ms": round(float(np.percentile(sync_ms, 50)), 4),
             "launch_log": launch_log,
         }
+        tr_ = None
+        if world == 1 and not distributed and not args.no_traffic:
+            tr_ = measure_traffic(args)            # live PMC passes (child processes; the GPU is idle here)
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file) and world == 1 and not args.all_transmissive and args.roughness_override is None:
+        if tr_ is None and os.path.exists(traffic_file) and world == 1 and not args.all_transmissive and args.roughness_override is None:
             try:
                 with open(traffic_file) as f:
-                    tr_ = json.load(f)
-                if tr_.get("width") == fw and tr_.get("height") == fh and tr_.get("lights") == args.lights:
-                    out["roofline"]["traffic"] = tr_["hbm_bytes_per_launch"]
-                    out["roofline"]["achieved_from_traffic"] = round(tr_["hbm_bytes_per_launch"] / kernel_s / 1e9, 1)
-                    out["roofline"]["frac_from_traffic"] = round(tr_["hbm_bytes_per_launch"] / kernel_s / 1e9 / HBM_PEAK_GBS, 4)
-                    out["roofline"]["traffic_source"] = tr_.get("source")
+                    committed = json.load(f)
+                if committed.get("width") == fw and committed.get("height") == fh and committed.get("lights") == args.lights:
+                    tr_ = committed
             except Exception:
                 pass
+        if tr_ is not None:
+            out["roofline"]["traffic"] = tr_["hbm_bytes_per_launch"]
+            out["roofline"]["achieved_from_traffic"] = round(tr_["hbm_bytes_per_launch"] / kernel_s / 1e9, 1)
+            out["roofline"]["frac_from_traffic"] = round(tr_["hbm_bytes_per_launch"] / kernel_s / 1e9 / HBM_PEAK_GBS, 4)
+            out["roofline"]["traffic_source"] = tr_.get("source")
         if single_stream_ms is not None:
             ss = single_stream_ms * 1e-3
             out["single_stream"] = {"avg_kernel_ms": round(single_stream_ms, 4),

@@ -12,7 +12,7 @@ C="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LEVEL_WAVES
 i=0
 for P in "$A" "$B" "$C"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/bench$i -o p -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants > $OUT/bench$i.log 2>&1 || echo "bench pass $i failed"
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/bench$i -o p -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants --no-traffic > $OUT/bench$i.log 2>&1 || echo "bench pass $i failed"
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/ubench$i -o p -- $R/build_ab/valu_rate > $OUT/ubench$i.log 2>&1 || echo "ubench pass $i failed"
 done
 python3 - $OUT <<'PY'
