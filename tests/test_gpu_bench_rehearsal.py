@@ -31,3 +31,32 @@ def test_distributed_bench_path_on_one_gpu(fmt):
     assert out["composite_allgather_ms"] > 0 and out["composite_rgba8_allgather_ms"] > 0
     assert out["single_gpu_ms"] > 0 and out["speedup_vs_1gpu"]["kernel_only"] > 0.5
     assert out["kernel_only"]["two_frames_in_flight"]["ms_per_step"] > 0 and out["speedup_vs_1gpu"]["kernel_only_two_frames_in_flight"] > 0.5
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_contract_and_live_traffic():
+    """The default command's JSON line at a reduced step count: the contract's keys, the roofline block priced on the
+    bytes the kernel moves, and roofline.traffic measured in the run by the two rocprofv3 --pmc child passes (skipped,
+    with the committed file as fallback, only where rocprofv3 is not installed)."""
+    import shutil
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline",
+                        "--no-variants"], env=env, capture_output=True, text=True, timeout=580)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 40 and out["dtype"] == "f32" and out["vs_baseline"] is None
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["algorithmic_bytes_per_pixel"] == 52 and r["streams"] == 2
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
+    assert abs(out["value"] - 3840 * 2160 / out["ms_per_step"] / 1e3) / out["value"] < 0.02     # value = pixels / wall time
+    assert out["single_stream"]["avg_kernel_ms"] >= 0.9 * r["avg_kernel_ms"]
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        assert r["traffic_source"].startswith("measured in this run"), r.get("traffic_source")
+    # nothing is fetched twice: the counters' bytes stay within a few per cent of the 52 B/px (and above the 44 a kernel
+    # that skipped the opaque-colour taps of every tile would move)
+    assert 0.85 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.05 * r["algorithmic_bytes_per_launch"]
