@@ -7,10 +7,12 @@
 //   contiguous band of the screen (or, for real frames, stripes of it): the data-dependent taps into the opaque
 //   pyramid then re-use texel rows inside one L2 instead of being fetched by all eight.
 //
-// What bounds it (rocprofv3 PMC, profiles/): VALU issue and latency, not HBM — ~460 vector instructions per
-// 64-pixel tile against 52-60 B of traffic per pixel.  So the math is arranged to be short, NOT as a transliteration
-// of the reference, and the kernel is kept at 64 VGPRs (8 waves per SIMD), because resident waves are what hides the
-// scalar-load, G-buffer and tap latencies:
+// What bounds it (rocprofv3 PMC and the TR_ABLATION builds): with the sun and one light HBM — the pass
+// moves its 52 B per pixel at 0.9 of the rate its own streaming skeleton reaches, and switching the lights off changes
+// nothing — because the ~410 vector instructions per 64-pixel tile hide behind the stream; every further light is vector
+// work on top.  That is why the math is arranged to be short, NOT as a transliteration of the reference, and why the
+// kernel is kept at 64 VGPRs (8 waves per SIMD): resident waves are what overlaps the arithmetic with the scalar-load,
+// G-buffer and tap latencies:
 //   * everything that depends only on the material is digested once per upload into `tr_dmat`
 //     and read through the scalar unit: a wave handles one material at a time (waves that
 //     straddle several run a waterfall loop over them), so there is a single code path and the
