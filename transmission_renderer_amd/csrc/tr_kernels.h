@@ -1368,6 +1368,17 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
 // forms the quad differences with two lane swizzles (the 16x4 wave tile holds whole 2x2 quads: partner lanes are
 // lane^1 and lane^16; the host guarantees an even rect origin) before the wave splits by material, and sends
 // materials flagged as textured through shade_pixel_textured.  The sRGB decode table sits in LDS.
+#ifndef TR_PLANES_NT_MASK
+#define TR_PLANES_NT_MASK (TEXTURED ? TR_PLANES_NT_MASK_TEXTURED : 1u)
+#endif
+#ifndef TR_PLANES_NT_MASK_TEXTURED
+#define TR_PLANES_NT_MASK_TEXTURED 10u   // (textured plane launches: normal + uv planes non-temporal; all four: +3 %)
+#endif
+template <class T, bool NT>
+__device__ __forceinline__ T ld_plane(const void* base, uint32_t byte_offset) {
+    if constexpr (NT) return ld_stream<T>(base, byte_offset);
+    else return ld<T>(base, byte_offset);
+}
 constexpr uint32_t kWaveTileW = 16u, kWaveTileH = 4u;                       // wave tile: 16x4 pixels
 constexpr uint32_t kBlockTileW = 4u * kWaveTileW, kBlockTileH = kWaveTileH;   // block tile: four of them side by side
 constexpr uint32_t kGridRounds = 8u;   // waves in the grid per resident wave
@@ -1410,6 +1421,7 @@ constexpr uint32_t kSlotsAll = 0xFFu, kSlotsMid = 0x07u;   // bit k: slot k of s
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, int TEX = kTexNone, bool VIS = false>
 __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
     constexpr bool TEXTURED = TEX != kTexNone;
+    constexpr uint32_t kPlanesNt = TR_PLANES_NT_MASK;   // which planes are loaded non-temporally (see fetch)
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
     __shared__ float lds_srgb[TEXTURED ? 256 : 1];
@@ -1512,8 +1524,12 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             t.cluster_x = 5; t.cluster_y_term = 0;
             return;
         }
-        // the planes are read once: non-temporal, so they do not displace the pyramid texels, LUT lines and cluster
-        // lists the kernel keeps re-reading from L2 (measured 115 -> 111 us)
+        // The planes are read once.  ONE of the two float4 planes is loaded non-temporally, so that the stream does not
+        // displace the pyramid texels, LUT lines and cluster lists the kernel keeps re-reading from L2; the other one and
+        // the ids are ordinary loads: the pass is bound by the memory system, and the streaming skeleton of
+        // this kernel runs 13 % faster on ordinary loads than on non-temporal ones (55.9 vs 64.2 us).  Both float4 planes
+        // non-temporal: 88.5 us; both ordinary: 88.2; one of each: 80.4 (4K, one stream).  TR_PLANES_NT_MASK (bit 0 the
+        // position plane, 1 the normal plane, 2 the ids, 3 the uv plane) is for the A/B builds of tools/.
         typedef float f4v __attribute__((ext_vector_type(4)));
         typedef float f2v __attribute__((ext_vector_type(2)));
         if constexpr (VIS) {
@@ -1552,11 +1568,11 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             }
             t.mat = id;
         } else {
-            t.mat = ld_stream<uint32_t>(F->material_id, gpix * 4u);
+            t.mat = ld_plane<uint32_t, (kPlanesNt & 4u) != 0u>(F->material_id, gpix * 4u);
         }
-        { const f4v a = ld_stream<f4v>(F->pos_depth, gpix * 16u); t.pd = float4{a.x, a.y, a.z, a.w}; }
-        { const f4v a = ld_stream<f4v>(F->nrm_scale, gpix * 16u); t.ns = float4{a.x, a.y, a.z, a.w}; }
-        if constexpr (TEXTURED) { const f2v a = ld_stream<f2v>(F->uv, gpix * 8u); t.uv = float2{a.x, a.y}; }
+        { const f4v a = ld_plane<f4v, (kPlanesNt & 1u) != 0u>(F->pos_depth, gpix * 16u); t.pd = float4{a.x, a.y, a.z, a.w}; }
+        { const f4v a = ld_plane<f4v, (kPlanesNt & 2u) != 0u>(F->nrm_scale, gpix * 16u); t.ns = float4{a.x, a.y, a.z, a.w}; }
+        if constexpr (TEXTURED) { const f2v a = ld_plane<f2v, (kPlanesNt & 8u) != 0u>(F->uv, gpix * 8u); t.uv = float2{a.x, a.y}; }
         t.cluster_x = (uint32_t)ld<uint16_t>(F->cluster_x, cx * 2u);
         t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
     };
