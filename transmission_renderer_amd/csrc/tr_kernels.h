@@ -1369,7 +1369,7 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
 // lane^1 and lane^16; the host guarantees an even rect origin) before the wave splits by material, and sends
 // materials flagged as textured through shade_pixel_textured.  The sRGB decode table sits in LDS.
 #ifndef TR_PLANES_NT_MASK
-#define TR_PLANES_NT_MASK (TEXTURED ? TR_PLANES_NT_MASK_TEXTURED : 1u)
+#define TR_PLANES_NT_MASK (TEXTURED ? TR_PLANES_NT_MASK_TEXTURED : TRANSMISSIVE ? 1u : 5u)   // (opaque pass: position + ids: 73 -> 69 us)
 #endif
 #ifndef TR_PLANES_NT_MASK_TEXTURED
 #define TR_PLANES_NT_MASK_TEXTURED 10u   // (textured plane launches: normal + uv planes non-temporal; all four: +3 %)
