@@ -7,13 +7,19 @@ metric   shaded Mpixels/s (+ p50 frame ms) of the 4K transmissive pass: `fragmen
 step     one transmissive pass over one 3840x2160 frame (tr_shade_transmission) — at N > 1 followed by the
          composite (tr_allgather_frame: RCCL all-gather of the row bands; by default of the frame AS PRESENTED: every
          rank tonemaps its band to RGBA8 inside the step, `--composite-format rgba16f` gathers the HDR target instead).
-frames in flight (N = 1)   `--streams S` (default 2): the K frames of the timed region are independent (a renderer has
-         S frames in flight: S colour targets), so step k is issued on HIP stream k mod S into target k mod S and the
-         hardware starts frame k+1's waves in the wave slots frame k's stragglers leave empty — on ONE stream a launch
-         waits for the last wave of the one before, and ~5 % of the launch is its fill and drain (tools/gpu_overlap_probe.py).
-         `value` and `roofline` are wall clock / K of that region; kernels of different streams overlap, so a kernel's
-         own start-to-end duration (what rocprofv3 lists) is about S times that; the same K launches on ONE stream are
-         timed right after and reported as `single_stream` (frac and ms, the round-1/2 way of running it).
+one frame, two launches (N = 1)   `--split P` (default 2): a step shades the frame as P row bands (tr_band_rows: 4-row
+         aligned), band i through its own tr_shade_transmission call (the sharding API's rect) on HIP stream i.  On ONE
+         stream a launch waits for the last wave of the one before, and ~5 % of a launch is its fill and drain; with the
+         frame in two half-frame launches on two streams the hardware starts one band's waves in the wave slots the other
+         band's stragglers leave empty — disjoint halves of one frame, nothing shared, nothing cached (4K: 81.4 -> 76.9 us,
+         tools/gpu_overlap_probe.py; four bands on four streams: 83.8).  `value` and `roofline` are wall clock / K of that
+         region; a launch's own start-to-end duration (what rocprofv3 lists) is about one step, for half a frame.  The
+         same K frames as whole-frame launches on one stream are timed right after and reported as `single_stream`.
+frames in flight (N = 1)   `--streams S` (default 1): S > 1 issues step k on HIP stream k mod S, every frame in flight with
+         its OWN copy of the G-buffer planes, the opaque pyramid and the colour target (and one launch per frame).  Two
+         such frames gain nothing (83.8 vs 81.4 us: two frames' windows in every L2).  (Round 3's first bench ran two
+         frames in flight over ONE shared G-buffer: the second frame found the first one's plane reads in the caches —
+         75.8 us — which no renderer's consecutive frames do.  Those figures are withdrawn.)
 
 python bench.py --gpus N   starts by itself: with WORLD_SIZE unset and N > 1 it spawns N child processes (one per
          GPU, before anything touches a GPU) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 set; under
@@ -68,9 +74,11 @@ def parse_args(argv=None):
     ap.add_argument("--composite-format", choices=("rgba8", "rgba16f"), default="rgba8",
                     help="N > 1: what is composited — rgba8: the frame as it is presented (every rank tonemaps its band with "
                          "tr_tonemap inside the step, the 4 B/px bands are gathered); rgba16f: the HDR target itself (8 B/px)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="N = 1: frames in flight — step k goes to HIP stream k mod S and colour target k mod S (1: every "
-                         "launch behind the previous one on one stream)")
+    ap.add_argument("--split", type=int, default=2,
+                    help="N = 1: a step shades the frame as P row bands, band i on HIP stream i (1: one whole-frame launch)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="N = 1: frames in flight — step k goes to HIP stream k mod S, every frame in flight with its own inputs "
+                         "and target (S > 1 implies --split 1)")
     ap.add_argument("--all-transmissive", action="store_true",
                     help="every synthetic material gets transmission_factor 1 (DragonAttenuation's is 1): no tile skips "
                          "the refraction taps; the default run reports this variant beside the headline number")
@@ -244,7 +252,7 @@ def measure_traffic(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
-                   sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--streams", "1", "--no-cpu-baseline",
+                   sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--streams", "1", "--split", "1", "--no-cpu-baseline",
                    "--no-variants", "--no-traffic", "--ramp-s", "0.0", "--width", str(args.width), "--height", str(args.height),
                    "--lights", str(args.lights)] + (["--roughness-override", str(args.roughness_override)] if args.roughness_override is not None else []) \
                   + (["--all-transmissive"] if args.all_transmissive else [])
@@ -264,7 +272,7 @@ def measure_traffic(args):
         return {"hbm_bytes_per_launch": int(round(2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"])),
                 "fetch_size_bytes_raw": int(round(out["FETCH_SIZE"])), "write_size_bytes": int(round(out["WRITE_SIZE"])),
                 "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child "
-                          "passes of this script (--steps 6 --streams 1; median over the kernel's launches), KiB -> bytes; FETCH_SIZE "
+                          "passes of this script (--steps 6 --split 1: whole-frame launches; median over the kernel's launches), KiB -> bytes; FETCH_SIZE "
                           "doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of 16 B/lane streaming reads at 64 B)"}
     except Exception:
         return None
@@ -412,11 +420,24 @@ def run_rank(args) -> int:
     r.upload_ggx_lut(lut)
     r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(dev),
                          torch.from_numpy(scene["light_indices"].view(np.int32)).to(dev))
+    rect_whole = (0, y0, fw, y1)
     g = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh, rows=(y0, y1) if y1 > y0 else (0, 1)), dev)   # this rank's screen tile only
     pyr = OpaquePyramid(fw, fh, dev)                                                  # replicated read-only input
     pyr.level(0).copy_(make_mip0_torch(fw, fh, dev))
     r.generate_mips(pyr)
     n_streams = max(1, args.streams) if not distributed else 1
+    split = max(1, args.split) if (not distributed and n_streams == 1) else 1
+    parts = [(0, a, fw, b) for a, b in (sharded.band_rows(fh, split, i)[1:] for i in range(split)) if b > a] if split > 1 else [rect_whole]
+    # every frame in flight has its OWN inputs as well as its own target — its own copy of the G-buffer planes and of the
+    # opaque pyramid (consecutive frames of a renderer are different frames: one frame must not find the other's
+    # plane reads in the caches)
+    gs = [g] + [GBufferPlanes(g.pos_depth.clone(), g.nrm_scale.clone(), g.uv.clone(), g.material_id.clone(), g.origin_x, g.origin_y)
+                for _ in range(n_streams - 1)]
+    pyrs = [pyr]
+    for _ in range(n_streams - 1):
+        p2 = OpaquePyramid(fw, fh, dev)
+        p2.texels.copy_(pyr.texels)
+        pyrs.append(p2)
     frames = [torch.zeros((padded, fw, 4), dtype=torch.float16, device=dev)
               for _ in range(2 if composite == "overlap" else n_streams)]
     uniforms, push = scene["uniforms"], scene["push"]
@@ -432,14 +453,14 @@ def run_rank(args) -> int:
 
     compute = torch.cuda.current_stream()
     comm = torch.cuda.Stream() if composite == "overlap" else None
-    flight = [compute] + [torch.cuda.Stream() for _ in range(n_streams - 1)]   # N = 1: one stream per frame in flight
+    flight = [compute] + [torch.cuda.Stream() for _ in range(max(n_streams, len(parts)) - 1)]   # N = 1: a stream per band / frame in flight
     shaded = [torch.cuda.Event() for _ in frames]
     gathered = [None for _ in frames]
     launches = {"count": 0}
 
-    def shade(buf):
+    def shade(buf, slot=0):
         if y1 > y0:     # (a band can be empty when the height is far from a multiple of 4 N; it still joins the gathers)
-            r.shade_transmission(g, uniforms, push, pyr, buf, rect)
+            r.shade_transmission(gs[slot], uniforms, push, pyrs[slot], buf, rect)
         launches["count"] += 1
 
     def present(i):
@@ -468,7 +489,12 @@ def run_rank(args) -> int:
                 gathered[i] = ev
         elif n_streams > 1:
             with torch.cuda.stream(flight[k % n_streams]):
-                shade(buf)
+                shade(buf, k % n_streams)
+        elif len(parts) > 1:
+            for i, part in enumerate(parts):       # the frame's row bands, each on its own stream
+                with torch.cuda.stream(flight[i]):
+                    r.shade_transmission(g, uniforms, push, pyr, buf, part)
+                    launches["count"] += 1
         else:
             shade(buf)
             if composite == "serial":
@@ -481,9 +507,10 @@ def run_rank(args) -> int:
     #  launches after a second hardware queue comes into use run ~6 % slow, tools/gpu_overlap_probe.py — for 150 ms)
     t_ramp = time.perf_counter()
     ramp_k = 0
-    while time.perf_counter() - t_ramp < (args.ramp_s if args.ramp_s is not None else (0.15 if n_streams > 1 else 0.05)):
+    multi = n_streams > 1 or len(parts) > 1
+    while time.perf_counter() - t_ramp < (args.ramp_s if args.ramp_s is not None else (0.15 if multi else 0.05)):
         for _ in range(16):
-            if n_streams > 1:
+            if multi:
                 step(ramp_k)
                 ramp_k += 1
             else:
@@ -521,7 +548,7 @@ def run_rank(args) -> int:
         elapsed = float(t.item())
     region_ms = max(ev0[0].elapsed_time(e) for e in ev1) / K
     # a launch's own time on its stream (what a per-kernel trace shows: launches of different streams overlap)
-    in_stream_ms = max(a.elapsed_time(b) / max(1, len(range(i, K, n_streams)))
+    in_stream_ms = max(a.elapsed_time(b) / max(1, K if len(parts) > 1 else len(range(i, K, n_streams)))
                        for i, (a, b) in enumerate(zip(ev0, ev1)))
 
     # ---- outside the timed region -------------------------------------------------------------------------------
@@ -541,16 +568,21 @@ def run_rank(args) -> int:
     kernel_in_flight_ms = None
     if distributed and len(frames) >= 2:
         ko = [compute, torch.cuda.Stream()]
+        if len(gs) < 2:      # (the second frame in flight reads its own copy of the band's planes and of the pyramid)
+            gs.append(GBufferPlanes(g.pos_depth.clone(), g.nrm_scale.clone(), g.uv.clone(), g.material_id.clone(), g.origin_x, g.origin_y))
+            p2 = OpaquePyramid(fw, fh, dev)
+            p2.texels.copy_(pyr.texels)
+            pyrs.append(p2)
 
         def two_in_flight(n):
             for k in range(n):
                 with torch.cuda.stream(ko[k % 2]):
-                    shade(frames[k % 2])
+                    shade(frames[k % 2], k % 2)
             compute.wait_stream(ko[1])
         timed_launches(1, lambda: two_in_flight(32))
         kernel_in_flight_ms = timed_launches(1, lambda: two_in_flight(K)) / K
     # N = 1: the same K launches on ONE stream, each behind the previous one (how rounds 1 and 2 ran the metric)
-    single_stream_ms = timed_launches(K, lambda: shade(frames[0])) if (not distributed and n_streams > 1) else None
+    single_stream_ms = timed_launches(K, lambda: shade(frames[0])) if (not distributed and multi) else None
     kernel_ms_max = kernel_ms
     composite_ms = None
     per_rank_kernel_ms = [kernel_ms]
@@ -594,7 +626,8 @@ def run_rank(args) -> int:
         shade(frames[0])
         torch.cuda.synchronize()
         sync_ms.append((time.perf_counter() - t1) * 1e3)
-    launch_log = [("clock_ramp", clock_ramp_launches), ("warmup", W), ("timed", K)]
+    lps = len(parts) if (not distributed and n_streams == 1) else 1      # kernel launches per step
+    launch_log = [("clock_ramp", clock_ramp_launches), ("warmup", W * lps), ("timed", K * lps)]
     if distributed:
         launch_log.append(("kernel_only", K))
     if single_stream_ms is not None:
@@ -620,16 +653,17 @@ def run_rank(args) -> int:
             single_gpu_ms = timed_launches(K, fn)
             if kernel_in_flight_ms is not None:
                 whole2 = torch.zeros((fh, fw, 4), dtype=torch.float16, device=dev)
+                gw2 = GBufferPlanes(gw.pos_depth.clone(), gw.nrm_scale.clone(), gw.uv.clone(), gw.material_id.clone())
                 ko2 = [compute, torch.cuda.Stream()]
 
                 def whole_in_flight(n):
                     for k in range(n):
                         with torch.cuda.stream(ko2[k % 2]):
-                            r.shade_transmission(gw, uniforms, push, pyr, whole if k % 2 == 0 else whole2)
+                            r.shade_transmission(gw if k % 2 == 0 else gw2, uniforms, push, pyrs[k % 2], whole if k % 2 == 0 else whole2)
                     compute.wait_stream(ko2[1])
                 timed_launches(1, lambda: whole_in_flight(64))
                 single_gpu_in_flight_ms = timed_launches(1, lambda: whole_in_flight(K)) / K
-                del whole2
+                del whole2, gw2
             del gw, whole
         dist.barrier()
 
@@ -646,7 +680,7 @@ def run_rank(args) -> int:
                 compute.wait_stream(s_)
         timed_launches(200, lambda: shade(frames[0]))
         ms = timed_launches(1, lambda: in_flight(K)) / K
-        launch_log += [("all_transmissive_ramp", 200), ("all_transmissive", K)]
+        launch_log += [("all_transmissive_ramp", 200), ("all_transmissive", K * lps)]
         variants["all_transmissive"] = {
             "avg_kernel_ms": round(ms, 4), "Mpixels_per_s": round(pixels_rank / ms / 1e3, 1),
             "frac": round(pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -682,8 +716,10 @@ def run_rank(args) -> int:
                                    + (f", roughness override {args.roughness_override}" if args.roughness_override is not None else "")
                                    + f", sun + {args.lights} punctual light(s) (DragonAttenuation rig), RGBA16F target, "
                                      f"{pyr.levels}-level opaque pyramid, ggx_lut.png"
-                                   + (f", {n_streams} frames in flight (one HIP stream and one colour target each)"
-                                      if n_streams > 1 else ""),
+                                   + (f", {n_streams} frames in flight (each on its own HIP stream, with its own G-buffer planes, opaque pyramid and colour target)"
+                                      if n_streams > 1 else "")
+                                   + (f", every frame shaded as {len(parts)} row bands (one tr_shade_transmission call each) on {len(parts)} HIP streams"
+                                      if lps > 1 else ""),
                        "pixels_per_step": pixels_step, "pixels_per_gpu": pixels_rank,
                        "sharding": f"{world} row band(s) of {rows_per_rank} rows (tr_band_rows)",
                        "composite": ("none (one GPU holds the frame)" if not distributed else
@@ -698,13 +734,14 @@ def run_rank(args) -> int:
                          "algorithmic_bytes_per_pixel": ALGORITHMIC_BYTES_PER_PIXEL,
                          "algorithmic_bytes_per_launch": pixels_rank * ALGORITHMIC_BYTES_PER_PIXEL,
                          "frac_survey_60B": round(pixels_rank * SURVEY_BYTES_PER_PIXEL / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
-                         "streams": n_streams,
+                         "streams": n_streams, "launches_per_step": lps,
                          "kernel_ms_on_its_stream": round(in_stream_ms, 4),
                          "note": "52 B/px = what this untextured variant moves (16 + 16 + 4 B planes, 8 B opaque colour, 8 B "
                                  "write; = SURVEY 8d's read-only figure); SURVEY 8d's 60 B/px also counts the 8 B/px uv plane, "
-                                 "which this kernel never loads (frac_survey_60B).  avg_kernel_ms = timed region / K with "
-                                 f"{n_streams} frame(s) in flight; kernel_ms_on_its_stream = the same launches as a per-kernel "
-                                 "trace sees them (they overlap across streams)"},
+                                 "which this kernel never loads (frac_survey_60B).  avg_kernel_ms = timed region / K = the time "
+                                 f"of a step: {lps} launch(es) of the kernel, one per row band of the frame, each on its own stream; "
+                                 "kernel_ms_on_its_stream = a launch's own duration as a per-kernel trace sees it (the bands' "
+                                 "launches overlap: about one step for 1 / launches_per_step of the frame's bytes)"},
             "clock_ramp_launches": clock_ramp_launches,
             "launch_sync_p50_ms": round(float(np.percentile(sync_ms, 50)), 4),
             "launch_log": launch_log,

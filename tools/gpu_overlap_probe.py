@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """How much of the 4K transmissive launch is head / tail / inter-launch gap: the same K launches issued (a) back to back
-on one stream, (b) alternately on S streams with S frame buffers (independent frames in flight), (c) every frame as two
-half-frame rects on two streams.  Prints wall-clock us per frame for each.  python tools/gpu_overlap_probe.py [lights]"""
+on one stream, (b) alternately on S streams with S frame buffers — sharing ONE set of inputs (what round 3's first bench
+did: the second frame finds the first one's plane reads in the caches, a frame of a real renderer does not) and with its
+own copy of the G-buffer planes and the pyramid per frame in flight —, (c) every frame as two / four row bands on two /
+four streams (disjoint parts of one frame: nothing shared).  Prints wall-clock us per frame for each.  python tools/gpu_overlap_probe.py [lights]"""
 import json
 import os
 import sys
@@ -33,6 +35,12 @@ pyr = OpaquePyramid(w, h, r.device)
 pyr.level(0).copy_(torch.from_numpy(synthetic.make_opaque_mip0(w, h)).to(r.device))
 r.generate_mips(pyr)
 S_MAX = 4
+gs = [g] + [GBufferPlanes(g.pos_depth.clone(), g.nrm_scale.clone(), g.uv.clone(), g.material_id.clone()) for _ in range(S_MAX - 1)]
+pyrs = [pyr]
+for _ in range(S_MAX - 1):
+    q = OpaquePyramid(w, h, r.device)
+    q.texels.copy_(pyr.texels)
+    pyrs.append(q)
 hdrs = [torch.zeros((h, w, 4), dtype=torch.float16, device=r.device) for _ in range(S_MAX)]
 streams = [torch.cuda.Stream() for _ in range(S_MAX)]
 u, p = scene["uniforms"], scene["push"]
@@ -67,19 +75,29 @@ def multi(S):
     return fn
 
 
-def halves(K):
-    for k in range(K):
-        with torch.cuda.stream(streams[0]):
-            r.shade_transmission(g, u, p, pyr, hdrs[0], (0, 0, w, h // 2))
-        with torch.cuda.stream(streams[1]):
-            r.shade_transmission(g, u, p, pyr, hdrs[0], (0, h // 2, w, h))
+def multi_own(S):
+    def fn(K):
+        for k in range(K):
+            with torch.cuda.stream(streams[k % S]):
+                r.shade_transmission(gs[k % S], u, p, pyrs[k % S], hdrs[k % S])
+    return fn
+
+
+def parts(n):
+    rows = ((h // n + 3) // 4) * 4
+    def fn(K):
+        for k in range(K):
+            for i in range(n):
+                with torch.cuda.stream(streams[i]):
+                    r.shade_transmission(g, u, p, pyr, hdrs[0], (0, i * rows, w, min(h, (i + 1) * rows)))
+    return fn
 
 
 res = {}
 ramp()
 for rep in range(3):
-    for name, fn in (("one_stream", one_stream), ("two_streams", multi(2)), ("three_streams", multi(3)),
-                     ("four_streams", multi(4)), ("halves_two_streams", halves)):
+    for name, fn in (("one_stream", one_stream), ("two_streams_shared_inputs", multi(2)), ("two_streams_own_inputs", multi_own(2)),
+                     ("three_streams_own_inputs", multi_own(3)), ("halves_two_streams", parts(2)), ("quarters_four_streams", parts(4))):
         fn(50)
         res.setdefault(name, []).append(round(wall(fn), 2))
 print(json.dumps({"lights": nl, "all_transmissive": all_t, "us_per_frame": res}))

@@ -4,7 +4,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-pmc}
-ARGS="${2:---steps 20 --warmup 3 --no-cpu-baseline --no-variants --no-traffic}"
+ARGS="${2:---steps 20 --warmup 3 --no-cpu-baseline --no-variants --no-traffic --split 1}"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
