@@ -36,12 +36,15 @@ for n in (1, 2, 4, 8):
     base = base or us
     # the same with consecutive frames' bands on two streams (two targets): a band's fill and drain overlap the next one's
     hdr2 = torch.zeros_like(hdr)
+    g2 = GBufferPlanes(g.pos_depth.clone(), g.nrm_scale.clone(), g.uv.clone(), g.material_id.clone(), g.origin_x, g.origin_y)
+    pyr2 = OpaquePyramid(w, h, dev)      # (a frame in flight has its own inputs: nothing of the other frame's in the caches)
+    pyr2.texels.copy_(pyr.texels)
     cur = torch.cuda.current_stream()
 
     def in_flight(k):
         for i in range(k):
             with torch.cuda.stream(second if i & 1 else cur):
-                r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr2 if i & 1 else hdr, (0, y0, w, y1))
+                r.shade_transmission(g2 if i & 1 else g, scene["uniforms"], scene["push"], pyr2 if i & 1 else pyr, hdr2 if i & 1 else hdr, (0, y0, w, y1))
         cur.wait_stream(second)
     in_flight(64); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
