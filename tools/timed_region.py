@@ -18,7 +18,7 @@ pos = 0
 for phase, count in b["launch_log"]:
     seg = d[pos:pos + count]
     if seg:
-        # span_per_launch: (last end - first start) / launches of the phase — with S frames in flight the launches of
+        # span_per_launch: (last end - first start) / launches of the phase — with the frame's bands (or S frames) on several streams the launches of
         # different streams overlap, a launch's own start-to-end duration ("avg") is then ~S x the time per frame
         span = (max(t1s[pos:pos + count]) - min(t0s[pos:pos + count])) / len(seg)
         out["phases"][phase] = {"launches": len(seg), "avg": r(st.mean(seg)), "p50": r(st.median(seg)), "min": r(min(seg)), "max": r(max(seg)),
