@@ -93,11 +93,24 @@ def parts(n):
     return fn
 
 
+def strips(n, rows):
+    """the frame as n launches of rank-interleaved strips (tr_set_strips): launch i shades strips i, i + n, ... of `rows` rows"""
+    def fn(K):
+        for k in range(K):
+            for i in range(n):
+                r.set_strips(rows, n, i)
+                with torch.cuda.stream(streams[i]):
+                    r.shade_transmission(g, u, p, pyr, hdrs[0], (0, 0, w, h))
+        r.set_strips(0, 1, 0)
+    return fn
+
+
 res = {}
 ramp()
 for rep in range(3):
     for name, fn in (("one_stream", one_stream), ("two_streams_shared_inputs", multi(2)), ("two_streams_own_inputs", multi_own(2)),
-                     ("three_streams_own_inputs", multi_own(3)), ("halves_two_streams", parts(2)), ("quarters_four_streams", parts(4))):
+                     ("three_streams_own_inputs", multi_own(3)), ("halves_two_streams", parts(2)), ("quarters_four_streams", parts(4)),
+                     ("strips136_two_streams", strips(2, 136)), ("strips68_two_streams", strips(2, 68)), ("strips272_two_streams", strips(2, 272))):
         fn(50)
         res.setdefault(name, []).append(round(wall(fn), 2))
 print(json.dumps({"lights": nl, "all_transmissive": all_t, "us_per_frame": res}))
