@@ -41,6 +41,8 @@ def _whole_frame(r, scene, g, w, h):
     (320, 136, 2, 64, "full"),      # 3 strips on 2 ranks, the last one 8 rows
     (130, 44, 8, 4, "holes"),       # ragged right edge, strips of one tile row, ranks 3..7 own a single strip
     (64, 12, 8, 4, "full"),         # more ranks than strips: ranks 3..7 own nothing
+    (192, 200, 2, 4, "holes"),      # strips of one tile row, 25 strips per rank (strip_magic of T = 1 must not wrap to 0)
+    (128, 92, 3, 4, "full"),        # ... 23 strips on 3 ranks: 8 / 8 / 7
 ])
 def test_strips_in_place_equal_whole_frame(renderer, w, h, world, strip_rows, coverage):
     from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid

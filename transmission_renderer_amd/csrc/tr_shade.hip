@@ -155,6 +155,18 @@ struct tr_context {
     bool slice_valid = false;
     uint32_t slice_max = 0;
     float h_slice_thr[TR_MAX_DEPTH_SLICES + 2]{};
+
+    // The lazily built device tables (digested materials, LUT lines, level table, tap records, cluster x / y tables, slice
+    // thresholds) are enqueued on the stream of the call that finds them stale.  A context may be driven from several
+    // streams (a pass as two bands on two streams): a call on ANOTHER stream waits for `tables_event`
+    // (recorded behind the last build) before it launches, and a rebuild first waits for every stream that launched
+    // against the previous tables (tables_before_rebuild).
+    hipEvent_t tables_event = nullptr;
+    hipStream_t tables_stream = nullptr;
+    uint64_t tables_generation = 0;
+    struct stream_seen { hipStream_t stream; uint64_t generation; };
+    std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
+    bool no_mid_class = false;                  // TR_NO_MID_CLASS (tests only), read once at context creation
 };
 
 namespace {
@@ -178,9 +190,47 @@ uint32_t mip_levels_for_size(uint32_t w, uint32_t h) {
     return li + 1u;
 }
 
+// Before a lazily built table is overwritten on `stream`: launches enqueued on other streams may still read it.
+// (Rebuilds are rare — new materials, another pyramid geometry, other cluster coefficients — so this is a device-wide
+// wait, not an event per launch.)
+tr_status tables_before_rebuild(tr_context* ctx, hipStream_t stream) {
+    bool others = false;
+    for (const auto& s : ctx->launch_streams) others |= s.stream != stream;
+    if (others) TR_HIP(ctx, hipDeviceSynchronize());
+    ctx->launch_streams.clear();
+    return TR_OK;
+}
+// After table work was enqueued on `stream`.
+tr_status tables_rebuilt(tr_context* ctx, hipStream_t stream) {
+    if (!ctx->tables_event) TR_HIP(ctx, hipEventCreateWithFlags(&ctx->tables_event, hipEventDisableTiming));
+    TR_HIP(ctx, hipEventRecord(ctx->tables_event, stream));
+    ctx->tables_stream = stream;
+    ctx->tables_generation += 1u;
+    return TR_OK;
+}
+// Before a launch on `stream` that reads the tables: ordered behind the build when that ran on another stream.
+tr_status tables_acquire(tr_context* ctx, hipStream_t stream) {
+    for (auto& s : ctx->launch_streams) {
+        if (s.stream != stream) continue;
+        if (s.generation == ctx->tables_generation) return TR_OK;
+        if (stream != ctx->tables_stream && ctx->tables_event) TR_HIP(ctx, hipStreamWaitEvent(stream, ctx->tables_event, 0));
+        s.generation = ctx->tables_generation;
+        return TR_OK;
+    }
+    if (stream != ctx->tables_stream && ctx->tables_event) TR_HIP(ctx, hipStreamWaitEvent(stream, ctx->tables_event, 0));
+    ctx->launch_streams.push_back({stream, ctx->tables_generation});
+    return TR_OK;
+}
+#define TR_TRY(expr)                         \
+    do {                                     \
+        const tr_status st_ = (expr);        \
+        if (st_ != TR_OK) return st_;        \
+    } while (0)
+
 tr_status ensure_digested(tr_context* ctx, hipStream_t stream) {
     if (!ctx->dmats_dirty) return TR_OK;
     if (ctx->num_materials == 0 || ctx->lut_h == 0) return TR_ERR_TABLES_MISSING;
+    TR_TRY(tables_before_rebuild(ctx, stream));
     uint32_t n = ctx->num_materials;
     hipLaunchKernelGGL(digest_materials_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, ctx->d_materials_raw,
                        ctx->d_dmats, n, ctx->lut_h, ctx->lut_stride);
@@ -199,7 +249,7 @@ tr_status ensure_digested(tr_context* ctx, hipStream_t stream) {
     TR_HIP(ctx, hipGetLastError());
     ctx->dmats_dirty = false;
     ctx->dtaps_valid = false;
-    return TR_OK;
+    return tables_rebuilt(ctx, stream);
 }
 
 tr_status ensure_levels(tr_context* ctx, const tr_pyramid* p, hipStream_t stream) {
@@ -208,6 +258,7 @@ tr_status ensure_levels(tr_context* ctx, const tr_pyramid* p, hipStream_t stream
         same = ctx->h_levels.offset[l] == p->level_offset[l] && ctx->h_levels.width[l] == level_dim(p->width, l) &&
                ctx->h_levels.height[l] == level_dim(p->height, l);
     if (same) return TR_OK;
+    TR_TRY(tables_before_rebuild(ctx, stream));
     std::memset(&ctx->h_levels, 0, sizeof(ctx->h_levels));
     for (uint32_t l = 0; l < p->levels; ++l) {
         ctx->h_levels.offset[l] = p->level_offset[l];
@@ -220,7 +271,7 @@ tr_status ensure_levels(tr_context* ctx, const tr_pyramid* p, hipStream_t stream
     ctx->h_levels_count = p->levels;
     ctx->dtaps_valid = false;
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_levels, &ctx->h_levels, sizeof(tr_level_table), hipMemcpyHostToDevice, stream));
-    return TR_OK;
+    return tables_rebuilt(ctx, stream);
 }
 
 // The per-material tap records of the transmissive pass (tr_dtap): after ensure_digested and ensure_levels.
@@ -228,13 +279,14 @@ tr_status ensure_tap_records(tr_context* ctx, float log2_fb_width, hipStream_t s
     if (ctx->dtaps_valid && std::memcmp(&ctx->dtaps_log2_width, &log2_fb_width, sizeof(float)) == 0) return TR_OK;
     if (!ctx->d_dtaps || ctx->num_materials == 0 || ctx->h_levels_count == 0) return TR_ERR_TABLES_MISSING;
     if ((uint64_t)ctx->h_levels.offset[ctx->h_levels_count - 1u] * 8u + 16u > 0xFFFFFFFFull) return TR_ERR_UNSUPPORTED;
+    TR_TRY(tables_before_rebuild(ctx, stream));
     hipLaunchKernelGGL(digest_taps_kernel, dim3((ctx->num_materials + 63u) / 64u), dim3(64), 0, stream,
                        (const tr_dmat*)ctx->d_dmats, (const tr_level_table*)ctx->d_levels, ctx->h_levels_count, log2_fb_width,
                        ctx->d_dtaps, ctx->num_materials);
     TR_HIP(ctx, hipGetLastError());
     ctx->dtaps_valid = true;
     ctx->dtaps_log2_width = log2_fb_width;
-    return TR_OK;
+    return tables_rebuilt(ctx, stream);
 }
 
 // The sRGB transfer functions of the Khronos data format specification (13.3), with the host's libm.
@@ -285,6 +337,7 @@ tr_status ensure_cluster_tables(tr_context* ctx, const tr_uniforms* u, uint32_t 
     if (ctx->d_cluster_x && ctx->cl_w == fw && ctx->cl_h == fh && ctx->cl_sx == sx && ctx->cl_sy == sy &&
         ctx->cl_ncx == ncx)
         return TR_OK;
+    TR_TRY(tables_before_rebuild(ctx, stream));
     if (fw > ctx->cl_cap_w) {
         (void)hipFree(ctx->d_cluster_x);
         ctx->d_cluster_x = nullptr;
@@ -315,7 +368,7 @@ tr_status ensure_cluster_tables(tr_context* ctx, const tr_uniforms* u, uint32_t 
     ctx->cl_sx = sx;
     ctx->cl_sy = sy;
     ctx->cl_ncx = ncx;
-    return TR_OK;
+    return tables_rebuilt(ctx, stream);
 }
 
 // LightClusterCoefficients::get_depth_slice (shared-structs/src/lib.rs:43-63) with the reference's own fp32
@@ -357,12 +410,13 @@ tr_status ensure_slice_thresholds(tr_context* ctx, const tr_uniforms* u, hipStre
     uint32_t top = 0;
     const tr_status st = build_slice_thresholds(c, ctx->h_slice_thr, &top);
     if (st != TR_OK) return st;
-    // (stream order protects the launches that still read the previous table)
+    // (stream order protects this stream's launches that still read the previous table; other streams': below)
+    TR_TRY(tables_before_rebuild(ctx, stream));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_slice_thr, ctx->h_slice_thr, sizeof(float) * (top + 2u), hipMemcpyHostToDevice, stream));
     ctx->slice_coeffs = c;
     ctx->slice_max = top;
     ctx->slice_valid = true;
-    return TR_OK;
+    return tables_rebuilt(ctx, stream);
 }
 
 tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u,
@@ -418,7 +472,7 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
         if (owned != 0u && (strips - 1u) % ctx->strip_world == ctx->strip_rank) rows -= strips * T - frame_tile_rows;   // the frame's last strip is short
         fp->tiles_y = rows;
         fp->strip_tile_rows = T;
-        fp->strip_magic = (uint32_t)((1ull << 32) / T);
+        fp->strip_magic = T == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / T);   // (2^32 / 1 does not fit: clamped like the other magics)
         fp->strip_world = ctx->strip_world;
         fp->strip_rank = ctx->strip_rank;
     }
@@ -546,7 +600,7 @@ tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bo
                           hipStream_t stream) {
     // the full-class launch: its kTexMid build when no full-class material binds a slot beyond base colour,
     // metallic-roughness and normal map (the transmission / thickness slots do not exist for the opaque pass)
-    const bool mid = (ctx->full_slots & ~(TRANSMISSIVE ? kSlotsMid : (kSlotsMid | 0x30u))) == 0u && !std::getenv("TR_NO_MID_CLASS");
+    const bool mid = (ctx->full_slots & ~(TRANSMISSIVE ? kSlotsMid : (kSlotsMid | 0x30u))) == 0u && !ctx->no_mid_class;
     if (ctx->any_plain_or_lite) {
         if (ctx->any_full_textured && L.tile_list) {   // (the frame recorder's buffers) the TEX = 1 launch lists the tiles itself
             L.list_build = const_cast<uint32_t*>(L.tile_list);
@@ -653,6 +707,7 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
             ctx->num_cus = (uint32_t)prop.multiProcessorCount;
         }
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
+        ctx->no_mid_class = std::getenv("TR_NO_MID_CLASS") != nullptr;   // tests only: the full-class launch's general build
     }
     if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_slice_thr, sizeof(float) * (TR_MAX_DEPTH_SLICES + 2)) != hipSuccess ||
@@ -700,6 +755,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_colour_tables);
     free_geometry(ctx);
     (void)hipFree(ctx->d_vis[0]);
+    if (ctx->tables_event) (void)hipEventDestroy(ctx->tables_event);
     delete ctx;
     return TR_OK;
 }
@@ -773,12 +829,13 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_dtaps, sizeof(tr_dtap) * count));
         ctx->cap_materials = count;
     }
+    TR_TRY(tables_before_rebuild(ctx, stream));   // (launches of other streams may still read the previous records)
     ctx->stage_materials.assign(materials_host, materials_host + count);
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_materials_raw, ctx->stage_materials.data(), sizeof(tr_material_info) * count,
                                hipMemcpyHostToDevice, stream));
     ctx->num_materials = count;
     ctx->dmats_dirty = true;
-    return TR_OK;
+    return tables_rebuilt(ctx, stream);
 }
 
 tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_t count, void* stream_) {
@@ -796,6 +853,7 @@ tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_alights, sizeof(tr_alight) * alloc));
         ctx->cap_lights = alloc;
     }
+    TR_TRY(tables_before_rebuild(ctx, stream));
     ctx->stage_lights.resize(alloc);
     ctx->stage_alights.resize(alloc);
     std::memset(ctx->stage_lights.data(), 0, sizeof(tr_dlight) * alloc);
@@ -827,7 +885,7 @@ tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_alights, ctx->stage_alights.data(), sizeof(tr_alight) * alloc,
                                hipMemcpyHostToDevice, stream));
     ctx->num_lights = count;
-    return TR_OK;
+    return tables_rebuilt(ctx, stream);
 }
 
 tr_status tr_set_cluster_tables(tr_context* ctx, const void* counts_dev, const void* indices_dev,
@@ -853,6 +911,7 @@ tr_status tr_upload_ggx_lut(tr_context* ctx, const uint8_t* rgba8_host, uint32_t
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_lut_rgba8, (size_t)width * height * 4u));
         TR_HIP(ctx, hipMalloc((void**)&ctx->d_lut_pairs, (size_t)stride * height * 4u));
     }
+    TR_TRY(tables_before_rebuild(ctx, stream));
     ctx->stage_lut.assign(rgba8_host, rgba8_host + (size_t)width * height * 4u);
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_lut_rgba8, ctx->stage_lut.data(), ctx->stage_lut.size(), hipMemcpyHostToDevice,
                                stream));
@@ -863,7 +922,7 @@ tr_status tr_upload_ggx_lut(tr_context* ctx, const uint8_t* rgba8_host, uint32_t
     ctx->lut_h = height;
     ctx->lut_stride = stride;
     ctx->dmats_dirty = ctx->num_materials > 0;  // LUT rows are part of the digested material
-    return TR_OK;
+    return tables_rebuilt(ctx, stream);
 }
 
 tr_status tr_upload_textures(tr_context* ctx, const tr_texture_desc* textures_host, uint32_t count, void* stream_) {
@@ -1170,6 +1229,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     const uint32_t* mat_flags = nullptr;
     if (ensure_digested(ctx, stream) == TR_OK)
         mat_flags = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctx->d_dmats) + offsetof(tr_dmat, flags));
+    TR_TRY(tables_acquire(ctx, stream));
     if (fused_demux) {
         tr_draw_buffers out;
         for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k) out.draws[k] = (tr_draw_command*)draws[k];
@@ -1296,7 +1356,9 @@ tr_status tr_get_depth_slice(tr_context* ctx, const tr_light_cluster_coefficient
     tr_uniforms u;
     std::memset(&u, 0, sizeof(u));
     u.light_clustering_coefficients = *c;
-    const tr_status st = ensure_slice_thresholds(ctx, &u, stream);
+    tr_status st = ensure_slice_thresholds(ctx, &u, stream);
+    if (st != TR_OK) return st;
+    st = tables_acquire(ctx, stream);
     if (st != TR_OK) return st;
     slice_params sp;
     sp.scale = c->scale;
@@ -1329,6 +1391,8 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     st = ensure_cluster_tables(ctx, u, fp.width, fp.height, stream);
     if (st != TR_OK) return st;
     st = check_textured_launch(ctx, g, fp);
+    if (st != TR_OK) return st;
+    st = tables_acquire(ctx, stream);
     if (st != TR_OK) return st;
     fp.pyr_levels = 1;
     // one-wave workgroups: blocks_per_xcd counts units of four waves
@@ -1442,6 +1506,8 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     if (st != TR_OK) return st;
     st = check_textured_launch(ctx, g, fp);
     if (st != TR_OK) return st;
+    st = tables_acquire(ctx, stream);
+    if (st != TR_OK) return st;
     fp.pyr_levels = p->levels;
     // one-wave workgroups: blocks_per_xcd counts units of four waves
     const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * 4u), block(64);
@@ -1504,6 +1570,8 @@ tr_status tr_ibl_volume_refraction(tr_context* ctx, const void* params, uint32_t
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     tr_status st = ensure_levels(ctx, p, stream);
+    if (st != TR_OK) return st;
+    st = tables_acquire(ctx, stream);
     if (st != TR_OK) return st;
     tr_ibl_tables t;
     t.pyramid = (const uint2*)p->texels;
