@@ -195,6 +195,11 @@ def _bind_passes(lib):
         fn.argtypes = [vp] * nin + [u32, vp]
     lib.o_ibl_volume_refraction_batch.restype = None
     lib.o_ibl_volume_refraction_batch.argtypes = [vp, u32, C.POINTER(OPyramid), vp, u32, u32, vp]
+    # the rasteriser: float arrays in, float planes out in both precisions (the fp64 twin evaluates in double and rounds
+    # what it stores; its alpha-clip kill samples textures, which are not bound for it: use it on scenes without kills)
+    lib.o_rasterize.restype = None
+    lib.o_rasterize.argtypes = [C.POINTER(OScene), C.POINTER(OGeometry), C.POINTER(vp * 4), C.POINTER(u32 * 4), u32, u32,
+                                OLayer, OLayer]
 
 
 _lib64 = None
@@ -415,9 +420,10 @@ def new_layer(width: int, height: int) -> dict:
             "width": width, "height": height}
 
 
-def rasterize(binding: "SceneBinding", geometry: dict, draw_counts, draws, width: int, height: int):
+def rasterize(binding: "SceneBinding", geometry: dict, draw_counts, draws, width: int, height: int, fp64: bool = False):
     """(opaque layer, transmissive layer) as TGB-v1 plane dicts; `geometry` holds position / normal / uv / index /
-    instances arrays, `draws` four DRAW_COMMAND_DTYPE arrays (e.g. from demultiplex_draws)."""
+    instances arrays, `draws` four DRAW_COMMAND_DTYPE arrays (e.g. from demultiplex_draws).  fp64: the same formulas
+    evaluated in double (the diagnostic twin: how far the fp32 evaluation is from its own exact value)."""
     pos = np.ascontiguousarray(geometry["position"], dtype=np.float32)
     nrm = np.ascontiguousarray(geometry["normal"], dtype=np.float32)
     uv = np.ascontiguousarray(geometry["uv"], dtype=np.float32)
@@ -430,7 +436,8 @@ def rasterize(binding: "SceneBinding", geometry: dict, draw_counts, draws, width
     counts = (C.c_uint32 * 4)(*[int(c) for c in draw_counts])
     layers = [new_layer(width, height), new_layer(width, height)]
     structs = [OLayer(_ptr(l["pos_depth"]), _ptr(l["nrm_scale"]), _ptr(l["uv"]), _ptr(l["material_id"])) for l in layers]
-    load().o_rasterize(C.byref(binding.struct), C.byref(geo), C.byref(ptrs), C.byref(counts), width, height, structs[0], structs[1])
+    (load64() if fp64 else load()).o_rasterize(C.byref(binding.struct), C.byref(geo), C.byref(ptrs), C.byref(counts), width, height,
+                                               structs[0], structs[1])
     return layers[0], layers[1]
 
 

@@ -2,9 +2,11 @@
 rasterisation into the two TGB-v1 layers and the alpha-clip kill through the C ABI against the CPU oracle, whose
 vertex stage / kill logic are pinned bit-exactly by the reference's compiled shaders (tests/test_geometry.py).
 
-Criteria: coverage, material ids, depth and every interpolated attribute are BIT-EXACT (same fp32 operations in the
-same order); the only tolerance is on alpha-clipped primitives, where the kill compares a filtered texture value
-(computed with v_log_f32 / fma on the GPU) against the cutoff: a handful of pixels on the cut-out's rim may differ.
+Criteria (see _compare): coverage, material ids and depth are BIT-EXACT (index work: same fp32 operations in the same
+order as the oracle's rasteriser); the interpolated position / normal / uv agree within ATTRIBUTE_TOLERANCE (the
+kernels evaluate the perspective interpolation as per-triangle plane equations, not as the oracle's barycentric mix).
+The only other tolerance is on alpha-clipped primitives, where the kill compares a filtered texture value (computed
+with v_log_f32 / fma on the GPU) against the cutoff: a handful of pixels on the cut-out's rim may differ.
 """
 import numpy as np
 import pytest
@@ -37,12 +39,12 @@ def _scene(w, h, view, alpha_cutoffs=(0.75, 0.6)):
     return sc
 
 
-def _oracle_layers(geo, sc, w, h, view):
+def _oracle_layers(geo, sc, w, h, view, fp64=False):
     b = oracle.SceneBinding(sc, np.zeros((4, 4, 4), np.uint8))
     push = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
     counts = oracle.frustum_culling(geo["primitives"], geo["instances"], push)
     dc, draws = oracle.demultiplex_draws(geo["primitives"], counts)
-    return oracle.rasterize(b, geo, dc, draws, w, h), push
+    return oracle.rasterize(b, geo, dc, draws, w, h, fp64=fp64), push
 
 
 def _gpu_layers(r, geo, sc, w, h, culling):
@@ -59,18 +61,57 @@ def _gpu_layers(r, geo, sc, w, h, culling):
     return out
 
 
-def _compare(got, want, alpha_materials=(), max_rim_pixels=0):
-    """Bit-exact, except that up to `max_rim_pixels` pixels may differ where either side shows an alpha-clipped
-    material (the pixel then shows whatever is behind the cut-out on the other side)."""
+ATTRIBUTE_RMSE = 1e-4    # RMSE of (gpu - oracle) / max(|oracle|, 1) per plane over the pixels both sides cover: the criterion
+ATTRIBUTE_MAX = 2e-3     # ... and its largest single value (the fp32 oracle's own rounding noise at sliver triangles, below)
+_worst = {"rmse": 0.0, "max": 0.0}
+
+
+def _attribute_errors(a, b, mask):
+    """(rmse, max) of (a - b) / max(|b|, 1) over position / normal / uv of the masked pixels."""
+    worst_rmse = worst_max = 0.0
+    for k, n in (("pos_depth", 3), ("nrm_scale", 3), ("uv", 2)):
+        x, y = a[k][..., :n].astype(np.float64)[mask], b[k][..., :n].astype(np.float64)[mask]
+        if x.size == 0:
+            continue
+        assert np.isfinite(x).all(), k
+        err = np.abs(x - y) / np.maximum(np.abs(y), 1.0)
+        worst_rmse = max(worst_rmse, float(np.sqrt(np.mean(err ** 2))))
+        worst_max = max(worst_max, float(err.max()))
+    return worst_rmse, worst_max
+
+
+def _compare(got, want, alpha_materials=(), max_rim_pixels=0, want64=None):
+    """Two criteria.
+    BIT-EXACT: coverage, material ids, depth (the rasteriser's words: index work) and the instance scale — except that
+    up to `max_rim_pixels` pixels may differ where either side shows an alpha-clipped material (the pixel then shows
+    whatever is behind the cut-out on the other side).
+    WITHIN TOLERANCE: the interpolated position / normal / uv of every pixel both sides agree on — RMSE <= ATTRIBUTE_RMSE,
+    no pixel beyond ATTRIBUTE_MAX.  The oracle mixes the corners with barycentrics (three fp32 edge functions evaluated
+    about the frame origin, one IEEE division); the kernels evaluate the same rational function as plane equations
+    centred on the triangle (tr_visibility.h: tr_tri_planes) with v_rcp_f32 — same function, different roundings: a few
+    1e-7 typically; where the oracle's own edge functions cancel (sliver triangles far from the frame origin) ITS value
+    moves by up to ~1e-4.  `want64` (the oracle's fp64 twin on the same scene) shows whose noise that is: the kernels
+    must be as close to the fp64 evaluation as the fp32 oracle is."""
     differ = got["material_id"] != want["material_id"]
     covered = want["material_id"] != wire.NOT_COVERED        # without a fragment only the id plane is defined
-    for k in ("pos_depth", "nrm_scale", "uv"):
-        differ |= (got[k].view(np.uint32) != want[k].view(np.uint32)).any(axis=2) & covered
+    differ |= (got["pos_depth"][..., 3].view(np.uint32) != want["pos_depth"][..., 3].view(np.uint32)) & covered
+    differ |= (got["nrm_scale"][..., 3].view(np.uint32) != want["nrm_scale"][..., 3].view(np.uint32)) & covered
+    same = covered & ~differ
+    rmse, worst = _attribute_errors(got, want, same)
+    _worst["rmse"], _worst["max"] = max(_worst["rmse"], rmse), max(_worst["max"], worst)
+    assert rmse <= ATTRIBUTE_RMSE and worst <= ATTRIBUTE_MAX, (rmse, worst)
+    if want64 is not None:
+        all3 = same & (want64["material_id"] == want["material_id"])
+        g_rmse, g_max = _attribute_errors(got, want64, all3)
+        o_rmse, o_max = _attribute_errors(want, want64, all3)
+        print(f"   vs the fp64 twin: kernels rmse {g_rmse:.2e} max {g_max:.2e}; fp32 oracle rmse {o_rmse:.2e} max {o_max:.2e} "
+              f"({int(all3.sum())} pixels); kernels vs fp32 oracle rmse {rmse:.2e} max {worst:.2e}")
+        assert g_rmse <= 1.25 * o_rmse + 1e-7 and g_max <= 1.25 * o_max + 1e-6, (g_rmse, o_rmse, g_max, o_max)
     if not differ.any():
         return 0
     ys, xs = np.nonzero(differ)
     involved = np.isin(got["material_id"][ys, xs], alpha_materials) | np.isin(want["material_id"][ys, xs], alpha_materials)
-    assert involved.all(), ("pixels differ away from alpha-clipped surfaces", int((~involved).sum()), ys[~involved][:5], xs[~involved][:5])
+    assert involved.all(), ("coverage / id / depth differ away from alpha-clipped surfaces", int((~involved).sum()), ys[~involved][:5], xs[~involved][:5])
     assert differ.sum() <= max_rim_pixels, int(differ.sum())
     return int(differ.sum())
 
@@ -84,7 +125,7 @@ CAMERAS = [
 
 @pytest.mark.parametrize("w,h", [(256, 256), (250, 130), (640, 360)])
 @pytest.mark.parametrize("cam", [c[0] for c in CAMERAS])
-def test_layers_bit_exact(renderer, w, h, cam):
+def test_layers_coverage_depth_ids_bit_exact_attributes_within_tolerance(renderer, w, h, cam):
     view = dict(CAMERAS)[cam]()
     geo = meshes.make_mesh_scene()
     sc = _scene(w, h, view)
@@ -99,24 +140,26 @@ def test_layers_bit_exact(renderer, w, h, cam):
           f"alpha-rim pixels {n0} + {n1}")
 
 
-def test_layers_bit_exact_1080p(renderer):
-    """BASELINE config 2's frame size: both rasterised layers (coverage, ids, depth, every attribute) against the oracle's,
-    bit for bit (alpha-clip rims counted as above)."""
+def test_layers_1080p(renderer):
+    """BASELINE config 2's frame size: both rasterised layers against the oracle's — coverage, ids and depth bit for bit
+    (alpha-clip rims counted as above), attributes within ATTRIBUTE_TOLERANCE."""
     w, h = 1920, 1080
     view = wire.default_camera()[1]
     geo = meshes.make_mesh_scene()
     sc = _scene(w, h, view)
     (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
     got_o, got_t = _gpu_layers(renderer, geo, sc, w, h, culling)
+    (twin_o, twin_t), _ = _oracle_layers(geo, sc, w, h, view, fp64=True)
     budget = w * h // 20000
-    n0 = _compare(got_o, want_o, alpha_materials=(2,), max_rim_pixels=budget)
-    n1 = _compare(got_t, want_t, alpha_materials=(7, 2), max_rim_pixels=budget)
+    n0 = _compare(got_o, want_o, alpha_materials=(2,), max_rim_pixels=budget, want64=twin_o)
+    n1 = _compare(got_t, want_t, alpha_materials=(7, 2), max_rim_pixels=budget, want64=twin_t)
     cov = want_o["material_id"] != wire.NOT_COVERED
     assert cov.mean() > 0.2, cov.mean()
-    print(f"1080p: coverage {cov.mean():.2f} / {(want_t['material_id'] != wire.NOT_COVERED).mean():.2f}, alpha-rim pixels {n0} + {n1}")
+    print(f"1080p: coverage {cov.mean():.2f} / {(want_t['material_id'] != wire.NOT_COVERED).mean():.2f}, alpha-rim pixels {n0} + {n1}, "
+          f"attribute errors so far: rmse {_worst['rmse']:.2e} (bound {ATTRIBUTE_RMSE}), max {_worst['max']:.2e} (bound {ATTRIBUTE_MAX})")
 
 
-def test_layers_without_alpha_clip_are_bit_exact_everywhere(renderer):
+def test_layers_without_alpha_clip_have_no_rim_tolerance(renderer):
     """Cutoff 0 switches every kill off: then there is no tolerance at all."""
     w, h = 512, 288
     view = wire.default_camera()[1]
@@ -146,8 +189,9 @@ def test_many_small_triangles_and_depth_ties(renderer):
     geo = mb.finish()
     sc = _scene(w, h, view, alpha_cutoffs=(0.0, 0.0))
     (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    (twin_o, twin_t), _ = _oracle_layers(geo, sc, w, h, view, fp64=True)
     got_o, got_t = _gpu_layers(renderer, geo, sc, w, h, culling)
-    assert _compare(got_o, want_o) == 0 and _compare(got_t, want_t) == 0
+    assert _compare(got_o, want_o, want64=twin_o) == 0 and _compare(got_t, want_t, want64=twin_t) == 0
     assert (want_o["material_id"] == 10).sum() > 50 and not (want_o["material_id"] == 8).any()
 
 

@@ -70,6 +70,13 @@ __device__ __forceinline__ uint32_t opaque(uint32_t s) {
     return s;
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over every address space:
+// it also waits for the wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)), a full memory round trip per barrier — the
+// mip-chain kernels store a level to global memory and hand it to the next step through LDS, seven barriers deep.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }

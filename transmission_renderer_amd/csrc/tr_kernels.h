@@ -258,7 +258,7 @@ struct tr_launch {
     uint32_t* list_build_count;         // tiles whose coverage word has bit 1 set, for the TEX = 2 launch behind it
     // VIS launches (the frame recorder): the layer's visibility words and triangle records instead of the planes
     unsigned long long* vis;
-    const tr_tri_record* records;
+    const tr_tri_planes* tri_planes;
     // opaque VIS launches: the transmissive layer's words and coverage map.  The rasteriser keeps the pixel's NEAREST
     // transmissive fragment whatever lies in front of it (raster_kernel); the opaque launch, the last to know the opaque
     // depth, zeroes that word where the fragment is not nearer than the opaque surface.
@@ -1540,7 +1540,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             t.uv = float2{0.f, 0.f};
             if (key != 0ull) {
                 vis_fragment v;
-                vis_interpolate(F->records[(uint32_t)key], key, cx, cy, v);
+                vis_planes_interpolate(F->tri_planes[(uint32_t)key], key, cx, cy, v);
                 t.pd = float4{v.position[0], v.position[1], v.position[2], v.depth};
                 t.ns = float4{v.normal[0], v.normal[1], v.normal[2], v.scale};
                 if constexpr (TEXTURED) t.uv = float2{v.uv[0], v.uv[1]};
@@ -2005,7 +2005,7 @@ __global__ __launch_bounds__(256) void mip_even_kernel(uint2* __restrict__ pyr, 
     uint32_t base = 0, side = 16;   // LDS offset and side of the level just produced
 #pragma unroll
     for (uint32_t l = 1; l < 5u; ++l) {
-        __syncthreads();
+        lds_barrier();               // (the level just produced is handed on through LDS; its global stores are not waited for)
         if (l >= p.nlevels) break;   // uniform
         const uint32_t half = side >> 1;
         const uint32_t wl = p.w0 >> (l + 1u), hl = p.h0 >> (l + 1u);
@@ -2029,6 +2029,50 @@ struct tr_mip_tail_params {
 };
 constexpr uint32_t kMipTailMaxTexels = 12288;   // first tail level must fit: 96 KiB + 24 KiB + ... of LDS
 
+// One destination texel of a general LINEAR blit: taps and weights (downsample_kernel's arithmetic).
+struct blit_taps {
+    uint32_t i00, i10, i01, i11;   // texel indices in the source level
+    float w00, w10, w01, w11;
+};
+__device__ __forceinline__ blit_taps blit_taps_for(uint32_t t, uint32_t ws, uint32_t hs, uint32_t wd, float sx, float sy) {
+#pragma clang fp contract(off)
+    const uint32_t i = t % wd, j = t / wd;
+    const float x = ((float)i + 0.5f) * sx - 0.5f, y = ((float)j + 0.5f) * sy - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float ax = x - fx0, by = y - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    const int x1 = min(x0 + 1, (int)ws - 1), y1 = min(y0 + 1, (int)hs - 1);
+    x0 = min(max(x0, 0), (int)ws - 1);
+    y0 = min(max(y0, 0), (int)hs - 1);
+    blit_taps o;
+    o.w00 = (1.0f - ax) * (1.0f - by);
+    o.w10 = ax * (1.0f - by);
+    o.w01 = (1.0f - ax) * by;
+    o.w11 = ax * by;
+    o.i00 = (uint32_t)y0 * ws + (uint32_t)x0;
+    o.i10 = (uint32_t)y0 * ws + (uint32_t)x1;
+    o.i01 = (uint32_t)y1 * ws + (uint32_t)x0;
+    o.i11 = (uint32_t)y1 * ws + (uint32_t)x1;
+    return o;
+}
+__device__ __forceinline__ uint2 blit_filter(const blit_taps& k, uint2 q00, uint2 q10, uint2 q01, uint2 q11) {
+#pragma clang fp contract(off)
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        auto ch = [c](uint2 q) {
+            uint32_t wv = (c < 2) ? q.x : q.y;
+            return __half2float(__ushort_as_half((unsigned short)((c & 1) ? (wv >> 16) : (wv & 0xFFFFu))));
+        };
+        o[c] = (ch(q00) * k.w00 + ch(q10) * k.w10) + (ch(q01) * k.w01 + ch(q11) * k.w11);
+    }
+    return pack_rgba16f(o[0], o[1], o[2], o[3]);
+}
+
+// The first level of the tail reads its parent from global memory: every thread takes up to kTailBatch destination
+// texels and has all their taps in flight together (one memory round trip for the level instead of one per texel of a
+// thread: the level is 8 040 texels at 4K, eight per thread — this loop was 8 of the kernel's 11.7 us).
+constexpr uint32_t kTailBatch = 4u;
 __global__ __launch_bounds__(1024) void mip_tail_kernel(uint2* __restrict__ pyr, const tr_mip_tail_params p) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) uint2 tail_lds[];
@@ -2040,34 +2084,39 @@ __global__ __launch_bounds__(1024) void mip_tail_kernel(uint2* __restrict__ pyr,
         const uint2* gsrc = pyr + p.offset[l - 1];
         nxt = src_in_lds ? cur + (size_t)ws * hs : tail_lds;
         const float sx = (float)ws / (float)wd, sy = (float)hs / (float)hd;
-        for (uint32_t t = threadIdx.x; t < wd * hd; t += blockDim.x) {
-            const uint32_t i = t % wd, j = t / wd;
-            float x = ((float)i + 0.5f) * sx - 0.5f;
-            float y = ((float)j + 0.5f) * sy - 0.5f;
-            float fx0 = floorf(x), fy0 = floorf(y);
-            float ax = x - fx0, by = y - fy0;
-            int x0 = (int)fx0, y0 = (int)fy0;
-            int x1 = min(x0 + 1, (int)ws - 1), y1 = min(y0 + 1, (int)hs - 1);
-            x0 = min(max(x0, 0), (int)ws - 1);
-            y0 = min(max(y0, 0), (int)hs - 1);
-            const float w00 = (1.0f - ax) * (1.0f - by), w10 = ax * (1.0f - by), w01 = (1.0f - ax) * by, w11 = ax * by;
-            const uint2* s = src_in_lds ? cur : gsrc;
-            const uint2 q00 = s[(size_t)y0 * ws + x0], q10 = s[(size_t)y0 * ws + x1];
-            const uint2 q01 = s[(size_t)y1 * ws + x0], q11 = s[(size_t)y1 * ws + x1];
-            float o[4];
+        const uint32_t n = wd * hd;
+        if (!src_in_lds) {
+            for (uint32_t base = 0; base < n; base += blockDim.x * kTailBatch) {
+                blit_taps k[kTailBatch];
+                uint2 q[kTailBatch][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                auto ch = [k](uint2 q) {
-                    uint32_t wv = (k < 2) ? q.x : q.y;
-                    return __half2float(__ushort_as_half((unsigned short)((k & 1) ? (wv >> 16) : (wv & 0xFFFFu))));
-                };
-                o[k] = (ch(q00) * w00 + ch(q10) * w10) + (ch(q01) * w01 + ch(q11) * w11);
+                for (uint32_t b = 0; b < kTailBatch; ++b) {
+                    const uint32_t t = min(base + b * blockDim.x + threadIdx.x, n - 1u);
+                    k[b] = blit_taps_for(t, ws, hs, wd, sx, sy);
+                    q[b][0] = gsrc[k[b].i00];
+                    q[b][1] = gsrc[k[b].i10];
+                    q[b][2] = gsrc[k[b].i01];
+                    q[b][3] = gsrc[k[b].i11];
+                }
+#pragma unroll
+                for (uint32_t b = 0; b < kTailBatch; ++b) {
+                    const uint32_t t = base + b * blockDim.x + threadIdx.x;
+                    if (t < n) {
+                        const uint2 v = blit_filter(k[b], q[b][0], q[b][1], q[b][2], q[b][3]);
+                        pyr[p.offset[l] + t] = v;
+                        nxt[t] = v;
+                    }
+                }
             }
-            const uint2 v = pack_rgba16f(o[0], o[1], o[2], o[3]);
-            pyr[p.offset[l] + t] = v;
-            nxt[t] = v;
+        } else {
+            for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+                const blit_taps k = blit_taps_for(t, ws, hs, wd, sx, sy);
+                const uint2 v = blit_filter(k, cur[k.i00], cur[k.i10], cur[k.i01], cur[k.i11]);
+                pyr[p.offset[l] + t] = v;
+                nxt[t] = v;
+            }
         }
-        __syncthreads();
+        lds_barrier();   // (LDS only: the level's global stores are not waited for — seven store round trips otherwise)
         cur = nxt;
         src_in_lds = true;
     }

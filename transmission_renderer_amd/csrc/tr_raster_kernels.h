@@ -129,18 +129,17 @@ __device__ __forceinline__ void vertex_stage(const tr_geometry_view& g, const tr
     mat4_mul_point(pv, world[0], world[1], world[2], clip);
 }
 
-__device__ __forceinline__ void raster_setup_body(const tr_geometry_view g, const tr_raster_frame f,
+// One triangle of the layer's draw stream: record + planes written, returns its number of work items.
+__device__ __forceinline__ uint32_t raster_setup_body(const tr_geometry_view g, const tr_raster_frame f,
                                                            const tr_draw_command* __restrict__ draws_a,
                                                            const tr_draw_command* __restrict__ draws_b,
                                                            const uint32_t* __restrict__ tri_base,
                                                            const tr_layer_counts* __restrict__ counts, uint32_t alpha_buffer_b,
                                                            tr_tri_record* __restrict__ records,
-                                                           uint32_t* __restrict__ item_counts,
+                                                           tr_tri_planes* __restrict__ tri_planes,
                                                            const uint32_t* __restrict__ material_flags /* tr_dmat::flags or null */,
-                                                           uint32_t flags_stride /* in words */) {
+                                                           uint32_t flags_stride /* in words */, uint32_t t) {
 #pragma clang fp contract(off)
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= counts->num_triangles) return;
     const uint32_t d = upper_index(tri_base, counts->num_draws, t);
     const bool second = d >= counts->num_draws_first;
     const tr_draw_command c = second ? draws_b[d - counts->num_draws_first] : draws_a[d];
@@ -148,16 +147,16 @@ __device__ __forceinline__ void raster_setup_body(const tr_geometry_view g, cons
     const uint32_t inst_id = c.first_instance + local / ntri, tri = local % ntri;
     const tr_instance inst = g.instances[inst_id];
     tr_tri_record r;
-    float X[3], Y[3], W[3];
+    float X[3], Y[3], W[3], P[3][3], N[3][3];   // (P, N: the vertex stage's world position and rotated normal per corner)
     const float hw = 0.5f * (float)f.width, hh = 0.5f * (float)f.height;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        r.v[k] = g.index[c.first_index + tri * 3u + (uint32_t)k] + (uint32_t)c.vertex_offset;
+        const uint32_t vi = g.index[c.first_index + tri * 3u + (uint32_t)k] + (uint32_t)c.vertex_offset;
         float clip[4];
-        vertex_stage(g, inst, f.proj_view, r.v[k], r.P[k], clip);
-        quat_rotate(inst.rotation, g.normal[r.v[k] * 3u], g.normal[r.v[k] * 3u + 1u], g.normal[r.v[k] * 3u + 2u], r.N[k]);
-        r.T[k][0] = g.uv[r.v[k] * 2u];
-        r.T[k][1] = g.uv[r.v[k] * 2u + 1u];
+        vertex_stage(g, inst, f.proj_view, vi, P[k], clip);
+        quat_rotate(inst.rotation, g.normal[vi * 3u], g.normal[vi * 3u + 1u], g.normal[vi * 3u + 2u], N[k]);
+        r.T[k][0] = g.uv[vi * 2u];
+        r.T[k][1] = g.uv[vi * 2u + 1u];
         X[k] = (clip[0] + clip[3]) * hw;
         Y[k] = (clip[1] + clip[3]) * hh;
         W[k] = clip[3];
@@ -194,75 +193,65 @@ __device__ __forceinline__ void raster_setup_body(const tr_geometry_view g, cons
     } else {
         r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0;
     }
-    r.instance = inst_id;
     // the class of the material, for the tile coverage words the shading launches steer by (shade_kernel's TEX launches)
     const uint32_t cls = material_flags ? ((material_flags[(size_t)inst.material_id * flags_stride] & 12u) == 4u ? 2u : 4u) : 6u;
     r.flags = ((second && alpha_buffer_b) ? 1u : 0u) | cls;
     r.material_id = inst.material_id;
-    r.scale = inst.translation_and_scale[3];
+    for (int k = 0; k < 7; ++k) r._pad[k] = 0u;
     records[t] = r;
-    item_counts[t] = items;
+    tr_tri_planes pl;   // what the shading launches / the resolve interpolate from (tr_visibility.h)
+    tri_planes_from_record(r, P, N, inst.translation_and_scale[3], pl);
+    tri_planes[t] = pl;
+    return items;
 }
 
-// item_base = exclusive prefix of item_counts over the layer's triangles, in three passes so that millions of
-// triangles scan at memory speed: per-chunk sums -> (single workgroup) prefix of the chunk sums -> per-chunk scan.
-// The triangle count lives on the device, so the grids are sized for the capacity and surplus blocks exit.
-constexpr uint32_t kScanChunk = 4096u;   // 1024 threads x 4
-
-__device__ __forceinline__ void raster_scan_items_reduce_body(const uint32_t* __restrict__ item_counts,
-                                                                        const tr_layer_counts* __restrict__ counts,
-                                                                        uint32_t* __restrict__ chunk_sums) {
-    __shared__ uint32_t lds[17];
-    const uint32_t n = counts->num_triangles;
-    const uint32_t first = blockIdx.x * kScanChunk;
-    if (first >= n) return;
-    uint32_t v = 0;
+// item_base = exclusive prefix of the work-item counts over the layer's triangles, formed INSIDE the set-up launch by a
+// decoupled look-back (Merrill & Garland's single-pass scan): a workgroup scans its 256 counts, publishes its aggregate in
+// a status word and adds up its predecessors' words until it meets one that already holds an inclusive prefix.  The words
+// are 64-bit agent-scope atomics that CARRY the value — (epoch << 34 | state << 32 | value) — so no fence is needed (a
+// device-scope release writes back the calling XCD's whole L2 on this chip: DESIGN.md), and the epoch (the context's frame
+// counter) makes last frame's words read as "not yet": nothing is cleared between frames.  This replaces the separate
+// scan launches (one ~5 us launch for small layers, three for large ones).
+constexpr unsigned long long kScanAggregate = 1ull, kScanInclusive = 2ull;
+__device__ __forceinline__ unsigned long long scan_word(uint32_t epoch, unsigned long long state, uint32_t value) {
+    return ((unsigned long long)epoch << 34) | (state << 32) | (unsigned long long)value;
+}
+// Called by the first wave of workgroup `block` (all 64 lanes); returns the exclusive prefix of the block.
+__device__ __forceinline__ uint32_t scan_lookback(unsigned long long* __restrict__ status, uint32_t block, uint32_t aggregate,
+                                                  uint32_t epoch, uint32_t lane) {
+    if (lane == 0u)
+        __hip_atomic_store(&status[block], scan_word(epoch, block == 0u ? kScanInclusive : kScanAggregate, aggregate), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (block == 0u) return 0u;
+    uint32_t exclusive = 0u;
+    int base = (int)block - 1;
+    for (;;) {
+        const int idx = base - (int)lane;                       // lane k looks at predecessor base - k
+        unsigned long long w = scan_word(epoch, kScanInclusive, 0u);   // (before block 0: prefix 0)
+        uint64_t pending, inclusive;
+        for (;;) {
+            if (idx >= 0) w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool current = (uint32_t)(w >> 34) == epoch;
+            const uint32_t state = current ? (uint32_t)(w >> 32) & 3u : 0u;
+            pending = ballot(state == 0u);
+            inclusive = ballot(state == (uint32_t)kScanInclusive);
+            // usable when, walking back from the nearest predecessor, an inclusive word comes before any missing one
+            const int first_missing = pending ? __ffsll((unsigned long long)pending) - 1 : 64;
+            const int first_inclusive = inclusive ? __ffsll((unsigned long long)inclusive) - 1 : 64;
+            if (first_inclusive < first_missing || first_missing == 64) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const int stop = inclusive ? __ffsll((unsigned long long)inclusive) - 1 : 63;   // last lane whose value counts
+        uint32_t v = (int)lane <= stop ? (uint32_t)w : 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) {
-        const uint32_t t = first + k * 1024u + threadIdx.x;
-        v += t < n ? item_counts[t] : 0u;
+        for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        exclusive += v;
+        if (inclusive) break;
+        base -= 64;
     }
-    uint32_t total;
-    (void)block_exclusive_scan(v, lds, total);
-    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = total;
-}
-
-__device__ __forceinline__ void raster_scan_items_chunks_body(uint32_t* __restrict__ chunk_sums,
-                                                                        tr_layer_counts* __restrict__ counts) {
-    __shared__ uint32_t lds[17];
-    const uint32_t nchunks = (counts->num_triangles + kScanChunk - 1u) / kScanChunk;
-    uint32_t running = 0;
-    for (uint32_t base = 0; base < nchunks; base += 1024u) {
-        const uint32_t c = base + threadIdx.x;
-        const uint32_t v = c < nchunks ? chunk_sums[c] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, lds, total);
-        if (c < nchunks) chunk_sums[c] = running + ex;
-        running += total;
-    }
-    if (threadIdx.x == 0) counts->num_items = running;
-}
-
-__device__ __forceinline__ void raster_scan_items_apply_body(const uint32_t* __restrict__ item_counts,
-                                                                       const uint32_t* __restrict__ chunk_sums,
-                                                                       const tr_layer_counts* __restrict__ counts,
-                                                                       uint32_t* __restrict__ item_base) {
-    __shared__ uint32_t lds[17];
-    const uint32_t n = counts->num_triangles;
-    const uint32_t first = blockIdx.x * kScanChunk;
-    if (first == 0u && threadIdx.x == 0 && n == 0u) item_base[0] = 0u;
-    if (first >= n) return;
-    uint32_t running = chunk_sums[blockIdx.x];
-#pragma unroll 1
-    for (uint32_t k = 0; k < 4u; ++k) {
-        const uint32_t t = first + k * 1024u + threadIdx.x;
-        const uint32_t v = t < n ? item_counts[t] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, lds, total);
-        if (t < n) item_base[t] = running + ex;
-        running += total;
-    }
-    if (first + kScanChunk >= n && threadIdx.x == 0) item_base[n] = running;   // the last chunk closes the prefix
+    if (lane == 0u)
+        __hip_atomic_store(&status[block], scan_word(epoch, kScanInclusive, exclusive + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return exclusive;
 }
 
 struct tr_alpha_tables {        // what the alpha-clip kill reads (depth_pre_pass_alpha_clip, shader/src/lib.rs:269-292)
@@ -376,6 +365,9 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
                 }
                 hit = !(alpha_v < m.alpha_clipping_cutoff);
             }
+            // (Testing the word with a plain or agent-scope load first and skipping fragments that already lose — the word only
+            //  grows within a frame — measured SLOWER, 57.6 -> 62.5 us on the 4K mesh frame: the load costs an L2 channel slot
+            //  like the atomic it saves, and an instruction is saved only when all 64 lanes lose.)
             if (hit) atomicMax(&vis[pix], ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)t);
             // the 64x4 block tiles that received a fragment (the 8x8 block lies in two of them, one above the other), and
             // the material classes of what landed there (bit 0 = touched, bit 1 = full-class textured, bit 2 = any other;
@@ -413,8 +405,7 @@ struct tr_layer_work {
     uint32_t* tri_base;
     tr_layer_counts* counts;
     tr_tri_record* records;
-    uint32_t* item_counts;
-    uint32_t* chunk_sums;
+    tr_tri_planes* tri_planes;
     uint32_t* item_base;
     unsigned long long* vis;
     tr_layer_planes planes;
@@ -427,14 +418,14 @@ struct tr_two_layers {
 
 // One thread per pixel and BOTH layers: the winning triangles' attributes at the pixel centre (vis_interpolate), or "no
 // fragment".  The transmissive layer's winner counts only if it is nearer than the opaque surface (see raster_kernel).
-__device__ __forceinline__ void raster_resolve_layer(const tr_raster_frame f, const tr_tri_record* __restrict__ records,
+__device__ __forceinline__ void raster_resolve_layer(const tr_raster_frame f, const tr_tri_planes* __restrict__ tri_planes,
                                                      unsigned long long key, const tr_layer_planes out, size_t pix, uint32_t px, uint32_t py) {
     if (key == 0ull) {   // no fragment: only the id plane is defined there (the shading passes look at nothing else)
         out.material_id[pix] = TR_NOT_COVERED;
         return;
     }
     vis_fragment v;
-    vis_interpolate(records[(uint32_t)key], key, px, py, v);
+    vis_planes_interpolate(tri_planes[(uint32_t)key], key, px, py, v);
     out.pos_depth[pix] = float4{v.position[0], v.position[1], v.position[2], v.depth};
     out.nrm_scale[pix] = float4{v.normal[0], v.normal[1], v.normal[2], v.scale};
     out.uv[pix] = float2{v.uv[0], v.uv[1]};
@@ -461,7 +452,7 @@ __device__ __forceinline__ void raster_resolve_body(const tr_raster_frame f, con
     for (uint32_t l = 0; l < 2u; ++l) {
         const bool touched = two.l[l].tile_cover && as_constant(two.l[l].tile_cover)[tile] != 0u;
         if (!touched && !ids_of_untouched_tiles) continue;
-        raster_resolve_layer(f, two.l[l].records, key[l], two.l[l].planes, pix, px, py);
+        raster_resolve_layer(f, two.l[l].tri_planes, key[l], two.l[l].planes, pix, px, py);
     }
 }
 
@@ -487,55 +478,62 @@ __global__ __launch_bounds__(1024) void frame_demux_scan_kernel(const tr_primiti
         __syncthreads();
     }
 }
-//   the prefix over the work items of a small layer (up to kSmallScanChunks chunks of 4096 triangles): one workgroup per
-//   layer walks the chunks with a running total instead of the three launches of the chunked scan.
-constexpr uint32_t kSmallScanChunks = 4u;
-__global__ __launch_bounds__(1024) void raster_scan_items_small_kernel(const tr_two_layers two) {
-    TR_PICK_LAYER(two, blockIdx.y);
-    if (W.capacity_triangles == 0u) return;
-    __shared__ uint32_t lds[17];
-    const uint32_t n = W.counts->num_triangles;
-    uint32_t running = 0;
-    for (uint32_t first = 0; first < n; first += 1024u) {
-        const uint32_t t = first + threadIdx.x;
-        const uint32_t v = t < n ? W.item_counts[t] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, lds, total);
-        if (t < n) W.item_base[t] = running + ex;
-        running += total;
-    }
-    if (threadIdx.x == 0) {
-        W.item_base[n] = running;
-        W.counts->num_items = running;
-    }
-}
-
 __global__ __launch_bounds__(1024) void raster_scan_draws_kernel(const tr_two_layers two, const uint32_t* __restrict__ draw_counts,
                                                                  uint32_t capacity_draws) {
     TR_PICK_LAYER(two, blockIdx.y);
     if (W.capacity_triangles == 0u) return;
     raster_scan_draws_body(W.draws_a, W.draws_b, draw_counts, W.buffer_a, capacity_draws, W.capacity_triangles, W.tri_base, W.counts);
 }
+// Vertex stage + triangle set-up + the work-item prefix of both layers (blockIdx.y = layer).  The grid is sized for the
+// layer's capacity; the triangle count lives on the device: workgroups past it exit, the one that holds the last triangle
+// closes the prefix.
 __global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two,
-                                                           const uint32_t* __restrict__ material_flags, uint32_t flags_stride) {
+                                                           const uint32_t* __restrict__ material_flags, uint32_t flags_stride,
+                                                           unsigned long long* __restrict__ scan_status, uint32_t status_stride,
+                                                           uint32_t epoch) {
     TR_PICK_LAYER(two, blockIdx.y);
     if (W.capacity_triangles == 0u) return;
-    raster_setup_body(g, f, W.draws_a, W.draws_b, W.tri_base, W.counts, 1u, W.records, W.item_counts, material_flags, flags_stride);
-}
-__global__ __launch_bounds__(1024) void raster_scan_items_reduce_kernel(const tr_two_layers two) {
-    TR_PICK_LAYER(two, blockIdx.y);
-    if (W.capacity_triangles == 0u) return;
-    raster_scan_items_reduce_body(W.item_counts, W.counts, W.chunk_sums);
-}
-__global__ __launch_bounds__(1024) void raster_scan_items_chunks_kernel(const tr_two_layers two) {
-    TR_PICK_LAYER(two, blockIdx.y);
-    if (W.capacity_triangles == 0u) return;
-    raster_scan_items_chunks_body(W.chunk_sums, W.counts);
-}
-__global__ __launch_bounds__(1024) void raster_scan_items_apply_kernel(const tr_two_layers two) {
-    TR_PICK_LAYER(two, blockIdx.y);
-    if (W.capacity_triangles == 0u) return;
-    raster_scan_items_apply_body(W.item_counts, W.chunk_sums, W.counts, W.item_base);
+    __shared__ uint32_t lds_wave[4];
+    __shared__ uint32_t lds_prefix;
+    const uint32_t n = W.counts->num_triangles;
+    const uint32_t first = blockIdx.x * 256u, t = first + threadIdx.x;
+    if (first >= n) {
+        if (n == 0u && blockIdx.x == 0u && threadIdx.x == 0u) {
+            W.item_base[0] = 0u;
+            W.counts->num_items = 0u;
+        }
+        return;
+    }
+    const uint32_t items = t < n ? raster_setup_body(g, f, W.draws_a, W.draws_b, W.tri_base, W.counts, 1u, W.records, W.tri_planes,
+                                                     material_flags, flags_stride, t)
+                                 : 0u;
+    // exclusive scan over the workgroup's 256 counts
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = items;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63u) lds_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0u, total = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        before += k < wave ? lds_wave[k] : 0u;
+        total += lds_wave[k];
+    }
+    if (wave == 0u) {
+        const uint32_t ex = scan_lookback(scan_status + (size_t)blockIdx.y * status_stride, blockIdx.x, total, epoch, lane);
+        if (lane == 0u) lds_prefix = ex;
+    }
+    __syncthreads();
+    const uint32_t prefix = lds_prefix;
+    if (t < n) W.item_base[t] = prefix + before + incl - items;
+    if (first + 256u >= n && threadIdx.x == 0u) {   // the workgroup of the last triangle closes the prefix
+        W.item_base[n] = prefix + total;
+        W.counts->num_items = prefix + total;
+    }
 }
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const tr_raster_frame f, const tr_two_layers two,
                                                              uint32_t ids_of_untouched_tiles) {

@@ -90,9 +90,11 @@ struct tr_context {
     tr_draw_command* d_draws[TR_NUM_DRAW_BUFFERS] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* d_tri_base = nullptr;
     tr_tri_record* d_records = nullptr;
-    uint32_t* d_item_counts = nullptr;
+    tr_tri_planes* d_tri_planes = nullptr;   // per triangle, beside the record: what the shading launches interpolate from
     uint32_t* d_item_base = nullptr;
-    uint32_t* d_chunk_sums = nullptr;
+    unsigned long long* d_scan_status = nullptr;   // per layer and set-up workgroup: the look-back words of the work-item prefix
+    uint32_t scan_blocks = 0;                      // ... workgroups per layer (the words' stride)
+    uint32_t scan_epoch = 0;                       // ... and the frame counter they are tagged with (never 0)
     tr_layer_counts* d_layer_counts = nullptr;
     unsigned long long* d_vis[2] = {nullptr, nullptr};
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
@@ -100,7 +102,7 @@ struct tr_context {
     const uint32_t* list_hint = nullptr;               // ... with it: the layer's list of full-class tiles
     bool cover_cleared = false;                        // the frame's first launch has zeroed the coverage maps already
     unsigned long long* vis_hint = nullptr;            // ... and, when the frame skipped the resolve, the layer's visibility
-    const tr_tri_record* records_hint = nullptr;       //     words and triangle records: the shading launches read those (VIS)
+    const tr_tri_planes* planes_hint = nullptr;        //     words and triangle planes: the shading launches read those (VIS)
     unsigned long long* vis_front_hint = nullptr;      // opaque VIS launches: the transmissive layer's words and coverage map
     const uint32_t* cover_front_hint = nullptr;        //   (a transmissive winner behind the opaque surface is zeroed there)
     const uint32_t* list_count_hint = nullptr;
@@ -515,17 +517,18 @@ void free_geometry(tr_context* ctx) {
     }
     (void)hipFree(ctx->d_tri_base);
     (void)hipFree(ctx->d_records);
-    (void)hipFree(ctx->d_item_counts);
+    (void)hipFree(ctx->d_tri_planes);
     (void)hipFree(ctx->d_item_base);
-    (void)hipFree(ctx->d_chunk_sums);
+    (void)hipFree(ctx->d_scan_status);
     (void)hipFree(ctx->d_layer_counts);
     ctx->d_position = ctx->d_normal = ctx->d_uv = nullptr;
     ctx->d_index = nullptr;
     ctx->d_primitives = nullptr;
     ctx->d_instances = nullptr;
-    ctx->d_instance_counts = ctx->d_draw_counts = ctx->d_tri_base = ctx->d_item_counts = ctx->d_item_base = nullptr;
-    ctx->d_chunk_sums = nullptr;
+    ctx->d_instance_counts = ctx->d_draw_counts = ctx->d_tri_base = ctx->d_item_base = nullptr;
+    ctx->d_scan_status = nullptr;
     ctx->d_records = nullptr;
+    ctx->d_tri_planes = nullptr;
     ctx->d_layer_counts = nullptr;
     ctx->num_vertices = ctx->num_indices = ctx->num_primitives = ctx->num_instances = 0;
     ctx->max_triangles[0] = ctx->max_triangles[1] = 0;
@@ -561,7 +564,7 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.tile_list_count = L.tile_list ? ctx->list_count_hint : nullptr;
     L.list_build = L.list_build_count = nullptr;
     L.vis = L.tile_cover ? ctx->vis_hint : nullptr;
-    L.records = L.vis ? ctx->records_hint : nullptr;
+    L.tri_planes = L.vis ? ctx->planes_hint : nullptr;
     L.vis_front = L.vis ? ctx->vis_front_hint : nullptr;
     L.cover_front = L.vis ? ctx->cover_front_hint : nullptr;
     L.slice_thr = ctx->d_slice_thr;
@@ -1097,9 +1100,12 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
     ctx->work_draws = np_ + 1u;
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_tri_base, 2u * (np_ + 1u) * 4u));
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_records, 2u * cap * sizeof(tr_tri_record)));
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_counts, 2u * cap * 4u));
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_tri_planes, 2u * cap * sizeof(tr_tri_planes)));
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_base, 2u * (cap + 1u) * 4u));
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_chunk_sums, 2u * ((cap + kScanChunk - 1u) / kScanChunk + 1u) * 4u));
+    ctx->scan_blocks = (uint32_t)((cap + 255u) / 256u);
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_scan_status, 2u * (size_t)ctx->scan_blocks * 8u));
+    TR_HIP(ctx, hipMemsetAsync(ctx->d_scan_status, 0, 2u * (size_t)ctx->scan_blocks * 8u, stream));   // epoch 0 = never written
+    ctx->scan_epoch = 0;
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_layer_counts, 2u * sizeof(tr_layer_counts)));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_position, g->position, nv * 12u, hipMemcpyHostToDevice, stream));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_normal, g->normal, nv * 12u, hipMemcpyHostToDevice, stream));
@@ -1195,7 +1201,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     at.textures = ctx->d_textures;
     at.tex_arena = ctx->d_tex_arena;
     at.num_textures = ctx->num_textures;
-    const size_t cap = ctx->work_capacity, chunk_cap = (cap + kScanChunk - 1u) / kScanChunk + 1u;
+    const size_t cap = ctx->work_capacity;
     tr_two_layers two;
     for (uint32_t layer = 0; layer < 2u; ++layer) {
         tr_layer_work& W = two.l[layer];
@@ -1206,8 +1212,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
         W.tri_base = ctx->d_tri_base + layer * ctx->work_draws;
         W.counts = ctx->d_layer_counts + layer;
         W.records = ctx->d_records + layer * cap;
-        W.item_counts = ctx->d_item_counts + layer * cap;
-        W.chunk_sums = ctx->d_chunk_sums + layer * chunk_cap;
+        W.tri_planes = ctx->d_tri_planes + layer * cap;
         W.item_base = ctx->d_item_base + layer * (cap + 1u);
         W.vis = ctx->d_vis[layer];
         W.planes.pos_depth = (float4*)targets[layer]->pos_depth;
@@ -1237,19 +1242,17 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
                            ctx->d_instance_counts, ctx->num_primitives, (uint32_t*)draw_counts, out, two);
     }
     if (max_cap > 0u) {
-        const uint32_t chunks = (max_cap + kScanChunk - 1u) / kScanChunk;
         if (!fused_demux)
             hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1, 2), dim3(1024), 0, stream, two, (const uint32_t*)draw_counts,
                                ctx->num_primitives);
-        hipLaunchKernelGGL(raster_setup_kernel, dim3((max_cap + 255u) / 256u, 2), dim3(256), 0, stream, gv, fr, two, mat_flags,
-                           (uint32_t)(sizeof(tr_dmat) / 4u));
-        if (chunks <= kSmallScanChunks) {   // small layers: one launch for the work-item prefix
-            hipLaunchKernelGGL(raster_scan_items_small_kernel, dim3(1, 2), dim3(1024), 0, stream, two);
-        } else {
-            hipLaunchKernelGGL(raster_scan_items_reduce_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
-            hipLaunchKernelGGL(raster_scan_items_chunks_kernel, dim3(1, 2), dim3(1024), 0, stream, two);
-            hipLaunchKernelGGL(raster_scan_items_apply_kernel, dim3(chunks, 2), dim3(1024), 0, stream, two);
+        // set-up + the work-item prefix (decoupled look-back; its status words are tagged with this call's epoch)
+        if (ctx->scan_epoch >= 0x3FFFFFFFu) {   // (2^30 frames on: the tags wrap, start over from clean words)
+            TR_HIP(ctx, hipMemsetAsync(ctx->d_scan_status, 0, 2u * (size_t)ctx->scan_blocks * 8u, stream));
+            ctx->scan_epoch = 0u;
         }
+        ctx->scan_epoch += 1u;
+        hipLaunchKernelGGL(raster_setup_kernel, dim3((max_cap + 255u) / 256u, 2), dim3(256), 0, stream, gv, fr, two, mat_flags,
+                           (uint32_t)(sizeof(tr_dmat) / 4u), ctx->d_scan_status, ctx->scan_blocks, ctx->scan_epoch);
         tr_raster_layers rl;
         for (uint32_t layer = 0; layer < 2u; ++layer) {
             const tr_layer_work& W = two.l[layer];
@@ -2036,7 +2039,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->list_hint = ctx->d_tile_list[0];
         ctx->list_count_hint = ctx->d_tile_list_counts;
         ctx->vis_hint = use_vis ? ctx->d_vis[0] : nullptr;
-        ctx->records_hint = ctx->d_records;
+        ctx->planes_hint = ctx->d_tri_planes;
         ctx->vis_front_hint = use_vis ? ctx->d_vis[1] : nullptr;
         ctx->cover_front_hint = ctx->d_tile_cover[1];
         ctx->mip1_hint = fused_level1 ? (void*)((uint2*)f->pyramid.texels + f->pyramid.level_offset[1]) : nullptr;
@@ -2044,7 +2047,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->mip1_hint = nullptr;
         ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
         ctx->vis_hint = nullptr;
-        ctx->records_hint = nullptr;
+        ctx->planes_hint = nullptr;
         ctx->vis_front_hint = nullptr;
         ctx->cover_front_hint = nullptr;
     }
@@ -2060,11 +2063,11 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->list_hint = ctx->d_tile_list[1];
         ctx->list_count_hint = ctx->d_tile_list_counts + 1;
         ctx->vis_hint = use_vis ? ctx->d_vis[1] : nullptr;
-        ctx->records_hint = ctx->d_records + ctx->work_capacity;
+        ctx->planes_hint = ctx->d_tri_planes + ctx->work_capacity;
         st = tr_shade_transmission(ctx, &layers[1], f->uniforms, f->push, &f->pyramid, f->hdr, f->hdr_format, whole, stream);
         ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
         ctx->vis_hint = nullptr;
-        ctx->records_hint = nullptr;
+        ctx->planes_hint = nullptr;
     }
     if (st != TR_OK) return st;
     if (use_vis) ctx->vis_clean = true;   // (both passes enqueued: every visibility word the frame set is zeroed again)
