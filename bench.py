@@ -5,33 +5,36 @@ metric   shaded Mpixels/s (+ p50 frame ms) of the 4K transmissive pass: `fragmen
          (shader/src/lib.rs:37-162) over a fully covered synthetic TGB-v1 G-buffer, DragonAttenuation's
          light rig (sun + 1 punctual light), RGBA16F target, inputs resident in HBM.
 step     one transmissive pass over one 3840x2160 frame (tr_shade_transmission) — at N > 1 followed by the
-         composite (tr_allgather_frame: RCCL all-gather of the row bands; by default of the frame AS PRESENTED: every
-         rank tonemaps its band to RGBA8 inside the step, `--composite-format rgba16f` gathers the HDR target instead).
-one frame, two launches (N = 1)   `--split P` (default 2): a step shades the frame as P row bands (tr_band_rows: 4-row
-         aligned), band i through its own tr_shade_transmission call (the sharding API's rect) on HIP stream i.  On ONE
-         stream a launch waits for the last wave of the one before, and ~5 % of a launch is its fill and drain; with the
-         frame in two half-frame launches on two streams the hardware starts one band's waves in the wave slots the other
-         band's stragglers leave empty — disjoint halves of one frame, nothing shared, nothing cached (4K: 81.4 -> 76.9 us,
-         tools/gpu_overlap_probe.py; four bands on four streams: 83.8).  `value` and `roofline` are wall clock / K of that
-         region; a launch's own start-to-end duration (what rocprofv3 lists) is about one step, for half a frame.  The
-         same K frames as whole-frame launches on one stream are timed right after and reported as `single_stream`.
-frames in flight (N = 1)   `--streams S` (default 1): S > 1 issues step k on HIP stream k mod S, every frame in flight with
-         its OWN copy of the G-buffer planes, the opaque pyramid and the colour target (and one launch per frame).  Two
-         such frames gain nothing (83.8 vs 81.4 us: two frames' windows in every L2).  (Round 3's first bench ran two
-         frames in flight over ONE shared G-buffer: the second frame found the first one's plane reads in the caches —
-         75.8 us — which no renderer's consecutive frames do.  Those figures are withdrawn.)
-
+         composite (tr_allgather_frame: RCCL all-gather of the row bands).
+N = 1    (run_single) A step shades the frame as `--split P` row bands (default 2 from 4 Mpixels up), band i through its
+         own tr_shade_transmission call on HIP stream i (the pattern INTEGRATION.md documents: one band's waves start in the
+         slots the other band's stragglers leave).  COLD INPUTS: the timed steps rotate through `--sets` (default: as many
+         as make > 1.2 GB, at least 3) distinct input sets — own G-buffer planes, own opaque pyramid, own target — so no
+         step finds its inputs in the 256 MiB Infinity Cache; the same K steps over ONE set are reported beside it
+         (`same_input`).  `value`, `ms_per_step` and `roofline.frac` all come from the wall clock of the K timed steps;
+         the HIP-event bracket of the same region is reported as `roofline.frac_events`.
+         The line also carries, each measured the same way in this run:
+           configs.config2_1080p     BASELINE config 2's frame size: the transmissive pass, and opaque -> mips -> transmissive
+                                     through `record`
+           configs.config3_4k        4 punctual lights, roughness override 0.25 (arithmetic-bound: with a VALU roofline)
+           configs.config5_8k_1gpu   config 5's 7680x4320 frame on one GPU
+           configs.all_transmissive  every material transmission_factor 1 (what DragonAttenuation is)
+         with us, Mpixels/s and the roofline fraction on 52 B/px and on SURVEY 8d's 60 B/px, and
+           single_stream             one whole-frame tr_shade_transmission call per frame on one stream (rounds 1-2's step)
+           frame_pipeline            tr_record_frame (culling -> rasteriser -> opaque -> mips -> transmissive -> tonemap)
+         roofline.traffic / roofline.valu: three short child runs of this script (`--pmc-probe`) under rocprofv3 --pmc
+         (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU ...: separate passes, kernel trace only).
 python bench.py --gpus N   starts by itself: with WORLD_SIZE unset and N > 1 it spawns N child processes (one per
          GPU, before anything touches a GPU) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 set; under
          torch.distributed.run it uses the environment it is given.
-
-N > 1    BASELINE config 4 / north_star: ONE 3840x2160 frame cut into N row bands (tr_band_rows: 4-row aligned), one
-         process per GPU, replicated read-only inputs (tables, LUT, opaque pyramid), no collective while shading:
-         STRONG scaling (`--scaling strong`, the default).  The timed step is band kernel + composite, pipelined the
-         way a renderer would run it (`--composite overlap`: frame k's all-gather runs on a second stream under frame
+N > 1    (run_rank) BASELINE config 4 / north_star: ONE 3840x2160 frame cut into N row bands (tr_band_rows: 4-row
+         aligned), one process per GPU, replicated read-only inputs (tables, LUT, opaque pyramid), no collective while
+         shading: STRONG scaling (`--scaling strong`, the default).  The timed step is band kernel + composite, pipelined
+         the way a renderer would run it (`--composite overlap`: frame k's all-gather runs on a second stream under frame
          k+1's shading, two frame buffers); `value` = frame pixels x K / wall time of the K steps, max over ranks.
          Reported next to it: the kernel-only rate (no composite), the composite alone, rank 0's whole-frame
-         single-GPU time measured in the same run and both speed-ups over it.
+         single-GPU time measured in the same run and both speed-ups over it, and (`full_pipeline_8k`) the 8K frame of
+         BASELINE config 5 through the sharded full pipeline — the one workload where sharding can pay.
          `--scaling weak` keeps round 1's mode (every rank shades 8.29 Mpx of a frame that grows with N).
 
 Prints ONE JSON line on rank 0.
@@ -57,6 +60,11 @@ if ROOT not in sys.path:
 SURVEY_BYTES_PER_PIXEL = 60
 ALGORITHMIC_BYTES_PER_PIXEL = 52
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
+# The vector unit's measured issue peak (tools/ubench/valu_rate.hip on MI355X, profiles/r01/f_valu_issue_rates.txt): 1.12 G
+# wave64 instructions/s per SIMD for dual-issued VGPR-operand fp32 mul/add/fma (2.14 cycles each at 2.4 GHz) x 64 lanes x
+# 1024 SIMDs.  Instructions with an SGPR source, conversions / compares (4.0-4.1 cycles) and transcendentals (8.1) issue
+# slower: a kernel's mix reaches less.
+VALU_PEAK_LANEOPS = 1.12e9 * 64 * 1024
 
 
 def parse_args(argv=None):
@@ -84,11 +92,17 @@ def parse_args(argv=None):
     ap.add_argument("--all-transmissive", action="store_true",
                     help="every synthetic material gets transmission_factor 1 (DragonAttenuation's is 1): no tile skips "
                          "the refraction taps; the default run reports this variant beside the headline number")
-    ap.add_argument("--no-variants", action="store_true", help="N = 1: skip the extra reported variants")
+    ap.add_argument("--no-variants", action="store_true", help="N = 1: skip the extra reported configs / variants")
+    ap.add_argument("--sets", type=int, default=0,
+                    help="N = 1: distinct input sets (planes + pyramid + target) the timed steps rotate through; 0 = default: "
+                         "as many as make more than 1.2 GB, at least 3")
+    ap.add_argument("--pmc-probe", action="store_true",
+                    help="internal (the child runs under rocprofv3 --pmc): six whole-frame launches each of the headline "
+                         "scene, the all-transmissive scene and config 3, nothing else")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true",
-                    help="N = 1: do not measure roofline.traffic live (two short child runs of this script under "
-                         "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`); the committed profiles/pmc_traffic.json is used instead")
+                    help="N = 1: do not measure roofline.traffic / roofline.valu live (three short child runs of this script "
+                         "under `rocprofv3 --pmc ...`); the committed profiles/pmc_traffic.json is used for the traffic instead")
     ap.add_argument("--no-single-gpu-reference", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--ramp-s", type=float, default=None, help="seconds of back-to-back launches before the warm-up (clock ramp; "
@@ -180,6 +194,61 @@ def make_mip0_torch(width: int, height: int, device):
     return img
 
 
+def make_gbuffer_torch(width: int, height: int, device, rows=None, num_materials: int = 16):
+    """synthetic.make_gbuffer evaluated on the device (bench input only; the same analytic fields in float64, so the
+    planes equal the host version's up to the last bit of libm vs the device's sin / cos): an 8K frame takes the host
+    half a minute of numpy and the device a few milliseconds."""
+    import math
+    import torch
+    from transmission_renderer_amd import wire
+    from transmission_renderer_amd.renderer import GBufferPlanes
+    f64 = torch.float64
+    eye, view = wire.default_camera()
+    proj = wire.perspective_matrix_reversed(width, height)
+    y0, y1 = (0, height) if rows is None else rows
+    xs = torch.arange(width, dtype=f64, device=device) + 0.5
+    ys = torch.arange(y0, y1, dtype=f64, device=device) + 0.5
+    ndc_x = (xs / width * 2.0 - 1.0)[None, :]
+    ndc_y = (ys / height * 2.0 - 1.0)[:, None]
+    fx, fy = float(proj[0, 0]), float(-proj[1, 1])
+    dvx, dvy = ndc_x / fx, -ndc_y / fy
+    zv = 2.6 + 0.6 * torch.sin(7.0 * ndc_x + 1.3) * torch.cos(5.0 * ndc_y) + 0.25 * torch.sin(23.0 * ndc_x * ndc_y)
+    vx, vy, vz = dvx * zv, dvy * zv, -zv
+    v = view.astype("float64")
+    s_ = [float(v[0, 0]), float(v[1, 0]), float(v[2, 0])]
+    u_ = [float(v[0, 1]), float(v[1, 1]), float(v[2, 1])]
+    b_ = [float(v[0, 2]), float(v[1, 2]), float(v[2, 2])]
+    e = [float(x) for x in eye]
+    h = y1 - y0
+    pos_depth = torch.empty((h, width, 4), dtype=torch.float32, device=device)
+    nrm_scale = torch.empty((h, width, 4), dtype=torch.float32, device=device)
+    for k in range(3):
+        pos_depth[..., k] = e[k] + s_[k] * vx + u_[k] * vy + b_[k] * vz
+    pa, pb = float(proj[2, 2]), float(proj[3, 2])
+    pos_depth[..., 3] = (pa * vz + pb) / (-vz)
+    inv = 1.0 / torch.sqrt(vx * vx + vy * vy + vz * vz)
+    rx = 0.9 * torch.sin(31.0 * ndc_x + 2.0 * ndc_y) + 0.3 * torch.sin(97.0 * ndc_y)
+    ry = 0.9 * torch.cos(27.0 * ndc_y - 3.0 * ndc_x) + 0.3 * torch.cos(89.0 * ndc_x)
+    nvx, nvy, nvz = -vx * inv + rx, -vy * inv + ry, -vz * inv + 0.0 * rx
+    nlen = 0.75 + 0.25 * torch.sin(11.0 * ndc_x + 5.0 * ndc_y)
+    for k in range(3):
+        nrm_scale[..., k] = (s_[k] * nvx + u_[k] * nvy + b_[k] * nvz) * nlen
+    uv = torch.empty((h, width, 2), dtype=torch.float32, device=device)
+    uv[..., 0] = (xs[None, :] / width * 4.0).expand(h, width)
+    uv[..., 1] = (ys[:, None] / height * 4.0).expand(h, width)
+    cw, ch = width / 16.0, height / 9.0
+    xw = xs[None, :] + 0.35 * cw * torch.sin(ys[:, None] * (2.0 * math.pi / (3.1 * ch)))
+    yw = ys[:, None] + 0.35 * ch * torch.sin(xs[None, :] * (2.0 * math.pi / (2.7 * cw)))
+    cx = torch.floor(xw / cw).to(torch.int64)
+    cy = torch.floor(yw / ch).to(torch.int64)
+    hsh = (cx * 73856093) ^ (cy * 19349663) ^ ((cx + cy) * 83492791)
+    hsh = (hsh ^ (hsh >> 13)) & 0x7FFFFFFF
+    material_id = (hsh % num_materials).to(torch.int32)
+    scale = torch.tensor([1.0, 0.5, 2.0, 1.0], dtype=torch.float32, device=device)
+    nrm_scale[..., 3] = scale[(hsh >> 8) % 4]
+    return GBufferPlanes(pos_depth, nrm_scale, uv, material_id.contiguous(), 0, y0)
+
+
 def native_oracle():
     """The oracle as BASELINE.md 2 describes the CPU baseline: `-O3 -march=native`, no fast-math, no FMA contraction —
     compiled HERE (the host the baseline is timed on; a -march=native object from another machine may not even run)
@@ -217,14 +286,18 @@ def cpu_baseline(scene, lut, width, height, budget_s=12.0):
     if native is not None:
         oracle._bind_passes(native)
 
+    bands = {}
+
     def run(rows):
-        y0 = max(0, height // 2 - rows // 2)
-        band = synthetic.make_gbuffer(width, height, rows=(y0, y0 + rows))
+        if rows not in bands:                            # (the planes are inputs: made once, outside the timed region)
+            y0 = max(0, height // 2 - rows // 2)
+            bands[rows] = synthetic.make_gbuffer(width, height, rows=(y0, y0 + rows))
         t0 = time.perf_counter()
-        oracle.shade_transmission(binding, band, tex, hdr_f16=hdr16, hdr_f32=hdr32, nthreads=cores, lib=native)
+        oracle.shade_transmission(binding, bands[rows], tex, hdr_f16=hdr16, hdr_f32=hdr32, nthreads=cores, lib=native)
         return time.perf_counter() - t0
 
-    run(min(height, max(cores, 16)))                 # warm-up (page in the planes, spin up the threads)
+    run(min(height, max(cores, 16)))                 # warm-up (spin up the threads)
+    run(height)                                      # ... and page in the whole frame's planes
     dt1 = run(height)                                # one whole frame
     reps = max(1, min(200, int(budget_s / max(dt1, 1e-3))))   # many-core hosts finish a frame in < 1 s
     rows = height
@@ -235,12 +308,17 @@ def cpu_baseline(scene, lut, width, height, budget_s=12.0):
                       f"frame ({rows_total * width / 1e6:.1f} Mpx) in {dt:.1f} s, {cores} threads"}
 
 
-def measure_traffic(args):
-    """HBM bytes per launch of the transmissive kernel from the PMC counters, measured NOW: two child runs of this script
-    (a few untimed launches, one stream) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — the
-    counters in separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled (gfx950 tallies
-    the 128-byte requests of 16 B/lane streaming reads at 64 B), KiB -> bytes.  Returns None when rocprofv3 is missing,
-    this process already runs under it, or anything fails (the committed profiles/pmc_traffic.json is used then)."""
+PROBE_PHASES = ("headline", "all_transmissive", "config3")
+PROBE_LAUNCHES = 6
+
+
+def measure_pmc(args):
+    """Counters of the transmissive kernel, measured NOW: three child runs of this script (`--pmc-probe`: PROBE_LAUNCHES
+    whole-frame launches each of the headline scene, the all-transmissive scene and config 3, one stream) under
+    `rocprofv3 --kernel-trace --pmc ...` — FETCH_SIZE, WRITE_SIZE and the SQ counters in separate passes, kernel trace
+    only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of 16 B/lane
+    streaming reads at 64 B), KiB -> bytes.  Returns {phase: {counter: median over the phase's launches}} or None when
+    rocprofv3 is missing, this process already runs under it, or anything fails."""
     import csv
     import glob
     import shutil
@@ -248,38 +326,207 @@ def measure_traffic(args):
     rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rocprof is None or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
         return None
-    out = {}
+    out = {ph: {} for ph in PROBE_PHASES}
     tmp = tempfile.mkdtemp(prefix="tr_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
-                   sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--streams", "1", "--split", "1", "--no-cpu-baseline",
-                   "--no-variants", "--no-traffic", "--ramp-s", "0.0", "--width", str(args.width), "--height", str(args.height),
-                   "--lights", str(args.lights)] + (["--roughness-override", str(args.roughness_override)] if args.roughness_override is not None else []) \
-                  + (["--all-transmissive"] if args.all_transmissive else [])
+        for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]):
+            d = os.path.join(tmp, counters[0])
+            cmd = [rocprof, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-probe", "--width", str(args.width), "--height", str(args.height),
+                   "--lights", str(args.lights)]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             if r.returncode != 0:
                 return None
-            vals = []
+            rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if "shade_kernel<true" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if len(vals) < 4:
-                return None
-            vals.sort()
-            out[counter] = vals[len(vals) // 2] * 1024.0      # median over the launches, KiB -> bytes
-        return {"hbm_bytes_per_launch": int(round(2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"])),
-                "fetch_size_bytes_raw": int(round(out["FETCH_SIZE"])), "write_size_bytes": int(round(out["WRITE_SIZE"])),
-                "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child "
-                          "passes of this script (--steps 6 --split 1: whole-frame launches; median over the kernel's launches), KiB -> bytes; FETCH_SIZE "
-                          "doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of 16 B/lane streaming reads at 64 B)"}
+                rows += [row for row in csv.DictReader(open(f)) if "shade_kernel<true" in row["Kernel_Name"]]
+            for c in counters:
+                vals = [(int(row["Dispatch_Id"]), float(row["Counter_Value"])) for row in rows if row["Counter_Name"] == c]
+                vals.sort()
+                if len(vals) != PROBE_LAUNCHES * len(PROBE_PHASES):
+                    return None
+                for i, ph in enumerate(PROBE_PHASES):
+                    seg = sorted(v for _, v in vals[i * PROBE_LAUNCHES:(i + 1) * PROBE_LAUNCHES])
+                    out[ph][c] = seg[len(seg) // 2]
+        for ph in PROBE_PHASES:
+            c = out[ph]
+            c["hbm_bytes_per_launch"] = int(round(2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0))
+        out["source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU ... in "
+                         "separate child passes of this script (--pmc-probe: whole-frame launches, median over each scene's "
+                         f"{PROBE_LAUNCHES} launches), KiB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the "
+                         "128-B requests of 16 B/lane streaming reads at 64 B)")
+        return out
     except Exception:
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_probe(args) -> int:
+    """The child of measure_pmc: nothing but the launches (the parent finds them by dispatch order)."""
+    import torch
+    for phase in PROBE_PHASES:
+        wl = PassWorkload(0, args.width, args.height, lights=4 if phase == "config3" else args.lights,
+                          roughness=0.25 if phase == "config3" else None, all_transmissive=phase == "all_transmissive",
+                          sets=1, split=1)
+        for _ in range(PROBE_LAUNCHES):
+            wl.step(0)
+        torch.cuda.synchronize()
+        wl.close()
+    return 0
+
+
+class PassWorkload:
+    """One configuration of the transmissive pass on one GPU: a context with its tables, `sets` distinct input sets
+    (G-buffer planes, opaque pyramid, RGBA16F target) and the step that shades one frame — as `split` row bands, band i
+    through its own tr_shade_transmission call on HIP stream i."""
+
+    def __init__(self, device_index, width, height, lights=1, roughness=None, all_transmissive=False, sets=0, split=0):
+        import numpy as np
+        import torch
+        from transmission_renderer_amd import sharded, synthetic
+        from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer, load_ggx_lut
+        self.torch = torch
+        self.w, self.h = width, height
+        self.pixels = width * height
+        self.r = r = TransmissionRenderer(device_index)
+        dev = r.device
+        self.scene = scene = synthetic.make_scene(width, height, num_point_lights=lights, with_gbuffer=False,
+                                                  roughness_override=roughness)
+        if all_transmissive:
+            for m in scene["materials"]:
+                m.transmission_factor = 1.0
+        self.lut = load_ggx_lut()
+        r.upload_materials(scene["materials"])
+        r.upload_lights(scene["lights"])
+        r.upload_ggx_lut(self.lut)
+        r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(dev),
+                             torch.from_numpy(scene["light_indices"].view(np.int32)).to(dev))
+        g = make_gbuffer_torch(width, height, dev)
+        pyr = OpaquePyramid(width, height, dev)
+        pyr.level(0).copy_(make_mip0_torch(width, height, dev))
+        r.generate_mips(pyr)
+        self.set_bytes = self.pixels * 44 + pyr.texels.numel() * 2 + self.pixels * 8
+        n_sets = sets if sets > 0 else max(3, -(-1_200_000_000 // self.set_bytes) + 1)
+        self.sets = [(g, pyr, torch.zeros((height, width, 4), dtype=torch.float16, device=dev))]
+        for _ in range(n_sets - 1):
+            p2 = OpaquePyramid(width, height, dev)
+            p2.texels.copy_(pyr.texels)
+            self.sets.append((GBufferPlanes(g.pos_depth.clone(), g.nrm_scale.clone(), g.uv.clone(), g.material_id.clone()), p2,
+                              torch.zeros((height, width, 4), dtype=torch.float16, device=dev)))
+        self.split = split if split > 0 else (2 if self.pixels >= 4_000_000 else 1)
+        self.parts = [(0, a, width, b) for a, b in (sharded.band_rows(height, self.split, i)[1:] for i in range(self.split)) if b > a] \
+            if self.split > 1 else [None]
+        self.flight = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(len(self.parts) - 1)]
+        self.levels = pyr.levels
+        self.launches = 0
+        torch.cuda.synchronize()
+
+    def step(self, k, rotate=True):
+        g, pyr, frame = self.sets[k % len(self.sets) if rotate else 0]
+        u, pc = self.scene["uniforms"], self.scene["push"]
+        if len(self.parts) == 1:
+            self.r.shade_transmission(g, u, pc, pyr, frame, self.parts[0])
+        else:
+            for s_, part in zip(self.flight, self.parts):
+                with self.torch.cuda.stream(s_):
+                    self.r.shade_transmission(g, u, pc, pyr, frame, part)
+        self.launches += len(self.parts)
+
+    def whole_frame(self, k, rotate=True):
+        g, pyr, frame = self.sets[k % len(self.sets) if rotate else 0]
+        self.r.shade_transmission(g, self.scene["uniforms"], self.scene["push"], pyr, frame)
+        self.launches += 1
+
+    def ramp(self, seconds):
+        """Back-to-back steps until the GPU has been busy for `seconds`: its clocks ramp over the first ~10 ms of load."""
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(16):
+                self.step(k)
+                k += 1
+            self.torch.cuda.synchronize()
+
+    def timed(self, K, fn=None, rotate=True, first=0):
+        """K steps back to back: (wall-clock ms per step between two device synchronisations, HIP-event ms per step: from
+        the first stream's start event to the last stream's end event)."""
+        torch = self.torch
+        fn = fn or self.step
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in self.flight]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in self.flight]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_, e in zip(self.flight, ev0):
+            e.record(s_)
+        for k in range(K):
+            fn(first + k, rotate)
+        for s_, e in zip(self.flight, ev1):
+            e.record(s_)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / K * 1e3
+        return wall, max(ev0[0].elapsed_time(e) for e in ev1) / K
+
+    def figures(self, ms):
+        return {"us": round(ms * 1e3, 2), "Mpixels_per_s": round(self.pixels / ms / 1e3, 1),
+                "frac_52B": round(self.pixels * ALGORITHMIC_BYTES_PER_PIXEL / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_60B": round(self.pixels * SURVEY_BYTES_PER_PIXEL / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    def close(self):
+        self.sets = []
+        self.r.close()
+
+
+def valu_roofline(counters, pixels, ms):
+    """roofline.valu from the SQ counters of one launch and a step time: vector lane-operations against the vector unit's
+    measured issue peak."""
+    if not counters or "SQ_INSTS_VALU" not in counters:
+        return None
+    lane_ops = counters["SQ_INSTS_VALU"] * 64.0
+    achieved = lane_ops / (ms * 1e-3)
+    return {"bound": "valu", "lane_ops_per_pixel": round(lane_ops / pixels, 1), "achieved": round(achieved / 1e12, 2),
+            "peak": round(VALU_PEAK_LANEOPS / 1e12, 2), "unit": "T lane-ops/s", "frac": round(achieved / VALU_PEAK_LANEOPS, 4),
+            "vector_instructions_per_launch": int(counters["SQ_INSTS_VALU"]),
+            "scalar_instructions_per_launch": int(counters.get("SQ_INSTS_SALU", 0)),
+            "note": "SQ_INSTS_VALU x 64 lanes / step time; peak = dual-issued VGPR-operand fp32 ops, 1.12 G wave64 "
+                    "instructions/s/SIMD x 64 x 1024 SIMDs (tools/ubench/valu_rate.hip, profiles/r01/f_valu_issue_rates.txt); "
+                    "an SGPR source, a conversion / compare (4.0-4.1 cycles) or a transcendental (8.1) issues slower, so the "
+                    "kernel's instruction mix cannot reach 1.0"}
+
+
+def measure_config(name, device_index, width, height, K, W, lights=1, roughness=None, all_transmissive=False, with_record=False):
+    """One entry of the `configs` block: the transmissive pass of the configuration, steps as in the headline (row bands
+    on streams, rotating cold input sets), the same steps over one input set, and a whole-frame launch per frame."""
+    import torch
+    wl = PassWorkload(device_index, width, height, lights=lights, roughness=roughness, all_transmissive=all_transmissive)
+    try:
+        wl.ramp(0.1)
+        if W > 0:
+            wl.timed(W)
+        ms, _ = wl.timed(K)
+        same, _ = wl.timed(K, rotate=False)
+        single, _ = wl.timed(K, fn=wl.whole_frame)
+        out = dict(wl.figures(ms), workload=f"transmissive pass {width}x{height}, sun + {lights} punctual light(s)"
+                                           + (f", roughness override {roughness}" if roughness is not None else "")
+                                           + (", every material transmission_factor 1" if all_transmissive else ""),
+                   launches_per_step=len(wl.parts), input_sets=len(wl.sets), input_set_MB=round(wl.set_bytes / 1e6, 1),
+                   same_input_us=round(same * 1e3, 2), single_stream_us=round(single * 1e3, 2),
+                   single_stream_frac_52B=wl.figures(single)["frac_52B"])
+        if with_record:
+            # BASELINE config 2 "opaque + transmissive passes end-to-end": opaque -> mips -> transmissive through `record`
+            # (the synthetic layer serves as both the opaque and the transmissive layer, as in smoke())
+            def frame(k, rotate=True):
+                g, pyr, hdr = wl.sets[k % len(wl.sets) if rotate else 0]
+                wl.r.record(g, g, wl.scene["uniforms"], wl.scene["push"], hdr, pyr)
+            wl.timed(max(W, 1), fn=frame)
+            fms, _ = wl.timed(K, fn=frame)
+            out["opaque_mips_transmissive_frame"] = {"us": round(fms * 1e3, 2), "Mpixels_per_s": round(wl.pixels / fms / 1e3, 1),
+                                                     "note": "tr_shade_opaque + tr_generate_mips + tr_shade_transmission per frame, "
+                                                             "one stream, rotating input sets"}
+        return out
+    finally:
+        wl.close()
+        torch.cuda.empty_cache()
 
 
 def frame_pipeline_time(width, height):
@@ -379,13 +626,177 @@ def selftest_cpu(args, world, rank):
     return 0 if ok else 1
 
 
-# ------------------------------------------------------------------------------------------------ one rank
+# ------------------------------------------------------------------------------------------------ N = 1
+def run_single(args) -> int:
+    """The default command: the headline metric on one GPU and everything reported beside it (see the module docstring)."""
+    import numpy as np
+    import torch
+    from transmission_renderer_amd import synthetic
+    K, W = args.steps, args.warmup
+    fw, fh = args.width, args.height
+    wl = PassWorkload(0, fw, fh, lights=args.lights, roughness=args.roughness_override, all_transmissive=args.all_transmissive,
+                      sets=args.sets, split=args.split)
+    pixels = wl.pixels
+    multi = len(wl.parts) > 1
+    wl.ramp(args.ramp_s if args.ramp_s is not None else (0.15 if multi else 0.05))
+    clock_ramp_launches = wl.launches
+    if W > 0:
+        wl.timed(W)                                               # W untimed warm-up steps
+    # the metric: exactly K steps, wall clock between two device synchronisations
+    ms_per_step, events_ms = wl.timed(K, first=W)
+    value = pixels / ms_per_step / 1e3
+    launch_log = [("clock_ramp", clock_ramp_launches), ("warmup", W * len(wl.parts)), ("timed", K * len(wl.parts))]
+    # beside it: the same K steps over ONE input set (round 3's step), and one whole-frame launch per frame on one stream
+    same_ms, _ = wl.timed(K, rotate=False)
+    single_ms, _ = wl.timed(K, fn=wl.whole_frame)
+    launch_log += [("same_input", K * len(wl.parts)), ("single_stream", K)]
+    # p50 frame ms of the metric: the step's own pattern, timed in batches of 10 steps (an event pair per step would put a
+    # barrier packet between the steps it measures)
+    batch = 10
+    per_step = np.array([wl.timed(batch)[0] for _ in range(max(5, min(20, K // 2)))], dtype=np.float64)
+    launch_log.append(("percentiles", len(per_step) * batch * len(wl.parts)))
+    # ... and of single whole-frame launches, an event pair around each
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    for i in range(K):
+        starts[i].record()
+        wl.whole_frame(i)
+        ends[i].record()
+    torch.cuda.synchronize()
+    per_launch_ms = np.array([a.elapsed_time(b) for a, b in zip(starts, ends)], dtype=np.float64)
+    sync_ms = []
+    for i in range(30):     # a launch + synchronise per step: what a host loop that waits for every frame sees
+        t1 = time.perf_counter()
+        wl.whole_frame(i)
+        torch.cuda.synchronize()
+        sync_ms.append((time.perf_counter() - t1) * 1e3)
+    launch_log += [("per_launch_events", K), ("launch_sync", 30)]
+    levels, n_sets, set_mb, lps = wl.levels, len(wl.sets), wl.set_bytes / 1e6, len(wl.parts)
+    fig = wl.figures
+    headline, same_fig, single_fig, ev_fig = fig(ms_per_step), fig(same_ms), fig(single_ms), fig(events_ms)
+    scene_for_cpu, lut = wl.scene, wl.lut
+    wl.close()
+    torch.cuda.empty_cache()
+
+    extras = not args.no_variants and not args.all_transmissive and args.roughness_override is None
+    configs = {}
+    if extras:
+        kc, wc = min(K, 20), min(W, 5)
+        try:
+            configs["config2_1080p"] = measure_config("config2", 0, 1920, 1080, kc, wc, lights=1, with_record=True)
+            configs["config3_4k"] = measure_config("config3", 0, 3840, 2160, kc, wc, lights=4, roughness=0.25)
+            configs["config5_8k_1gpu"] = measure_config("config5", 0, 7680, 4320, kc, wc, lights=1)
+            configs["all_transmissive"] = measure_config("all_transmissive", 0, fw, fh, kc, wc, lights=args.lights, all_transmissive=True)
+        except Exception as e:       # (never costs the metric its line)
+            configs["error"] = f"{type(e).__name__}: {e}"
+    frame_pipeline = None
+    if extras:
+        try:
+            frame_pipeline = frame_pipeline_time(fw, fh)
+            frame_pipeline["at_1080p"] = {k: v for k, v in frame_pipeline_time(1920, 1080).items() if k in ("us_per_frame", "two_frames_in_flight")}
+            frame_pipeline["at_8k"] = {k: v for k, v in frame_pipeline_time(7680, 4320).items() if k in ("us_per_frame", "two_frames_in_flight")}
+        except Exception as e:
+            frame_pipeline = dict(frame_pipeline or {}, error=f"{type(e).__name__}: {e}")
+
+    pmc = None if args.no_traffic else measure_pmc(args)          # child processes; the GPU is idle here
+    achieved = pixels * ALGORITHMIC_BYTES_PER_PIXEL / (ms_per_step * 1e-3) / 1e9
+    out = {
+        "metric": "shaded Mpixels/sec, 4K transmissive pass (fragment_transmission over a synthetic TGB-v1 G-buffer)",
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": round(ms_per_step, 4),
+        "p50_frame_ms": round(float(np.percentile(per_step, 50)), 4), "p10_frame_ms": round(float(np.percentile(per_step, 10)), 4),
+        "p90_frame_ms": round(float(np.percentile(per_step, 90)), 4),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"transmissive pass, frame {fw}x{fh}, TGB-v1 synthetic G-buffer fully covered, 16 materials"
+                               + (" (all transmission_factor 1)" if args.all_transmissive else "")
+                               + (f", roughness override {args.roughness_override}" if args.roughness_override is not None else "")
+                               + f", sun + {args.lights} punctual light(s) (DragonAttenuation rig), RGBA16F target, "
+                                 f"{levels}-level opaque pyramid, ggx_lut.png"
+                               + (f", every frame shaded as {lps} row bands (one tr_shade_transmission call each) on {lps} HIP streams"
+                                  if lps > 1 else "")
+                               + f"; the timed steps rotate through {n_sets} distinct input sets of {set_mb:.0f} MB "
+                                 "(planes + pyramid + target): no step re-reads what the previous one left in the caches",
+                   "pixels_per_step": pixels, "pixels_per_gpu": pixels, "sharding": "none (one GPU holds the frame)",
+                   "composite": "none (one GPU holds the frame)", "input_sets": n_sets, "input_set_MB": round(set_mb, 1)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "tr::shade_kernel<true, uint2, 0, false>", "avg_kernel_ms": round(ms_per_step, 4),
+                     "algorithmic_bytes_per_pixel": ALGORITHMIC_BYTES_PER_PIXEL,
+                     "algorithmic_bytes_per_launch": pixels * ALGORITHMIC_BYTES_PER_PIXEL,
+                     "frac_survey_60B": headline["frac_60B"],
+                     "frac_events": ev_fig["frac_52B"], "events_ms_per_step": round(events_ms, 4),
+                     "streams": 1, "launches_per_step": lps,
+                     "note": "frac = 52 B/px x pixels / ms_per_step (the wall clock of the K timed steps, the same number `value` "
+                             "comes from) / 8 TB/s.  52 B/px = what this untextured variant moves (16 + 16 + 4 B planes, 8 B opaque "
+                             "colour, 8 B write; = SURVEY 8d's read-only figure); SURVEY 8d's 60 B/px also counts the 8 B/px uv "
+                             "plane, which this kernel never loads (frac_survey_60B).  frac_events: the same region bracketed by "
+                             "HIP events on the launch streams.  A step is "
+                             f"{lps} launch(es) of the kernel, one per row band of the frame, each on its own stream; `traffic` is "
+                             "and algorithmic_bytes_per_launch are per WHOLE-FRAME launch (the --pmc-probe child runs)"},
+        "same_input": dict(same_fig, note="the same K steps over ONE input set (round 3's timed step): what re-reading a G-buffer "
+                                          "that the previous step left in the Infinity Cache is worth"),
+        "single_stream": dict(single_fig, avg_kernel_ms=round(single_ms, 4), frac=single_fig["frac_52B"], p50_launch_ms=round(float(np.percentile(per_launch_ms, 50)), 4),
+                              p10_launch_ms=round(float(np.percentile(per_launch_ms, 10)), 4),
+                              p90_launch_ms=round(float(np.percentile(per_launch_ms, 90)), 4),
+                              note="ONE whole-frame tr_shade_transmission call per frame on one stream, each behind the "
+                                   "previous one, rotating input sets (rounds 1-2's step; what a caller that does not split the pass "
+                                   "gets); p*_launch_ms: an event pair around every launch"),
+        "clock_ramp_launches": clock_ramp_launches,
+        "launch_sync_p50_ms": round(float(np.percentile(sync_ms, 50)), 4),
+        "launch_log": launch_log,
+    }
+    tr_ = None
+    if pmc is not None:
+        c = pmc["headline"]
+        tr_ = {"hbm_bytes_per_launch": c["hbm_bytes_per_launch"], "source": pmc["source"]}
+        out["roofline"]["valu"] = valu_roofline(c, pixels, ms_per_step)
+        if "config3_4k" in configs and isinstance(configs["config3_4k"], dict):
+            configs["config3_4k"]["valu"] = valu_roofline(pmc["config3"], 3840 * 2160, configs["config3_4k"]["us"] * 1e-3)
+            configs["config3_4k"]["traffic"] = pmc["config3"]["hbm_bytes_per_launch"]
+        if "all_transmissive" in configs and isinstance(configs["all_transmissive"], dict):
+            configs["all_transmissive"]["valu"] = valu_roofline(pmc["all_transmissive"], pixels, configs["all_transmissive"]["us"] * 1e-3)
+            configs["all_transmissive"]["traffic"] = pmc["all_transmissive"]["hbm_bytes_per_launch"]
+    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if tr_ is None and os.path.exists(traffic_file) and not args.all_transmissive and args.roughness_override is None:
+        try:
+            with open(traffic_file) as f:
+                committed = json.load(f)
+            if committed.get("width") == fw and committed.get("height") == fh and committed.get("lights") == args.lights:
+                tr_ = committed
+        except Exception:
+            pass
+    if tr_ is not None:
+        kernel_s = ms_per_step * 1e-3
+        out["roofline"]["traffic"] = tr_["hbm_bytes_per_launch"]
+        out["roofline"]["achieved_from_traffic"] = round(tr_["hbm_bytes_per_launch"] / kernel_s / 1e9, 1)
+        out["roofline"]["frac_from_traffic"] = round(tr_["hbm_bytes_per_launch"] / kernel_s / 1e9 / HBM_PEAK_GBS, 4)
+        out["roofline"]["traffic_source"] = tr_.get("source")
+    if configs:
+        out["configs"] = configs
+        if "all_transmissive" in configs and isinstance(configs["all_transmissive"], dict):     # (the key rounds 2-3 reported)
+            a = configs["all_transmissive"]
+            out["variants"] = {"all_transmissive": {"avg_kernel_ms": round(a["us"] / 1e3, 4), "Mpixels_per_s": a["Mpixels_per_s"],
+                                                    "frac": a["frac_52B"], "frac_survey_60B": a["frac_60B"]}}
+    if frame_pipeline:
+        out["frame_pipeline"] = frame_pipeline
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene_for_cpu, lut, fw, fh, args.cpu_budget_s)
+        out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ one rank (N > 1)
 def run_rank(args) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.selftest_cpu:
         return selftest_cpu(args, world, rank)
+    if args.pmc_probe:
+        return pmc_probe(args)
+    if world == 1 and not args.rehearse_distributed and args.streams <= 1:
+        return run_single(args)
     import numpy as np
     import torch
     distributed = world > 1 or args.rehearse_distributed

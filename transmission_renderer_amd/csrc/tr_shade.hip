@@ -169,6 +169,7 @@ struct tr_context {
     struct stream_seen { hipStream_t stream; uint64_t generation; };
     std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
     bool no_mid_class = false;                  // TR_NO_MID_CLASS (tests only), read once at context creation
+    uint32_t vis_grid_rounds = 3;               // see persistent_grid (TR_VIS_ROUNDS: tuning only)
 };
 
 namespace {
@@ -491,9 +492,14 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
 }
 
 // Persistent grid: 8 XCDs x k blocks, k chosen so that every CU holds its 4 resident 256-thread blocks.
-uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles) {
+// `vis`: a launch of the frame recorder (visibility words, XCD stripes, most tiles of a real frame empty or cheap): fewer,
+// longer-lived waves — kVisGridRounds instead of kGridRounds times what is resident.  4K mesh frame by rounds
+// (TR_BLOCKS_PER_XCD sweep, all shading launches of the frame): 1 -> 243.8 us, 2 -> 227.0, 4 -> 227.0, 7 -> 228.9,
+// 8 -> 232.1, 16 -> 247.0: a wave's start (kernarg loads, the sRGB table into LDS) is paid per wave, and a frame's covered
+// tiles are spread evenly over the stripes anyway.  The synthetic G-buffer's plane launches keep 8 (§3.1 of DESIGN.md).
+uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles, bool vis = false) {
     const uint32_t per_xcd = (ntiles + 7u) / 8u;
-    uint32_t bpx = ctx->blocks_per_xcd;
+    uint32_t bpx = vis ? ctx->blocks_per_xcd / kGridRounds * ctx->vis_grid_rounds : ctx->blocks_per_xcd;
 #if TR_ABLATION || TR_TIMING
     if (const char* e = std::getenv("TR_GRID_QUARTERS")) bpx = bpx / kGridRounds * (uint32_t)std::atoi(e) / 4u;   // profiling builds only: quarters of the resident blocks
 #endif
@@ -711,6 +717,7 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         }
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
         ctx->no_mid_class = std::getenv("TR_NO_MID_CLASS") != nullptr;   // tests only: the full-class launch's general build
+        if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));  // tuning only
     }
     if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_slice_thr, sizeof(float) * (TR_MAX_DEPTH_SLICES + 2)) != hipSuccess ||
@@ -1399,10 +1406,10 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     if (st != TR_OK) return st;
     fp.pyr_levels = 1;
     // one-wave workgroups: blocks_per_xcd counts units of four waves
-    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * 4u), block(64);
+    tr_launch L;
+    fill_launch(L, ctx, fp, g);
+    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y, L.vis != nullptr) * 4u), block(64);
     {
-        tr_launch L;
-        fill_launch(L, ctx, fp, g);
         L.hdr = hdr_out;
         L.mip0 = (uint2*)opaque_mip0_out;
         L.mip1 = (L.vis && L.mip0 && format == TR_FORMAT_RGBA16F) ? (uint2*)ctx->mip1_hint : nullptr;   // (the frame recorder)
@@ -1513,10 +1520,10 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     if (st != TR_OK) return st;
     fp.pyr_levels = p->levels;
     // one-wave workgroups: blocks_per_xcd counts units of four waves
-    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y) * 4u), block(64);
+    tr_launch L;
+    fill_launch(L, ctx, fp, g);
+    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y, L.vis != nullptr) * 4u), block(64);
     {
-        tr_launch L;
-        fill_launch(L, ctx, fp, g);
         L.pyramid = (const uint2*)p->texels;
         L.hdr = hdr_inout;
         const bool half = format == TR_FORMAT_RGBA16F;
