@@ -79,9 +79,10 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--composite", choices=("overlap", "serial", "none"), default="overlap",
                     help="N > 1: how the composite all-gather enters the timed step")
-    ap.add_argument("--composite-format", choices=("rgba8", "rgba16f"), default="rgba8",
-                    help="N > 1: what is composited — rgba8: the frame as it is presented (every rank tonemaps its band with "
-                         "tr_tonemap inside the step, the 4 B/px bands are gathered); rgba16f: the HDR target itself (8 B/px)")
+    ap.add_argument("--composite-format", choices=("rgb8", "rgba8", "rgba16f"), default="rgb8",
+                    help="N > 1: what is composited — rgb8 (default): the frame as it is presented without its constant alpha "
+                         "(every rank tonemaps its band with tr_tonemap_rgb8 inside the step, the 3 B/px bands are gathered); "
+                         "rgba8: with the alpha byte (4 B/px, round 3); rgba16f: the HDR target itself (8 B/px)")
     ap.add_argument("--split", type=int, default=0,
                     help="N = 1: a step shades the frame as P row bands, band i on HIP stream i (1: one whole-frame launch; "
                          "0 = default: 2 for frames of 4 Mpixels and more, else 1 — at 1080p two small launches cost more than "
@@ -104,6 +105,11 @@ def parse_args(argv=None):
                     help="N = 1: do not measure roofline.traffic / roofline.valu live (three short child runs of this script "
                          "under `rocprofv3 --pmc ...`); the committed profiles/pmc_traffic.json is used for the traffic instead")
     ap.add_argument("--no-single-gpu-reference", action="store_true")
+    ap.add_argument("--no-full-pipeline", action="store_true", help="N > 1: skip the 8K full-pipeline frame (full_pipeline_8k)")
+    ap.add_argument("--exchange", choices=("halo", "allgather"), default="halo",
+                    help="N > 1, full pipeline: how the opaque colour crosses the band borders between the passes — halo: rows "
+                         "of levels 0 and 1 with the two neighbours + an all-gather of level 2 (1/16 of the bytes); allgather: "
+                         "all of level 0 (round 3)")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--ramp-s", type=float, default=None, help="seconds of back-to-back launches before the warm-up (clock ramp; "
                                                                "default 0.05, 0.15 with several frames in flight)")
@@ -626,6 +632,65 @@ def selftest_cpu(args, world, rank):
     return 0 if ok else 1
 
 
+def full_pipeline_8k(r, comp, world, rank, dev, dist, scene4k, K, args):
+    """ms per frame of sharded.record_sharded on the 7680x4320 synthetic frame, max over ranks; rank 0 also times the same
+    frame through `record` on one GPU."""
+    import torch
+    from transmission_renderer_amd import sharded, synthetic
+    from transmission_renderer_amd.renderer import OpaquePyramid
+    fw, fh = 7680, 4320
+    scene = synthetic.make_scene(fw, fh, num_point_lights=args.lights, with_gbuffer=False)     # (same materials and lights: uploaded)
+    uniforms, push = scene["uniforms"], scene["push"]
+    rows, y0, y1 = sharded.band_rows(fh, world, rank)
+    padded = rows * world
+    g = make_gbuffer_torch(fw, fh, dev, rows=(y0, y1) if y1 > y0 else (0, 1))
+    pyr = OpaquePyramid(fw, fh, dev, level0_rows=padded)
+    hdr = torch.zeros((padded, fw, 4), dtype=torch.float16, device=dev)
+    exchange = args.exchange if world > 1 else "allgather"
+
+    def frame():
+        sharded.record_sharded(r, g, g, uniforms, push, hdr, pyr, comp, exchange=exchange)
+
+    for _ in range(3):
+        frame()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        frame()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item()) / K * 1e3
+    out = {"ms_per_frame": round(ms, 4), "Mpixels_per_s": round(fw * fh / ms / 1e3, 1), "frames": K,
+           "workload": f"opaque -> exchange -> mip chain -> transmissive -> composite, frame {fw}x{fh} in {world} row bands of {rows} rows, "
+                       f"synthetic TGB-v1 layer as both layers, sun + {args.lights} punctual light(s)",
+           "exchange": exchange, "exchange_fallbacks": int(getattr(comp, "halo_fallbacks", 0)),
+           "composite": "RGBA16F frame, all-gather of the row bands"}
+    del g, pyr, hdr
+    if rank == 0 and not args.no_single_gpu_reference:
+        gw = make_gbuffer_torch(fw, fh, dev)
+        pw = OpaquePyramid(fw, fh, dev)
+        hw = torch.zeros((fh, fw, 4), dtype=torch.float16, device=dev)
+        for _ in range(3):
+            r.record(gw, gw, uniforms, push, hw, pw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            r.record(gw, gw, uniforms, push, hw, pw)
+        torch.cuda.synchronize()
+        one = (time.perf_counter() - t0) / K * 1e3
+        out["single_gpu_ms"] = round(one, 4)
+        out["speedup_vs_1gpu"] = round(one / ms, 3)
+        del gw, pw, hw
+    dist.barrier()
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ N = 1
 def run_single(args) -> int:
     """The default command: the headline metric on one GPU and everything reported beside it (see the module docstring)."""
@@ -834,7 +899,7 @@ def run_rank(args) -> int:
     r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(dev),
                          torch.from_numpy(scene["light_indices"].view(np.int32)).to(dev))
     rect_whole = (0, y0, fw, y1)
-    g = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh, rows=(y0, y1) if y1 > y0 else (0, 1)), dev)   # this rank's screen tile only
+    g = make_gbuffer_torch(fw, fh, dev, rows=(y0, y1) if y1 > y0 else (0, 1))   # this rank's screen tile only
     pyr = OpaquePyramid(fw, fh, dev)                                                  # replicated read-only input
     pyr.level(0).copy_(make_mip0_torch(fw, fh, dev))
     r.generate_mips(pyr)
@@ -858,8 +923,9 @@ def run_rank(args) -> int:
     # N > 1: what crosses the links.  rgba8 (default): the presented frame — the band is tonemapped (fragment_tonemap,
     # shader/src/lib.rs:683-697, what the reference's last pass does before the swapchain) inside the step and the 8-bit
     # bands are gathered: half the bytes per link of the RGBA16F target.
-    present_ldr = distributed and composite != "none" and args.composite_format == "rgba8"
-    ldr_frames = [torch.zeros((padded, fw, 4), dtype=torch.uint8, device=dev) for _ in frames] if present_ldr else None
+    present_ldr = distributed and composite != "none" and args.composite_format in ("rgba8", "rgb8")
+    ldr_channels = 3 if args.composite_format == "rgb8" else 4
+    ldr_frames = [torch.zeros((padded, fw, ldr_channels), dtype=torch.uint8, device=dev) for _ in frames] if present_ldr else None
     tonemap_params = r.baked_tonemap_params() if present_ldr else None
     comp = sharded.Compositor(world, rank, renderer=r, single_rank_comm=args.rehearse_distributed) if distributed else None
     torch.cuda.synchronize()
@@ -881,7 +947,7 @@ def run_rank(args) -> int:
         if not present_ldr:
             return frames[i]
         if y1 > y0:
-            r.tonemap(frames[i][y0:y1], tonemap_params, out=ldr_frames[i][y0:y1])
+            (r.tonemap_rgb8 if ldr_channels == 3 else r.tonemap)(frames[i][y0:y1], tonemap_params, out=ldr_frames[i][y0:y1])
         return ldr_frames[i]
 
     def step(k):
@@ -1016,7 +1082,7 @@ def run_rank(args) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         composite_ms = float(t.item())
         # the same composite of the frame as it is presented: bands tonemapped to RGBA8 first (half the bytes per link)
-        ldr = torch.zeros((padded, fw, 4), dtype=torch.uint8, device=dev)
+        ldr = torch.zeros((padded, fw, ldr_channels), dtype=torch.uint8, device=dev)
         dist.barrier()
         composite_ldr_ms = timed_launches(max(10, K // 4), lambda: comp.allgather_rows(ldr))
         t = torch.tensor([composite_ldr_ms], dtype=torch.float64, device=dev)
@@ -1057,7 +1123,7 @@ def run_rank(args) -> int:
     single_gpu_in_flight_ms = None
     if distributed and strong and not args.no_single_gpu_reference:
         if rank == 0:                          # the same frame on ONE GPU, same run: the denominator of the speed-ups
-            gw = GBufferPlanes.from_numpy(synthetic.make_gbuffer(fw, fh), dev)
+            gw = make_gbuffer_torch(fw, fh, dev)
             whole = torch.zeros((fh, fw, 4), dtype=torch.float16, device=dev)
             fn = lambda: r.shade_transmission(gw, uniforms, push, pyr, whole)   # noqa: E731
             t_r = time.perf_counter()      # (the GPU idled while the host made the planes: ramp its clocks again)
@@ -1079,6 +1145,13 @@ def run_rank(args) -> int:
                 del whole2, gw2
             del gw, whole
         dist.barrier()
+
+    # BASELINE config 5's frame through the sharded FULL pipeline (opaque band -> exchange of the opaque colour -> mip chain
+    # -> transmissive band -> composite): the workload where sharding can pay — per rank 1/N of two shading passes against one
+    # exchange, where the transmissive pass alone is ~1/N of 360 us against a composite that costs as much.
+    full_pipeline = None
+    if distributed and strong and not args.no_full_pipeline:
+        full_pipeline = full_pipeline_8k(r, comp, world, rank, dev, dist, scene, max(5, min(K, 20)), args)
 
     variants = {}
     if not distributed and not args.no_variants and not args.all_transmissive:
@@ -1138,8 +1211,8 @@ def run_rank(args) -> int:
                        "composite": ("none (one GPU holds the frame)" if not distributed else
                                      f"{composite}: {comp.backend}"
                                      + ("" if composite == "none" else
-                                        ", of the frame as presented: every rank tonemaps its band (tr_tonemap) inside the step and "
-                                        "the RGBA8 bands (4 B/px) are gathered" if present_ldr else
+                                        ", of the frame as presented: every rank tonemaps its band (tr_tonemap" + ("_rgb8" if ldr_channels == 3 else "") + ") inside the step and "
+                                        f"the {'RGB8' if ldr_channels == 3 else 'RGBA8'} bands ({ldr_channels} B/px) are gathered" if present_ldr else
                                         ", of the RGBA16F HDR target (8 B/px)"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -1196,13 +1269,18 @@ def run_rank(args) -> int:
                     "Mpixels_per_s": round(pixels_step / kernel_in_flight_ms / 1e3, 1),
                     "note": "the same with consecutive frames' bands on two HIP streams (max over ranks)"}
             out["composite_allgather_ms"] = round(composite_ms, 4)
-            out["composite_rgba8_allgather_ms"] = round(composite_ldr_ms, 4)
+            out["composite_rgba8_allgather_ms" if ldr_channels == 4 else "composite_rgb8_allgather_ms"] = round(composite_ldr_ms, 4)
             if single_gpu_ms is not None:
                 out["single_gpu_ms"] = round(single_gpu_ms, 4)
                 out["speedup_vs_1gpu"] = {"kernel_only": round(single_gpu_ms / kernel_ms_max, 3),
                                           "with_composite": round(single_gpu_ms / ms_per_step, 3)}
                 if kernel_in_flight_ms is not None:   # (both sides with two frames in flight)
                     out["speedup_vs_1gpu"]["kernel_only_two_frames_in_flight"] = round(single_gpu_in_flight_ms / kernel_in_flight_ms, 3)
+        if full_pipeline:
+            out["full_pipeline_8k"] = full_pipeline
+            out["values"] = {"value": "transmissive pass of the 3840x2160 frame in row bands + composite (BASELINE config 4: the metric)",
+                             "full_pipeline_8k.Mpixels_per_s": "opaque -> exchange -> mips -> transmissive -> composite of the 7680x4320 frame "
+                                                               "(BASELINE config 5), all ranks together"}
         if variants:
             out["variants"] = variants
         if frame_pipeline:

@@ -221,7 +221,8 @@ typedef struct tr_rect {
 typedef enum tr_format {
     TR_FORMAT_RGBA16F = 0,
     TR_FORMAT_RGBA32F = 1,
-    TR_FORMAT_RGBA8 = 2     /* tr_allgather_frame only: the tonemapped 8-bit frame (tr_tonemap's output) */
+    TR_FORMAT_RGBA8 = 2,    /* tr_allgather_frame only: the tonemapped 8-bit frame (tr_tonemap's output) */
+    TR_FORMAT_RGB8 = 3      /* ... and without its constant alpha (tr_tonemap_rgb8's output): 3 bytes per pixel */
 } tr_format;
 
 /*
@@ -419,6 +420,19 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* gbuffer, const tr_u
 /* "opaque framebuffer mipchain": generate_mips (src/main.rs:2046-2064): levels 1.. from level 0,
  * each level a LINEAR blit of the previous one, fp32 accumulate, RTNE store to RGBA16F. */
 tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* pyramid, void* stream);
+/* The same chain from level `first_level` on (>= 1): levels first_level .. from level first_level - 1, which the caller
+ * has completed — e.g. 3 after the level-2 all-gather of a row-band sharded frame (below). */
+tr_status tr_generate_mips_from(tr_context* ctx, const tr_pyramid* pyramid, uint32_t first_level, void* stream);
+/* Row-band sharded full pipeline (no reference counterpart: src/main.rs:243 is one queue): levels 1 and 2
+ * of the rows [y0, y1) of level 0 (a band on 4-row boundaries of a frame whose sizes are multiples of 4: the blits are
+ * exact 2x2 boxes that never look outside the band).  TR_ERR_UNSUPPORTED otherwise (exchange all of level 0 instead). */
+tr_status tr_generate_mips_band(tr_context* ctx, const tr_pyramid* pyramid, uint32_t y0, uint32_t y1, void* stream);
+/* ... and what the transmissive pass of such a rank may sample: rows [row_lo, row_hi) of level 0 (its band + the halo it
+ * received) and, halved, of level 1; levels >= 2 are whole on every rank.  With a window set tr_shade_transmission
+ * records in *excess_word_dev (device, 4 bytes, zeroed by the caller) 1 + the largest number of level-0 rows by which a
+ * tap of levels 0 / 1 lay outside it (atomicMax; 0 = the pass is exact) — the caller re-runs the exchange with a larger
+ * halo (or all of level 0) and the pass when it is not 0.  row_hi = 0 or a NULL word: off. */
+tr_status tr_set_tap_window(tr_context* ctx, uint32_t row_lo, uint32_t row_hi, void* excess_word_dev);
 
 /*
  * "opaque transmissive objects": `fragment_transmission` (shader/src/lib.rs:37-162) for
@@ -576,6 +590,17 @@ int32_t   tr_comm_last_error(const tr_comm* comm);
 tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame_dev, uint32_t width, uint32_t rows_per_rank,
                              tr_format format, void* stream);
 
+/* The mid-frame exchange of a row-band sharded full pipeline WITHOUT gathering all of level 0: `level_rows_dev` is a
+ * whole pyramid level (`total_rows` rows of `row_bytes` bytes) of which this rank has written its band (rows
+ * rank * rows_per_rank ..., clipped); on return (stream order) it also holds the `halo_rows` rows above and below its
+ * band, received from the ranks that own them (ncclSend / ncclRecv, one group; halo_rows >= total_rows: an all-gather).
+ * Per link a rank's band-border rows instead of its whole band.  Call it on every rank with the same arguments.
+ * tr_halo_rows (host only): the rows [*y0, *y1) of `owner`'s band that `reader` receives (y0 == y1: none). */
+tr_status tr_exchange_halo(tr_context* ctx, tr_comm* comm, void* level_rows_dev, uint32_t row_bytes, uint32_t total_rows,
+                           uint32_t rows_per_rank, uint32_t halo_rows, void* stream);
+tr_status tr_halo_rows(uint32_t total_rows, uint32_t rows_per_rank, uint32_t nranks, uint32_t owner, uint32_t reader,
+                       uint32_t halo_rows, uint32_t* y0, uint32_t* y1);
+
 /* Rank-interleaved strips, for frames whose cost is uneven over the screen (sky above, geometry below: contiguous bands
  * leave the ranks of the sky idle): the frame is cut into strips of `strip_rows` rows (a multiple of 4; 64 is a good
  * size), strip s belongs to rank s % nranks.  After tr_set_strips, tr_shade_opaque / tr_shade_transmission called with a
@@ -606,6 +631,11 @@ tr_status tr_bake_lottes_params(const tr_lottes_params* params, tr_tonemap_param
  * `bgra` != 0 selects that byte order, 0 gives R,G,B,A. */
 tr_status tr_tonemap(tr_context* ctx, const void* hdr_rgba16f, uint32_t width, uint32_t height,
                      const tr_tonemap_params* params, void* out_rgba8, int32_t bgra, void* stream);
+/* The same pixels without the alpha byte (it is 255 everywhere: fragment_tonemap writes alpha 1): 3 bytes per pixel,
+ * r g b (or b g r), rows tightly packed — what a row-band sharded frame composites (tr_allgather_frame with
+ * TR_FORMAT_RGB8): a quarter less per xGMI link than RGBA8.  width * height must be a multiple of 4. */
+tr_status tr_tonemap_rgb8(tr_context* ctx, const void* hdr_rgba16f, uint32_t width, uint32_t height,
+                          const tr_tonemap_params* params, void* out_rgb8, int32_t bgra, void* stream);
 
 /* ------------------------------------------------------------------ one frame */
 

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("fmt", ["rgba8", "rgba16f"])
+@pytest.mark.parametrize("fmt", ["rgb8", "rgba16f"])
 def test_distributed_bench_path_on_one_gpu(fmt):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-distributed", "--steps", "20", "--warmup", "3",
@@ -26,9 +26,11 @@ def test_distributed_bench_path_on_one_gpu(fmt):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["composite"].startswith("overlap: tr_allgather_frame (RCCL), of the "
-                                                 + ("frame as presented" if fmt == "rgba8" else "RGBA16F HDR target"))
+                                                 + ("frame as presented" if fmt == "rgb8" else "RGBA16F HDR target"))
     assert out["kernel_only"]["per_rank_kernel_ms"][0] > 0 and 0 < out["kernel_only"]["per_rank_roofline_frac"][0] < 1
-    assert out["composite_allgather_ms"] > 0 and out["composite_rgba8_allgather_ms"] > 0
+    assert out["composite_allgather_ms"] > 0 and out["composite_rgb8_allgather_ms" if fmt == "rgb8" else "composite_rgba8_allgather_ms"] > 0
+    fp = out["full_pipeline_8k"]            # BASELINE config 5's frame through the sharded full pipeline (one rank here)
+    assert fp["ms_per_frame"] > 0 and fp["single_gpu_ms"] > 0 and 0.5 < fp["speedup_vs_1gpu"] < 1.5
     assert out["single_gpu_ms"] > 0 and out["speedup_vs_1gpu"]["kernel_only"] > 0.5
     assert out["kernel_only"]["two_frames_in_flight"]["ms_per_step"] > 0 and out["speedup_vs_1gpu"]["kernel_only_two_frames_in_flight"] > 0.5
 

@@ -72,28 +72,40 @@ def _free_port():
 
 
 class _OraclePyramid:
-    """The pyramid as record_sharded sees it (level0_padded) over the oracle's packed texel array."""
+    """The pyramid as record_sharded sees it (level0_padded, level(k)) over the oracle's packed texel array.  Level 0 has
+    its own padded storage (the gathers want equal bands); the packed array's copy of it is refreshed before a chain is
+    built or sampled."""
 
     def __init__(self, w, h, rows):
         from oracle import oracle
         self.w, self.h = w, h
         self.level0 = torch.zeros((rows, w, 4), dtype=torch.float16)
-        self.tex = oracle.new_pyramid(w, h, np.zeros((h, w, 4), np.float16))
+        self.tex = oracle.new_pyramid(w, h, np.full((h, w, 4), 77.0, np.float16))      # (a sentinel: rows nobody delivered)
+        self.levels, layout, _ = wire.pyramid_layout(w, h)
+        self.offsets = [t[0] for t in layout]
+        self._tex_t = torch.from_numpy(self.tex)                                        # shares memory
 
     def level0_padded(self):
         return self.level0
 
     def level(self, k):
-        assert k == 0
-        return self.level0[:self.h]
+        if k == 0:
+            return self.level0[:self.h]
+        wk, hk = max(self.w >> k, 1), max(self.h >> k, 1)
+        off = int(self.offsets[k])
+        return self._tex_t[off:off + wk * hk].view(hk, wk, 4)
+
+    def sync_level0(self):
+        self.tex[:self.w * self.h] = self.level0[:self.h].numpy().reshape(-1, 4)
 
 
 class _OracleRenderer:
     """Stands in for TransmissionRenderer in sharded.record_sharded: the same three calls, answered by the CPU
     oracle on host tensors, so the REAL recorder (band arithmetic, exchange order, padded buffers) runs in the test."""
 
-    def __init__(self, binding):
+    def __init__(self, binding, materials=None):
         self.binding = binding
+        self.materials = materials
         self.calls = []
         self.strips = None
 
@@ -127,18 +139,106 @@ class _OracleRenderer:
     def generate_mips(self, pyramid):
         from oracle import oracle
         self.calls.append(("mips", None))
-        pyramid.tex[:pyramid.w * pyramid.h] = pyramid.level0[:pyramid.h].numpy().reshape(-1, 4)
+        pyramid.sync_level0()
         oracle.generate_mips(pyramid.w, pyramid.h, pyramid.tex)
+
+    def generate_mips_band(self, pyramid, y0, y1):
+        """tr_generate_mips_band: levels 1 and 2 of the band = levels 1 and 2 of the band's rows taken as an image of their
+        own (sizes multiples of 4: exact 2x2 boxes)."""
+        from oracle import oracle
+        self.calls.append(("mips_band", (y0, y1)))
+        assert pyramid.w % 4 == 0 and pyramid.h % 4 == 0 and y0 % 4 == 0 and (y1 % 4 == 0 or y1 == pyramid.h)
+        if y1 == y0:
+            return
+        sub = oracle.new_pyramid(pyramid.w, y1 - y0, pyramid.level0[y0:y1].numpy())
+        oracle.generate_mips(pyramid.w, y1 - y0, sub)
+        offs = [t[0] for t in wire.pyramid_layout(pyramid.w, y1 - y0)[1]]
+        for k in (1, 2):
+            wk, hk = pyramid.w >> k, (y1 - y0) >> k
+            pyramid.level(k)[y0 >> k:(y0 >> k) + hk] = torch.from_numpy(sub[int(offs[k]):int(offs[k]) + wk * hk].reshape(hk, wk, 4))
+
+    def generate_mips_from(self, pyramid, first):
+        """tr_generate_mips_from(3): levels 3.. = levels 1.. of the chain whose level 0 is level 2."""
+        from oracle import oracle
+        self.calls.append(("mips_from", first))
+        assert first == 3
+        w2, h2 = pyramid.w >> 2, pyramid.h >> 2
+        sub = oracle.new_pyramid(w2, h2, pyramid.level(2).numpy())
+        oracle.generate_mips(w2, h2, sub)
+        levels, layout, _ = wire.pyramid_layout(w2, h2)
+        offs = [t[0] for t in layout]
+        assert levels == pyramid.levels - 2
+        for k in range(1, levels):
+            wk, hk = max(w2 >> k, 1), max(h2 >> k, 1)
+            pyramid.level(k + 2)[:] = torch.from_numpy(sub[int(offs[k]):int(offs[k]) + wk * hk].reshape(hk, wk, 4))
+
+    window = None
+    excess = 0
+
+    def set_tap_window(self, lo=0, hi=0):
+        self.window = (lo, hi) if hi else None
+        if hi:
+            self.excess = 0
+
+    def tap_window_excess(self):
+        return self.excess
+
+    def _window_excess(self, g, push, pyramid, rect):
+        """What the kernel's tap_window_excess reports, restated in numpy (float64): 1 + the level-0 rows by which the
+        bilinear rows of a tap of level 0 / 1 lie outside the window."""
+        lo, hi = self.window
+        mats = self.materials
+        w, h = pyramid.w, pyramid.h
+        oy = g["origin_y"]
+        ys = slice(rect[1] - oy, rect[3] - oy)
+        pos = g["pos_depth"][ys, :, :3].astype(np.float64)
+        n = g["nrm_scale"][ys, :, :3].astype(np.float64)
+        scale = g["nrm_scale"][ys, :, 3].astype(np.float64)
+        mid = g["material_id"][ys]
+        ok = mid != wire.NOT_COVERED
+        mid = np.where(ok, mid, 0)
+        arr = lambda f: np.array([f(m) for m in mats], dtype=np.float64)[mid]       # noqa: E731
+        ior, thick, tf, rough = (arr(lambda m: m.index_of_refraction), arr(lambda m: m.thickness_factor),
+                                 arr(lambda m: m.transmission_factor), arr(lambda m: m.roughness_factor))
+        eye = np.array(push.view_position[:3], dtype=np.float64)
+        P = np.array(push.proj_view, dtype=np.float64).reshape(4, 4).T
+        v = eye - pos
+        v /= np.linalg.norm(v, axis=-1, keepdims=True)
+        n = n / np.linalg.norm(n, axis=-1, keepdims=True)
+        eta, nov = 1.0 / ior, (n * v).sum(-1)
+        cn = -eta * nov + np.sqrt(np.maximum(1.0 - eta ** 2 * (1.0 - nov ** 2), 0.0))
+        ex = pos + (-eta[..., None] * v - cn[..., None] * n) * (thick * scale)[..., None]
+        c = np.concatenate([ex, np.ones(ex.shape[:-1] + (1,))], -1) @ P.T
+        tv = (c[..., 1] / c[..., 3] + 1.0) / 2.0
+        lod = np.clip(np.log2(np.float32(w)) * rough * np.clip(2.0 * ior - 2.0, 0.0, 1.0), 0.0, pyramid.levels - 1)
+        l0 = np.floor(lod).astype(np.int64)
+        worst = 0.0
+        for k in (0, 1):                                                   # the lower and the upper level of the pair
+            level = np.minimum(l0 + k, pyramid.levels - 1)
+            for lv in (0, 1):
+                sel = ok & (tf != 0.0) & (level == lv)
+                if not sel.any():
+                    continue
+                hk = h >> lv
+                t = np.clip(tv[sel] * hk - 0.5, 0.0, hk - 1.0)
+                b = np.minimum(np.floor(t), max(hk - 2, 0))
+                first, last = lo >> lv, (hi >> lv) - 1
+                e = np.maximum(np.maximum(first - b, (b + 1.0) - last), 0.0) * (1 << lv)
+                worst = max(worst, float(e.max()))
+        return int(worst) + 1 if worst > 0.0 else 0
 
     def shade_transmission(self, g, uniforms, push, pyramid, hdr, rect):
         from oracle import oracle
         self.calls.append(("transmission", rect))
+        if self.window is not None:
+            self.excess = max(self.excess, self._window_excess(g, push, pyramid, rect))
+        pyramid.sync_level0()
         frame = hdr[:pyramid.h].numpy()                                   # shares memory: shaded in place (LOAD)
         for r in self._rects(rect):
             oracle.shade_transmission(self.binding, g, pyramid.tex, hdr_f16=frame, rect=r)
 
 
-def _worker(rank, world, port, w, h, out_dir, strip_rows=0):
+def _worker(rank, world, port, w, h, out_dir, strip_rows=0, halo=0, thickness_scale=1.0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -148,7 +248,23 @@ def _worker(rank, world, port, w, h, out_dir, strip_rows=0):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         lut = read_png_rgba8(os.path.join(root, "transmission_renderer_amd", "assets", "ggx_lut.png"))
         scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False)
+        for m in scene["materials"]:
+            m.thickness_factor *= thickness_scale
         binding = oracle.SceneBinding(scene, lut)
+        if halo:                                                          # the halo exchange instead of the level-0 gather
+            rows, y0, y1 = sharded.band_rows(h, world, rank)
+            band = synthetic.make_gbuffer(w, h, rows=(y0, y1))
+            hdr = torch.zeros((rows * world, w, 4), dtype=torch.float16)
+            pyr = _OraclePyramid(w, h, rows * world)
+            fake = _OracleRenderer(binding, scene["materials"])
+            comp = sharded.Compositor(world, rank)
+            comp.halo_rows = halo
+            sharded.record_sharded(fake, band, band, scene["uniforms"], scene["push"], hdr, pyr, comp, exchange="halo")
+            names = [c[0] for c in fake.calls]
+            np.save(os.path.join(out_dir, f"frame_{rank}.npy"), hdr[:h].numpy())
+            with open(os.path.join(out_dir, f"calls_{rank}.txt"), "w") as f:
+                f.write(" ".join(names) + f"\n{comp.halo_fallbacks} {comp.halo_rows}\n")
+            return
         if strip_rows:                                                    # rank-interleaved strips of whole-frame buffers
             g = synthetic.make_gbuffer(w, h)
             hdr = torch.full((h, w, 4), -7.0, dtype=torch.float16)        # (a sentinel no pass writes)
@@ -220,3 +336,53 @@ def test_record_sharded_strips_over_gloo_matches_single_rank(tmp_path, ggx_lut, 
     oracle.generate_mips(w, h, tex)
     oracle.shade_transmission(binding, scene["gbuffer"], tex, hdr_f16=hdr16)
     np.testing.assert_array_equal(frames[0].view(np.uint16), hdr16.view(np.uint16))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("w,h,world,halo,thickness_scale,fallback", [
+    (64, 48, 2, 8, 0.02, False),      # thin volumes: the taps stay within 8 rows of their pixel
+    (48, 72, 3, 12, 0.02, False),     # three bands of 24 rows
+    (64, 48, 2, 4, 1.0, True),        # the synthetic scene's thick volumes throw taps across the frame: the frame is redone
+])
+def test_record_sharded_halo_exchange_over_gloo_matches_single_rank(tmp_path, ggx_lut, w, h, world, halo, thickness_scale, fallback):
+    """record_sharded(exchange="halo") on gloo ranks (oracle-backed renderer): levels 1 / 2 per band, border rows of levels
+    0 / 1 to the neighbours, level 2 to everyone, the chain from level 3 on replicated — every rank ends with the
+    single-rank frame bit for bit; a frame whose taps leave the halo is detected, redone with the full gather, and the
+    compositor's halo grows."""
+    from oracle import oracle
+    mp.spawn(_worker, args=(world, _free_port(), w, h, str(tmp_path), 0, halo, thickness_scale), nprocs=world, join=True)
+    frames = [np.load(tmp_path / f"frame_{r}.npy") for r in range(world)]
+    for f in frames[1:]:
+        np.testing.assert_array_equal(frames[0].view(np.uint16), f.view(np.uint16))
+    scene = synthetic.make_scene(w, h, num_point_lights=2)
+    for m in scene["materials"]:
+        m.thickness_factor *= thickness_scale
+    binding = oracle.SceneBinding(scene, ggx_lut)
+    hdr16, _, mip0 = oracle.shade_opaque(binding, scene["gbuffer"])
+    tex = oracle.new_pyramid(w, h, mip0)
+    oracle.generate_mips(w, h, tex)
+    oracle.shade_transmission(binding, scene["gbuffer"], tex, hdr_f16=hdr16)
+    np.testing.assert_array_equal(frames[0].view(np.uint16), hdr16.view(np.uint16))
+    for r in range(world):
+        calls, state = open(tmp_path / f"calls_{r}.txt").read().splitlines()
+        fallbacks, halo_now = (int(x) for x in state.split())
+        if fallback:
+            assert calls.split() == ["opaque", "mips_band", "mips_from", "transmission", "mips", "transmission"]
+            assert fallbacks == 1 and halo_now > halo
+        else:
+            assert calls.split() == ["opaque", "mips_band", "mips_from", "transmission"] and fallbacks == 0 and halo_now == halo
+
+
+def test_halo_rows_between():
+    # reader 3 of 8 bands of 272 rows (4K) with a 64-row halo: the last 64 rows of band 2, the first 64 of band 4
+    got = [sharded.halo_rows_between(2160, 272, 8, o, 3, 64) for o in range(8)]
+    assert got == [(0, 0), (0, 0), (752, 816), (816, 1088), (1088, 1152), (0, 0), (0, 0), (0, 0)]
+    # a halo larger than a band reaches into the second neighbour; the frame's ends clip it
+    assert sharded.halo_rows_between(2160, 272, 8, 1, 3, 300) == (516, 544) and sharded.halo_rows_between(2160, 272, 8, 7, 6, 300) == (1904, 2160)
+    # halo >= the level: every band to every reader (the all-gather)
+    for o in range(3):
+        assert sharded.halo_rows_between(40, 16, 3, o, 1, 40) == (o * 16, min((o + 1) * 16, 40))
+    # bytes per link, 8K frame on 8 ranks, RGBA16F: level 0 + level 1 border rows + a band of level 2 vs a band of level 0
+    halo, rows, w = 128, 540, 7680
+    nb = (halo * w + (halo // 2) * (w // 2)) * 8 + (rows // 4) * (w // 4) * 8
+    assert nb < 0.37 * rows * w * 8      # 11.9 MB to each neighbour (+ 2.1 MB of level 2 to the others) instead of 33.2 MB to all seven

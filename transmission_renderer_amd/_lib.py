@@ -25,6 +25,7 @@ SYMBOLS = (
     "tr_v_smith_ggx_correlated", "tr_fresnel_schlick", "tr_compute_f0", "tr_get_depth_slice", "tr_depth_slice_thresholds",
     "tr_band_rows", "tr_comm_unique_id", "tr_comm_create", "tr_comm_from_nccl", "tr_comm_destroy", "tr_comm_last_error",
     "tr_allgather_frame", "tr_set_strips", "tr_strip_of_rank", "tr_allgather_strips",
+    "tr_generate_mips_from", "tr_generate_mips_band", "tr_set_tap_window", "tr_exchange_halo", "tr_halo_rows", "tr_tonemap_rgb8",
 )
 
 _lib = None
@@ -145,6 +146,18 @@ def load() -> C.CDLL:
     lib.tr_strip_of_rank.argtypes = [u32, u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
     lib.tr_allgather_strips.restype = i32
     lib.tr_allgather_strips.argtypes = [vp, vp, vp, u32, u32, u32, i32, vp]
+    lib.tr_generate_mips_from.restype = i32
+    lib.tr_generate_mips_from.argtypes = [vp, C.POINTER(wire.Pyramid), u32, vp]
+    lib.tr_generate_mips_band.restype = i32
+    lib.tr_generate_mips_band.argtypes = [vp, C.POINTER(wire.Pyramid), u32, u32, vp]
+    lib.tr_set_tap_window.restype = i32
+    lib.tr_set_tap_window.argtypes = [vp, u32, u32, vp]
+    lib.tr_exchange_halo.restype = i32
+    lib.tr_exchange_halo.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp]
+    lib.tr_halo_rows.restype = i32
+    lib.tr_halo_rows.argtypes = [u32, u32, u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+    lib.tr_tonemap_rgb8.restype = i32
+    lib.tr_tonemap_rgb8.argtypes = [vp, vp, u32, u32, C.POINTER(wire.TonemapParams), vp, i32, vp]
     lib.tr_ibl_volume_refraction.restype = i32
     lib.tr_ibl_volume_refraction.argtypes = [vp, vp, u32, C.POINTER(wire.Pyramid), vp, vp]
     if lib.tr_abi_version() != 1:

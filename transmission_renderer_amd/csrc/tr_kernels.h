@@ -175,8 +175,10 @@ struct alignas(16) tr_dtap {
     float wf[2], hf[2];       // (float)width, (float)height
     float xhi[2], yhi[2];     // width - 1, height - 1: the clamp of the texel coordinate
     float xlim[2], ylim[2];   // max(width - 2, 0), max(height - 2, 0): the first texel / row of the last pair
+    uint32_t level[2];        // the two levels' indices (a row-band sharded pass checks its taps of levels 0 and 1 against
+    uint32_t _pad[2];         //   the rows it holds: tap_window_excess)
 };
-static_assert(sizeof(tr_dtap) == 80, "tap record is 80 B");
+static_assert(sizeof(tr_dtap) == 96, "tap record is 96 B");
 
 // Everything a shading launch needs besides the planes; passed by value (kernarg -> SGPRs).
 struct tr_frame_params {
@@ -203,6 +205,9 @@ struct tr_frame_params {
     // Rank-interleaved strips (tr_set_strips; 0 tile rows = off): the rect is the frame, tile row r of the launch is the
     // frame's tile row ((r / T) * world + rank) * T + r % T — strip k of this rank is strip k * world + rank of the frame
     uint32_t strip_tile_rows, strip_magic /* floor(2^32 / T) */, strip_world, strip_rank;
+    // Row-band sharded full pipeline (tr_set_tap_window; hi = 0: off): the rows [lo, hi) of pyramid level 0 this rank
+    // holds — its own band and the halo it received — and, halved, of level 1; levels >= 2 are whole on every rank.
+    uint32_t tap_row_lo, tap_row_hi;
     float lut_wf;                // (float)lut_width
     uint32_t lut_stride;         // pair-table stride in entries (= lut_width + 2)
     uint32_t lut_height;
@@ -264,6 +269,7 @@ struct tr_launch {
     // depth, zeroes that word where the fragment is not nearer than the opaque surface.
     unsigned long long* vis_front;
     const uint32_t* cover_front;
+    uint32_t* tap_excess;               // optional (tap window set): atomicMax of the level-0 rows a tap reached beyond the window
 };
 typedef const TR_CONSTANT tr_launch claunch;
 
@@ -573,13 +579,25 @@ __device__ __forceinline__ void axis_single(float u, float dimf, float& w, uint3
     i1 = (uint32_t)fminf(fl + 1.0f, dimf - 1.0f);
 }
 
+// Sharded full pipeline: how many level-0 rows the bilinear rows (row, row + 1) of `level` lie outside the window of rows
+// this rank holds ([lo, hi) of level 0, [lo / 2, hi / 2) of level 1; 0 = inside, or a level every rank holds whole).
+__device__ __forceinline__ float tap_window_excess(uint32_t lo, uint32_t hi, uint32_t level, float row) {
+    if (level >= 2u) return 0.0f;
+    const float first = (float)(lo >> level), last = (float)((hi >> level) - 1u);
+    return fmaxf(fmaxf(first - row, (row + 1.0f) - last), 0.0f) * (float)(1u << level);
+}
+__device__ __forceinline__ void tap_window_report(uint32_t* excess_word, float excess) {
+    if (excess > 0.0f) atomicMax(excess_word, (uint32_t)excess + 1u);   // (rare: a fallback frame follows)
+}
+
 // Issues the loads of framebuffer.sample_by_lod(clamp_sampler, uv, lod) (shader/src/lib.rs:135-138) for the
 // lanes whose lower level is the (scalar) `l0`, so level geometry is scalar.  Every row of
 // every level is one 16-byte load of two adjacent texels; in a level that is a single texel wide the
 // second one belongs to the next row / level (or to the 8 bytes of tail padding tr_pyramid_layout
 // reserves) and is replaced by the first before use.
 __device__ __forceinline__ void pyramid_issue_levels(pyramid_fetch& pf, const uint2* __restrict__ texels,
-                                                     clevels* lv, uint32_t levels, float u, float v, uint32_t l0) {
+                                                     clevels* lv, uint32_t levels, float u, float v, uint32_t l0,
+                                                     uint32_t win_lo = 0u, uint32_t win_hi = 0u, uint32_t* excess_word = nullptr) {
     const uint32_t l1 = min(l0 + 1u, levels - 1u);
     const uint32_t w0 = lv->width[l0], w1 = lv->width[l1];
     const uint2* b0 = texels + lv->offset[l0];   // (scalar) level bases
@@ -591,6 +609,10 @@ __device__ __forceinline__ void pyramid_issue_levels(pyramid_fetch& pf, const ui
     axis_single(v, lv->hf[l0], wy0, y00, y01);
     axis_single(v, lv->hf[l1], wy1, y10, y11);
     pf.wy = v2f{wy0, wy1};
+    if (win_hi != 0u) {   // (scalar branch: a row-band sharded pass)
+        tap_window_report(excess_word, tap_window_excess(win_lo, win_hi, l0, (float)min(y00, lv->height[l0] >= 2u ? lv->height[l0] - 2u : 0u)));
+        tap_window_report(excess_word, tap_window_excess(win_lo, win_hi, l1, (float)min(y10, lv->height[l1] >= 2u ? lv->height[l1] - 2u : 0u)));
+    }
     auto ld2 = [](const uint2* level, uint32_t texel) {
         u32x4 t = ld<u32x4_a8>(level, texel * 8u);  // one global_load_dwordx4, saddr + voffset
         return uint4{t.x, t.y, t.z, t.w};
@@ -610,7 +632,7 @@ __device__ __forceinline__ void pyramid_issue_levels(pyramid_fetch& pf, const ui
 // plus the level's pitch: one offset per level, two scalar bases.  A level of one row has pitch 0, a level of one
 // column is flagged narrow (pyramid_resolve).
 __device__ __forceinline__ void pyramid_issue_record(pyramid_fetch& pf, const uint2* __restrict__ texels, cdtap* tp, float u,
-                                                     float v) {
+                                                     float v, uint32_t win_lo = 0u, uint32_t win_hi = 0u, uint32_t* excess_word = nullptr) {
     const char* base = reinterpret_cast<const char*>(texels);
     float wx[2], wy[2];
 #pragma unroll
@@ -621,6 +643,7 @@ __device__ __forceinline__ void pyramid_issue_record(pyramid_fetch& pf, const ui
         const float ty = __builtin_amdgcn_fmed3f(fmaf(v, tp->hf[k], -0.5f), 0.0f, tp->yhi[k]);
         const float by = min_s(floorf(ty), tp->ylim[k]);
         wy[k] = ty - by;
+        if (win_hi != 0u) tap_window_report(excess_word, tap_window_excess(win_lo, win_hi, tp->level[k], by));   // (scalar branch)
         const uint32_t at = mad24((uint32_t)by, tp->width[k], (uint32_t)bx) * 8u;
         const char* row0 = base + tp->offset[k];
         const char* row1 = row0 + tp->pitch[k];
@@ -639,7 +662,8 @@ __device__ __forceinline__ void pyramid_issue_record(pyramid_fetch& pf, const ui
 // so that level geometry is scalar inside pyramid_issue_levels.
 __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __restrict__ texels,
                                               clevels* lv, uint32_t levels, float u, float v,
-                                              float lod, uint32_t lane) {
+                                              float lod, uint32_t lane, uint32_t win_lo = 0u, uint32_t win_hi = 0u,
+                                              uint32_t* excess_word = nullptr) {
     float l = fminf(fmaxf(lod, 0.0f), (float)(levels - 1u));
     float lf = floorf(l);
     pf.t = l - lf;
@@ -650,7 +674,7 @@ __device__ __forceinline__ void pyramid_issue(pyramid_fetch& pf, const uint2* __
         const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, first);
         const uint64_t group = ballot(mine == l0);
         todo &= ~group;
-        if ((group >> lane) & 1ull) pyramid_issue_levels(pf, texels, lv, levels, u, v, l0);
+        if ((group >> lane) & 1ull) pyramid_issue_levels(pf, texels, lv, levels, u, v, l0, win_lo, win_hi, excess_word);
     }
 }
 
@@ -976,10 +1000,10 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
         // lod = log2(framebuffer width) * roughness * clamp(2 ior - 2, 0, 1) (:334-335): the material's alone when it
         // has no texture slots (its tap record), per lane otherwise
         if constexpr (SCALAR_MATERIAL) {
-            if (!TR_ABLATE(L, 1u)) pyramid_issue_record(pf, L->pyramid, as_constant(L->dtaps) + mat_index, tu, tv);
+            if (!TR_ABLATE(L, 1u)) pyramid_issue_record(pf, L->pyramid, as_constant(L->dtaps) + mat_index, tu, tv, L->fp.tap_row_lo, L->fp.tap_row_hi, L->tap_excess);
         } else {
             float lod = L->fp.log2_fb_width * m_rough_ior(*mb);
-            if (!TR_ABLATE(L, 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane);
+            if (!TR_ABLATE(L, 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane, L->fp.tap_row_lo, L->fp.tap_row_hi, L->tap_excess);
         }
         if (TR_ABLATE(L, 1u)) { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
         if constexpr (SCALAR_MATERIAL) {
@@ -1369,7 +1393,7 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
 // lane^1 and lane^16; the host guarantees an even rect origin) before the wave splits by material, and sends
 // materials flagged as textured through shade_pixel_textured.  The sRGB decode table sits in LDS.
 #ifndef TR_PLANES_NT_MASK
-#define TR_PLANES_NT_MASK (TEXTURED ? TR_PLANES_NT_MASK_TEXTURED : TRANSMISSIVE ? 1u : 5u)   // (opaque pass: position + ids: 73 -> 69 us)
+#define TR_PLANES_NT_MASK (TEXTURED ? TR_PLANES_NT_MASK_TEXTURED : TRANSMISSIVE ? 3u : 5u)   // (see fetch)
 #endif
 #ifndef TR_PLANES_NT_MASK_TEXTURED
 #define TR_PLANES_NT_MASK_TEXTURED 10u   // (textured plane launches: normal + uv planes non-temporal; all four: +3 %)
@@ -1524,12 +1548,13 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             t.cluster_x = 5; t.cluster_y_term = 0;
             return;
         }
-        // The planes are read once.  ONE of the two float4 planes is loaded non-temporally, so that the stream does not
-        // displace the pyramid texels, LUT lines and cluster lists the kernel keeps re-reading from L2; the other one and
-        // the ids are ordinary loads: the pass is bound by the memory system, and the streaming skeleton of
-        // this kernel runs 13 % faster on ordinary loads than on non-temporal ones (55.9 vs 64.2 us).  Both float4 planes
-        // non-temporal: 88.5 us; both ordinary: 88.2; one of each: 80.4 (4K, one stream).  TR_PLANES_NT_MASK (bit 0 the
-        // position plane, 1 the normal plane, 2 the ids, 3 the uv plane) is for the A/B builds of tools/.
+        // The planes are read once: the two float4 planes are loaded non-temporally, so that the stream does not displace
+        // the pyramid texels, LUT lines and cluster lists the kernel keeps re-reading from L2; the ids are ordinary loads.
+        // Measured with COLD inputs (bench.py: every step a different input set; 4K frame as two bands): both float4 planes
+        // non-temporal 83.5 us, all three planes 83.6, position only 87.0 (rounds 2-3's choice, tuned on ONE re-read input
+        // set, where a plane kept in the Infinity Cache is worth more than a clean L2: 78 vs 82 us), normal + ids 88.2,
+        // none 90.4.  The opaque pass keeps position + ids (its stores are re-read).  TR_PLANES_NT_MASK (bit 0 the position
+        // plane, 1 the normal plane, 2 the ids, 3 the uv plane) is for the A/B builds of tools/.
         typedef float f4v __attribute__((ext_vector_type(4)));
         typedef float f2v __attribute__((ext_vector_type(2)));
         if constexpr (VIS) {
@@ -1815,6 +1840,7 @@ __global__ void digest_taps_kernel(const tr_dmat* __restrict__ dmats, const tr_l
     d.narrow = 0u;
     for (int k = 0; k < 2; ++k) {
         const uint32_t w = lv->width[pair[k]], h = lv->height[pair[k]];
+        d.level[k] = pair[k];
         d.offset[k] = lv->offset[pair[k]] * 8u;
         d.pitch[k] = h >= 2u ? w * 8u : 0u;
         d.width[k] = w;
@@ -1826,6 +1852,7 @@ __global__ void digest_taps_kernel(const tr_dmat* __restrict__ dmats, const tr_l
         d.ylim[k] = h >= 2u ? (float)(h - 2u) : 0.0f;
         if (w < 2u) d.narrow |= 1u << k;
     }
+    d._pad[0] = d._pad[1] = 0u;
     out[i] = d;
 }
 
@@ -1986,15 +2013,17 @@ struct tr_mip_even_params {
     uint32_t nlevels;       // 1..5 levels to produce
     uint32_t src_offset;    // texel offsets from the pyramid base
     uint32_t dst_offset[5];
+    uint32_t row_begin, row_end;   // rows of the FIRST produced level to make ([0, h0 / 2) for the whole level; a row band of a
+                                   // sharded frame otherwise: row_begin a multiple of 2^(nlevels - 1), workgroups tile from it)
 };
 
 __global__ __launch_bounds__(256) void mip_even_kernel(uint2* __restrict__ pyr, const tr_mip_even_params p) {
     __shared__ uint2 lds[16 * 16 + 8 * 8 + 4 * 4 + 2 * 2 + 1];
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
     const uint32_t w1 = p.w0 >> 1, h1 = p.h0 >> 1;
-    const uint32_t i1 = blockIdx.x * 16u + tx, j1 = blockIdx.y * 16u + ty;
+    const uint32_t i1 = blockIdx.x * 16u + tx, j1 = p.row_begin + blockIdx.y * 16u + ty;
     uint2 r = {0u, 0u};
-    if (i1 < w1 && j1 < h1) {
+    if (i1 < w1 && j1 < min(h1, p.row_end)) {
         const uint2* src = pyr + p.src_offset;
         const uint4 a = *reinterpret_cast<const uint4*>(src + (size_t)(2u * j1) * p.w0 + 2u * i1);        // 16-byte aligned
         const uint4 b = *reinterpret_cast<const uint4*>(src + (size_t)(2u * j1 + 1u) * p.w0 + 2u * i1);
@@ -2011,11 +2040,11 @@ __global__ __launch_bounds__(256) void mip_even_kernel(uint2* __restrict__ pyr, 
         const uint32_t wl = p.w0 >> (l + 1u), hl = p.h0 >> (l + 1u);
         if (threadIdx.x < half * half) {
             const uint32_t x = threadIdx.x % half, y = threadIdx.x / half;
-            const uint32_t gi = blockIdx.x * half + x, gj = blockIdx.y * half + y;
+            const uint32_t gi = blockIdx.x * half + x, gj = (p.row_begin >> l) + blockIdx.y * half + y;
             const uint2* s = lds + base;
             const uint2 v = box4(s[(2u * y) * side + 2u * x], s[(2u * y) * side + 2u * x + 1u],
                                  s[(2u * y + 1u) * side + 2u * x], s[(2u * y + 1u) * side + 2u * x + 1u]);
-            if (gi < wl && gj < hl) pyr[p.dst_offset[l] + (size_t)gj * wl + gi] = v;
+            if (gi < wl && gj < min(hl, (p.row_end + (1u << l) - 1u) >> l)) pyr[p.dst_offset[l] + (size_t)gj * wl + gi] = v;
             lds[base + side * side + y * half + x] = v;
         }
         base += side * side;
@@ -2176,6 +2205,21 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const uint2* __restrict__ 
         const uint2 q = hdr[i];
         out[i] = tonemap_pixel(q.x, q.y, p, e1, bgra);
     }
+}
+
+// Four pixels per thread -> 12 bytes (three dwords) of r g b r g b ...: the frame as a sharded rank composites it.
+__global__ __launch_bounds__(256) void tonemap_rgb8_kernel(const uint2* __restrict__ hdr, uint32_t* __restrict__ out, uint32_t n,
+                                                           const tr_tonemap_params p, int bgra) {
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (i >= n) return;
+    const float e1 = p.saturation / p.cross_saturation;
+    const uint4 a = *reinterpret_cast<const uint4*>(hdr + i), b = *reinterpret_cast<const uint4*>(hdr + i + 2u);
+    const uint32_t c0 = tonemap_pixel(a.x, a.y, p, e1, bgra) & 0xFFFFFFu, c1 = tonemap_pixel(a.z, a.w, p, e1, bgra) & 0xFFFFFFu;
+    const uint32_t c2 = tonemap_pixel(b.x, b.y, p, e1, bgra) & 0xFFFFFFu, c3 = tonemap_pixel(b.z, b.w, p, e1, bgra) & 0xFFFFFFu;
+    uint32_t* o = out + (i / 4u) * 3u;
+    o[0] = c0 | (c1 << 24);
+    o[1] = (c1 >> 8) | (c2 << 16);
+    o[2] = (c2 >> 16) | (c3 << 8);
 }
 
 // The frame recorder's tonemap: it knows, from the rasteriser's tile coverage words of both layers, which 64x4 block tiles

@@ -115,6 +115,8 @@ struct tr_context {
     bool counts_clean = false;                         // d_instance_counts is all zero (stream order): the fused frame path
     uint32_t num_cus = 256;
     uint32_t strip_rows = 0, strip_world = 1, strip_rank = 0;   // tr_set_strips: whole-frame shading calls take this rank's strips
+    uint32_t tap_row_lo = 0, tap_row_hi = 0;                    // tr_set_tap_window: the pyramid rows (levels 0, 1) this rank holds
+    uint32_t* tap_excess = nullptr;                             // ... and the device word the transmissive pass reports excursions in
     bool occupancy_fallback = false;     // the occupancy query failed: the grid was sized for 8 waves per SIMD
     bool mip_tail_attr_set = false;      // hipFuncSetAttribute(mip_tail_kernel, 160 KiB of LDS) done on this context's device
 
@@ -479,6 +481,8 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
         fp->strip_world = ctx->strip_world;
         fp->strip_rank = ctx->strip_rank;
     }
+    fp->tap_row_lo = ctx->tap_row_lo;
+    fp->tap_row_hi = ctx->tap_excess ? ctx->tap_row_hi : 0u;
     fp->tiles_x_magic = (uint32_t)(0x100000000ull / fp->tiles_x > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->tiles_x);
     fp->stripe_tiles = fp->tiles_x * kStripeTileRows;
     fp->stripe_magic = (uint32_t)(0x100000000ull / fp->stripe_tiles > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->stripe_tiles);
@@ -573,6 +577,7 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.tri_planes = L.vis ? ctx->planes_hint : nullptr;
     L.vis_front = L.vis ? ctx->vis_front_hint : nullptr;
     L.cover_front = L.vis ? ctx->cover_front_hint : nullptr;
+    L.tap_excess = ctx->tap_excess;
     L.slice_thr = ctx->d_slice_thr;
     L.cluster_x = ctx->d_cluster_x;
     L.cluster_y_term = ctx->d_cluster_y_term;
@@ -1452,6 +1457,8 @@ tr_status generate_mips_from(tr_context* ctx, const tr_pyramid* p, uint32_t firs
         ep.nlevels = n;
         ep.src_offset = p->level_offset[l - 1];
         for (uint32_t k = 0; k < n; ++k) ep.dst_offset[k] = p->level_offset[l + k];
+        ep.row_begin = 0u;
+        ep.row_end = hs >> 1;
         hipLaunchKernelGGL(mip_even_kernel, dim3(((ws >> 1) + 15u) / 16u, ((hs >> 1) + 15u) / 16u), dim3(256), 0, stream,
                            base, ep);
         l += n;
@@ -1490,6 +1497,51 @@ tr_status generate_mips_from(tr_context* ctx, const tr_pyramid* p, uint32_t firs
 extern "C" {
 
 tr_status tr_generate_mips(tr_context* ctx, const tr_pyramid* p, void* stream) { return generate_mips_from(ctx, p, 1u, stream); }
+
+tr_status tr_generate_mips_from(tr_context* ctx, const tr_pyramid* p, uint32_t first_level, void* stream) {
+    if (first_level == 0u) return TR_ERR_INVALID_ARGUMENT;
+    if (p && first_level >= p->levels) return TR_OK;
+    return generate_mips_from(ctx, p, first_level, stream);
+}
+
+tr_status tr_generate_mips_band(tr_context* ctx, const tr_pyramid* p, uint32_t y0, uint32_t y1, void* stream_) {
+    if (!ctx || !p || !p->texels || p->levels < 3u || p->levels > TR_MAX_MIP_LEVELS) return TR_ERR_INVALID_ARGUMENT;
+    // exact 2x2 boxes only: both sizes multiples of 4, the band on 4-row boundaries (its levels 1 and 2 then depend on
+    // nothing but its own rows of level 0)
+    if ((p->width & 3u) || (p->height & 3u) || (y0 & 3u) || y0 > y1 || y1 > p->height || ((y1 & 3u) && y1 != p->height))
+        return TR_ERR_UNSUPPORTED;
+    if (y0 == y1) return TR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    tr_mip_even_params ep;
+    std::memset(&ep, 0, sizeof(ep));
+    ep.w0 = p->width;
+    ep.h0 = p->height;
+    ep.nlevels = 2u;
+    ep.src_offset = p->level_offset[0];
+    ep.dst_offset[0] = p->level_offset[1];
+    ep.dst_offset[1] = p->level_offset[2];
+    ep.row_begin = y0 >> 1;
+    ep.row_end = y1 >> 1;
+    hipLaunchKernelGGL(mip_even_kernel, dim3(((p->width >> 1) + 15u) / 16u, ((ep.row_end - ep.row_begin) + 15u) / 16u), dim3(256), 0,
+                       stream, (uint2*)p->texels, ep);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_set_tap_window(tr_context* ctx, uint32_t row_lo, uint32_t row_hi, void* excess_word_dev) {
+    if (!ctx) return TR_ERR_INVALID_ARGUMENT;
+    if (!excess_word_dev || row_hi == 0u) {   // off
+        ctx->tap_row_lo = ctx->tap_row_hi = 0u;
+        ctx->tap_excess = nullptr;
+        return TR_OK;
+    }
+    if (row_lo >= row_hi || (row_lo & 1u) || ((uintptr_t)excess_word_dev & 3u)) return TR_ERR_INVALID_ARGUMENT;
+    ctx->tap_row_lo = row_lo;
+    ctx->tap_row_hi = row_hi;
+    ctx->tap_excess = (uint32_t*)excess_word_dev;
+    return TR_OK;
+}
 
 tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u,
                                 const tr_push_constants* pc, const tr_pyramid* p, void* hdr_inout, tr_format format,
@@ -1662,6 +1714,8 @@ struct rccl_api {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     bool ok = false;
@@ -1681,9 +1735,11 @@ const rccl_api& rccl() {
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
         a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
         a.Broadcast = (decltype(a.Broadcast))dlsym(a.handle, "ncclBroadcast");
+        a.Send = (decltype(a.Send))dlsym(a.handle, "ncclSend");
+        a.Recv = (decltype(a.Recv))dlsym(a.handle, "ncclRecv");
         a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
         a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
-        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.Broadcast && a.GroupStart && a.GroupEnd;
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.Broadcast && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
         return a;
     }();
     return api;
@@ -1769,14 +1825,60 @@ int32_t tr_comm_last_error(const tr_comm* comm) { return comm ? comm->last_error
 tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame, uint32_t width, uint32_t rows_per_rank,
                              tr_format format, void* stream_) {
     if (!ctx || !comm || !frame || width == 0 || rows_per_rank == 0) return TR_ERR_INVALID_ARGUMENT;
-    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F && format != TR_FORMAT_RGBA8) return TR_ERR_INVALID_ARGUMENT;
+    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F && format != TR_FORMAT_RGBA8 && format != TR_FORMAT_RGB8) return TR_ERR_INVALID_ARGUMENT;
     if (!rccl().ok) return TR_ERR_COMM;
     TR_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t band_bytes = (size_t)width * rows_per_rank * (format == TR_FORMAT_RGBA16F ? 8u : format == TR_FORMAT_RGBA32F ? 16u : 4u);
+    const size_t band_bytes = (size_t)width * rows_per_rank * (format == TR_FORMAT_RGBA16F ? 8u : format == TR_FORMAT_RGBA32F ? 16u : format == TR_FORMAT_RGB8 ? 3u : 4u);
     char* base = static_cast<char*>(frame);
     // in place: this rank's band already sits at its slot of the receive buffer
     const ncclResult_t r = rccl().AllGather(base + (size_t)comm->rank * band_bytes, base, band_bytes, ncclUint8, comm->comm,
                                             (hipStream_t)stream_);
+    if (r != ncclSuccess) {
+        comm->last_error = (int32_t)r;
+        return TR_ERR_COMM;
+    }
+    return TR_OK;
+}
+
+tr_status tr_halo_rows(uint32_t total_rows, uint32_t rows_per_rank, uint32_t nranks, uint32_t owner, uint32_t reader, uint32_t halo_rows,
+                       uint32_t* y0, uint32_t* y1) {
+    if (!y0 || !y1 || total_rows == 0 || rows_per_rank == 0 || nranks == 0 || owner >= nranks || reader >= nranks)
+        return TR_ERR_INVALID_ARGUMENT;
+    auto band = [&](uint32_t r, uint64_t& a, uint64_t& b) {
+        a = std::min<uint64_t>((uint64_t)r * rows_per_rank, total_rows);
+        b = std::min<uint64_t>((uint64_t)(r + 1u) * rows_per_rank, total_rows);
+    };
+    uint64_t oa, ob, ra, rb;
+    band(owner, oa, ob);
+    band(reader, ra, rb);
+    const uint64_t wa = ra > halo_rows ? ra - halo_rows : 0u, wb = std::min<uint64_t>(rb + halo_rows, total_rows);   // the reader's window
+    const uint64_t a = std::max(oa, wa), b = std::min(ob, wb);
+    *y0 = (uint32_t)(a < b ? a : 0u);
+    *y1 = (uint32_t)(a < b ? b : 0u);
+    if (ra == rb) *y0 = *y1 = 0u;   // (a reader without rows reads nothing)
+    return TR_OK;
+}
+
+tr_status tr_exchange_halo(tr_context* ctx, tr_comm* comm, void* level_rows, uint32_t row_bytes, uint32_t total_rows,
+                           uint32_t rows_per_rank, uint32_t halo_rows, void* stream_) {
+    if (!ctx || !comm || !level_rows || row_bytes == 0 || total_rows == 0 || rows_per_rank == 0) return TR_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return TR_ERR_COMM;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    char* base = static_cast<char*>(level_rows);
+    // every rank sends the rows of its band that lie in a peer's window and receives the rows of the peer's band that lie in
+    // its own, in place, as one group: the links carry band-border rows only (halo_rows >= the frame: an all-gather)
+    ncclResult_t r = rccl().GroupStart();
+    for (uint32_t peer = 0; r == ncclSuccess && peer < comm->nranks; ++peer) {
+        if (peer == comm->rank) continue;
+        uint32_t a = 0, b = 0;
+        tr_halo_rows(total_rows, rows_per_rank, comm->nranks, comm->rank, peer, halo_rows, &a, &b);    // mine, for the peer
+        if (b > a) r = rccl().Send(base + (size_t)a * row_bytes, (size_t)(b - a) * row_bytes, ncclUint8, (int)peer, comm->comm, (hipStream_t)stream_);
+        if (r != ncclSuccess) break;
+        tr_halo_rows(total_rows, rows_per_rank, comm->nranks, peer, comm->rank, halo_rows, &a, &b);    // the peer's, for me
+        if (b > a) r = rccl().Recv(base + (size_t)a * row_bytes, (size_t)(b - a) * row_bytes, ncclUint8, (int)peer, comm->comm, (hipStream_t)stream_);
+    }
+    const ncclResult_t e = rccl().GroupEnd();
+    if (r == ncclSuccess) r = e;
     if (r != ncclSuccess) {
         comm->last_error = (int32_t)r;
         return TR_ERR_COMM;
@@ -1811,10 +1913,10 @@ tr_status tr_strip_of_rank(uint32_t height, uint32_t strip_rows, uint32_t nranks
 tr_status tr_allgather_strips(tr_context* ctx, tr_comm* comm, void* frame, uint32_t width, uint32_t height, uint32_t strip_rows,
                               tr_format format, void* stream_) {
     if (!ctx || !comm || !frame || width == 0 || height == 0 || strip_rows == 0) return TR_ERR_INVALID_ARGUMENT;
-    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F && format != TR_FORMAT_RGBA8) return TR_ERR_INVALID_ARGUMENT;
+    if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F && format != TR_FORMAT_RGBA8 && format != TR_FORMAT_RGB8) return TR_ERR_INVALID_ARGUMENT;
     if (!rccl().ok) return TR_ERR_COMM;
     TR_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t row_bytes = (size_t)width * (format == TR_FORMAT_RGBA16F ? 8u : format == TR_FORMAT_RGBA32F ? 16u : 4u);
+    const size_t row_bytes = (size_t)width * (format == TR_FORMAT_RGBA16F ? 8u : format == TR_FORMAT_RGBA32F ? 16u : format == TR_FORMAT_RGB8 ? 3u : 4u);
     char* base = static_cast<char*>(frame);
     // every strip is broadcast in place from the rank that shaded it; one group: RCCL schedules the strips of all roots
     // together (each xGMI link carries the strips of one peer in each direction, like the band all-gather)
@@ -1907,6 +2009,19 @@ tr_status tr_tonemap(tr_context* ctx, const void* hdr, uint32_t width, uint32_t 
     if (((uintptr_t)hdr & 15u) || ((uintptr_t)out_rgba8 & 7u)) return TR_ERR_INVALID_ARGUMENT;   // 2 pixels per thread
     hipLaunchKernelGGL(tonemap_kernel, dim3((n + 511u) / 512u), dim3(256), 0, stream, (const uint2*)hdr,
                        (uint32_t*)out_rgba8, n, *params, (int)bgra);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_tonemap_rgb8(tr_context* ctx, const void* hdr, uint32_t width, uint32_t height, const tr_tonemap_params* params,
+                          void* out_rgb8, int32_t bgra, void* stream_) {
+    if (!ctx || !hdr || !params || !out_rgb8 || width == 0 || height == 0) return TR_ERR_INVALID_ARGUMENT;
+    const uint32_t n = width * height;
+    if ((n & 3u) || ((uintptr_t)hdr & 15u) || ((uintptr_t)out_rgb8 & 3u)) return TR_ERR_INVALID_ARGUMENT;   // 4 pixels per thread
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(tonemap_rgb8_kernel, dim3((n + 1023u) / 1024u), dim3(256), 0, stream, (const uint2*)hdr, (uint32_t*)out_rgb8, n,
+                       *params, (int)bgra);
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }

@@ -321,6 +321,32 @@ class TransmissionRenderer:
         """"opaque framebuffer mipchain" (src/main.rs:2046-2064)."""
         self._check(self.lib.tr_generate_mips(self._ctx, C.byref(pyramid.desc), self._stream()), "tr_generate_mips")
 
+    def generate_mips_from(self, pyramid: OpaquePyramid, first_level: int):
+        """Levels first_level.. from level first_level - 1 (tr_generate_mips_from)."""
+        self._check(self.lib.tr_generate_mips_from(self._ctx, C.byref(pyramid.desc), int(first_level), self._stream()),
+                    "tr_generate_mips_from")
+
+    def generate_mips_band(self, pyramid: OpaquePyramid, y0: int, y1: int):
+        """Levels 1 and 2 of the rows [y0, y1) of level 0: a rank's band of a sharded frame (tr_generate_mips_band)."""
+        self._check(self.lib.tr_generate_mips_band(self._ctx, C.byref(pyramid.desc), int(y0), int(y1), self._stream()),
+                    "tr_generate_mips_band")
+
+    def set_tap_window(self, row_lo: int = 0, row_hi: int = 0) -> None:
+        """The pyramid rows (levels 0, 1) this rank holds; (0, 0): off.  tap_window_excess() after the transmissive pass."""
+        if row_hi == 0:
+            self._check(self.lib.tr_set_tap_window(self._ctx, 0, 0, None), "tr_set_tap_window")
+            return
+        if "tap_excess" not in self._keep:
+            self._keep["tap_excess"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._keep["tap_excess"].zero_()
+        self._check(self.lib.tr_set_tap_window(self._ctx, int(row_lo), int(row_hi), self._keep["tap_excess"].data_ptr()),
+                    "tr_set_tap_window")
+
+    def tap_window_excess(self) -> int:
+        """0: every tap of the last transmissive pass lay inside the window; else 1 + the rows by which the worst one
+        missed it (synchronises)."""
+        return int(self._keep["tap_excess"].item()) if "tap_excess" in self._keep else 0
+
     def shade_transmission(self, g: GBufferPlanes, uniforms: wire.Uniforms, push: wire.PushConstants,
                            pyramid: OpaquePyramid, hdr: torch.Tensor, rect=None):
         """"opaque transmissive objects": `fragment_transmission` (shader/src/lib.rs:37-162) over hdr (LOAD)."""
@@ -356,6 +382,20 @@ class TransmissionRenderer:
         assert out.dtype == torch.uint8 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (h, w, 4)
         self._check(self.lib.tr_tonemap(self._ctx, hdr.data_ptr(), w, h, C.byref(params), out.data_ptr(), int(bgra),
                                         self._stream()), "tr_tonemap")
+        return out
+
+    def tonemap_rgb8(self, hdr: torch.Tensor, params: Optional[wire.TonemapParams] = None, bgra: bool = False,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same pixels as tonemap() without the constant alpha byte: (H, W, 3) uint8 (tr_tonemap_rgb8) — what a
+        row-band sharded frame composites."""
+        assert hdr.dtype == torch.float16 and hdr.is_cuda and hdr.is_contiguous() and hdr.shape[-1] == 4
+        h, w = int(hdr.shape[0]), int(hdr.shape[1])
+        params = params or self.baked_tonemap_params()
+        if out is None:
+            out = torch.empty((h, w, 3), dtype=torch.uint8, device=self.device)
+        assert out.dtype == torch.uint8 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (h, w, 3)
+        self._check(self.lib.tr_tonemap_rgb8(self._ctx, hdr.data_ptr(), w, h, C.byref(params), out.data_ptr(), int(bgra),
+                                             self._stream()), "tr_tonemap_rgb8")
         return out
 
     def record_frame(self, uniforms: wire.Uniforms, push: wire.PushConstants, culling: wire.CullingPushConstants,

@@ -9,6 +9,14 @@ is needed while shading.  Two exchanges exist, both in-place all-gathers of whol
   * level 0 of the opaque pyramid between the two passes (the transmissive pass samples the *whole*
     pyramid at refracted coordinates; the 10.67 B/px chain is then built redundantly per rank).
 
+The level-0 exchange need not be a gather of everything (round 4): a pixel's refraction taps land a bounded number of
+rows from the pixel, and only taps of levels 0 and 1 need fine rows at all.  `record_sharded(exchange="halo")`: every rank
+builds levels 1 and 2 of its own band (tr_generate_mips_band: exact 2x2 boxes that never leave the band), exchanges
+`halo` border rows of levels 0 and 1 with the ranks that own them (tr_exchange_halo: ncclSend / ncclRecv), all-gathers
+level 2 (1/16 of level 0's bytes) and builds levels 3.. from it.  The transmissive pass checks every tap of levels 0 / 1
+against the rows the rank holds (tr_set_tap_window) and reports the largest excursion; when there is one the frame is
+redone with the full gather and the compositor's halo grows to what was needed (bytes per link: DESIGN.md 4).
+
 Band arithmetic is the library's (`tr_band_rows`, include/tr_shade.h): bands of ceil(H / N) rows rounded up to the
 4-row wave tile, the last ones clipped to the frame; buffers that are gathered hold N * rows_per_rank rows (>= H).
 On a GPU the gathers go through `tr_allgather_frame` — the library's own RCCL communicator, the entry point a
@@ -38,6 +46,15 @@ def band_rows(height: int, world: int, rank: int) -> Tuple[int, int, int]:
 def band_rect(width: int, height: int, world: int, rank: int) -> Tuple[int, int, int, int]:
     _, y0, y1 = band_rows(height, world, rank)
     return 0, y0, width, y1
+
+
+def halo_rows_between(total_rows: int, rows_per_rank: int, world: int, owner: int, reader: int, halo: int) -> Tuple[int, int]:
+    """Rows [y0, y1) of `owner`'s band of a level that `reader` receives in a halo exchange (tr_halo_rows)."""
+    y0, y1 = C.c_uint32(), C.c_uint32()
+    st = _lib.load().tr_halo_rows(int(total_rows), int(rows_per_rank), int(world), int(owner), int(reader), int(halo), C.byref(y0), C.byref(y1))
+    if st != 0:
+        raise ValueError(f"tr_halo_rows: status {st}")
+    return y0.value, y1.value
 
 
 def padded_rows(height: int, world: int) -> int:
@@ -100,6 +117,50 @@ class Compositor:
             self.renderer.lib.tr_comm_destroy(self._comm)
             self._comm = C.c_void_p()
 
+    # ---- the halo exchange of the sharded full pipeline
+    halo_rows = 0          # level-0 rows exchanged on either side of a band (0: not chosen yet -> the first frame gathers)
+    halo_fallbacks = 0     # frames that had to be redone with the full gather
+    halo_margin = 1.25     # growth factor over the largest excursion seen
+
+    def exchange_halo(self, level_rows: torch.Tensor, rows_per_rank: int, halo: int) -> None:
+        """level_rows: (total_rows, W, C) contiguous, a whole pyramid level of which this rank has written its band; on
+        return it also holds `halo` rows on either side, received from their owners."""
+        if self.world == 1:
+            return
+        total = int(level_rows.shape[0])
+        row_bytes = int(level_rows.shape[1]) * int(level_rows.shape[2]) * level_rows.element_size()
+        if self._comm.value:
+            st = self.renderer.lib.tr_exchange_halo(self.renderer._ctx, self._comm, level_rows.data_ptr(), row_bytes, total,
+                                                    int(rows_per_rank), int(halo), torch.cuda.current_stream().cuda_stream)
+            if st != 0:
+                raise _lib.TrError(st, "tr_exchange_halo", self.renderer.lib.tr_comm_last_error(self._comm))
+            return
+        ops, keep = [], []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            a, b = halo_rows_between(total, rows_per_rank, self.world, self.rank, peer, halo)     # mine, for the peer
+            if b > a:
+                keep.append(level_rows[a:b].clone())
+                ops.append(dist.P2POp(dist.isend, keep[-1], peer, group=self.group))
+            a, b = halo_rows_between(total, rows_per_rank, self.world, peer, self.rank, halo)     # the peer's, for me
+            if b > a:
+                ops.append(dist.P2POp(dist.irecv, level_rows[a:b], peer, group=self.group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+
+    def allgather_bands(self, level_rows: torch.Tensor, rows_per_rank: int) -> None:
+        """In-place all-gather of a level whose bands are clipped to it (no padding rows behind it)."""
+        self.exchange_halo(level_rows, rows_per_rank, int(level_rows.shape[0]))
+
+    def max_over_ranks(self, value: int) -> int:
+        if self.world == 1:
+            return int(value)
+        on_host = dist.get_backend(self.group) == "gloo"
+        t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if on_host else self.renderer.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
     def allgather_rows(self, frame: torch.Tensor) -> None:
         """frame: (rows_per_rank * world, W, C) contiguous; every rank has written its own band."""
         if self.world == 1 and not self._comm.value:
@@ -108,7 +169,10 @@ class Compositor:
         rows = frame.shape[0] // self.world
         if self._comm.value:
             fmt = {torch.float16: wire.FORMAT_RGBA16F, torch.float32: wire.FORMAT_RGBA32F, torch.uint8: wire.FORMAT_RGBA8}[frame.dtype]
-            assert frame.shape[2] == 4
+            if frame.dtype == torch.uint8 and frame.shape[2] == 3:
+                fmt = wire.FORMAT_RGB8           # (the presented frame without its constant alpha: tonemap_rgb8)
+            else:
+                assert frame.shape[2] == 4
             st = self.renderer.lib.tr_allgather_frame(self.renderer._ctx, self._comm, frame.data_ptr(), int(frame.shape[1]),
                                                       rows, fmt, torch.cuda.current_stream().cuda_stream)
             if st != 0:
@@ -172,22 +236,56 @@ def record_sharded_strips(renderer, opaque, transmissive, uniforms, push, hdr, p
 
 
 def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid, compositor: Compositor,
-                   composite: bool = True) -> None:
+                   composite: bool = True, exchange: str = "allgather") -> None:
     """The hot-path slice of `record()` (src/main.rs:1969-2124) for one rank of a row-band sharded frame.
 
     `opaque` / `transmissive` are this rank's G-buffer tiles (origin_y = its first row); `hdr` holds
     padded_rows(H, world) rows and `pyramid` was made with level0_rows = the same.  Order:
-    opaque band -> all-gather level 0 -> mip chain (replicated) -> transmissive band -> composite.
+    opaque band -> exchange of the opaque colour -> mip chain -> transmissive band -> composite.
+    exchange = "allgather": all of level 0 to every rank, the chain replicated (round 3);
+    exchange = "halo": border rows of levels 0 / 1 + all of level 2 (see the module docstring); needs frame sizes that are
+    multiples of 4 (else it gathers) and falls back to the gather for a frame whose taps left the halo.
     """
     world, rank = compositor.world, compositor.rank
     fw, fh = int(push.framebuffer_size[0]), int(push.framebuffer_size[1])
     rect = band_rect(fw, fh, world, rank)
-    if rect[3] > rect[1]:       # (a band can be empty when the height is far from a multiple of world * 4)
+    rows = band_rows(fh, world, rank)[0]
+    mine = rect[3] > rect[1]     # (a band can be empty when the height is far from a multiple of world * 4)
+    if mine:
         renderer.shade_opaque(opaque, uniforms, push, hdr, pyramid, rect)
+    halo = compositor.halo_rows
+    use_halo = (world > 1 and exchange == "halo" and fw % 4 == 0 and fh % 4 == 0 and pyramid.levels >= 4
+                and 0 < halo and halo + rows < fh)     # (a halo that reaches every row is the gather)
+    if use_halo:
+        halo = min(-(-halo // 4) * 4, fh)
+        renderer.generate_mips_band(pyramid, rect[1], rect[3])                       # levels 1, 2 of the band
+        compositor.exchange_halo(pyramid.level(0), rows, halo)
+        compositor.exchange_halo(pyramid.level(1), rows // 2, halo // 2)
+        compositor.allgather_bands(pyramid.level(2), rows // 4)
+        renderer.generate_mips_from(pyramid, 3)
+        if mine:
+            renderer.set_tap_window(max(rect[1] - halo, 0), min(rect[3] + halo, fh))
+            try:
+                renderer.shade_transmission(transmissive, uniforms, push, pyramid, hdr, rect)
+            finally:
+                excess = renderer.tap_window_excess()
+                renderer.set_tap_window(0, 0)
+        else:
+            excess = 0
+        excess = compositor.max_over_ranks(excess)
+        if excess == 0:
+            if composite:
+                compositor.allgather_rows(hdr)
+            return
+        # a tap left the halo: this frame is redone with the full gather, the next ones exchange what was needed
+        compositor.halo_fallbacks += 1
+        compositor.halo_rows = int((halo + excess) * compositor.halo_margin) + 4
+    elif world > 1 and exchange == "halo" and halo == 0:
+        compositor.halo_rows = max(rows // 4, 4)         # (first frame: gather, then start from a quarter band)
     if world > 1:
         compositor.allgather_rows(pyramid.level0_padded())
     renderer.generate_mips(pyramid)
-    if rect[3] > rect[1]:
+    if mine:
         renderer.shade_transmission(transmissive, uniforms, push, pyramid, hdr, rect)
     if world > 1 and composite:
         compositor.allgather_rows(hdr)

@@ -27,6 +27,7 @@ NOT_COVERED = 0xFFFFFFFF
 FORMAT_RGBA16F = 0
 FORMAT_RGBA32F = 1
 FORMAT_RGBA8 = 2        # tr_allgather_frame only
+FORMAT_RGB8 = 3         # ... without the constant alpha (tr_tonemap_rgb8's output)
 MAX_MIP_LEVELS = 16
 
 
