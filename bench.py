@@ -335,13 +335,14 @@ def measure_pmc(args):
     out = {ph: {} for ph in PROBE_PHASES}
     tmp = tempfile.mkdtemp(prefix="tr_pmc_", dir="/tmp")
     try:
-        for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]):
+        for counters in (["FETCH_SIZE"], ["WRITE_SIZE"],
+                         ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "SQ_WAIT_ANY"]):
             d = os.path.join(tmp, counters[0])
             cmd = [rocprof, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-probe", "--width", str(args.width), "--height", str(args.height),
                    "--lights", str(args.lights)]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
             if r.returncode != 0:
                 return None
             rows = []
@@ -490,14 +491,27 @@ def valu_roofline(counters, pixels, ms):
         return None
     lane_ops = counters["SQ_INSTS_VALU"] * 64.0
     achieved = lane_ops / (ms * 1e-3)
-    return {"bound": "valu", "lane_ops_per_pixel": round(lane_ops / pixels, 1), "achieved": round(achieved / 1e12, 2),
-            "peak": round(VALU_PEAK_LANEOPS / 1e12, 2), "unit": "T lane-ops/s", "frac": round(achieved / VALU_PEAK_LANEOPS, 4),
-            "vector_instructions_per_launch": int(counters["SQ_INSTS_VALU"]),
-            "scalar_instructions_per_launch": int(counters.get("SQ_INSTS_SALU", 0)),
+    out = {"bound": "valu", "lane_ops_per_pixel": round(lane_ops / pixels, 1), "achieved": round(achieved / 1e12, 2),
+           "peak": round(VALU_PEAK_LANEOPS / 1e12, 2), "unit": "T lane-ops/s", "frac": round(achieved / VALU_PEAK_LANEOPS, 4),
+           "vector_instructions_per_launch": int(counters["SQ_INSTS_VALU"]),
+           "scalar_instructions_per_launch": int(counters.get("SQ_INSTS_SALU", 0))}
+    if all(k in counters for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES")):
+        # SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles summed over the waves; SQ_BUSY_CYCLES cycles summed over the 32
+        # shader engines.  The vector unit's first issue port is occupied by every instruction that is not the second half
+        # of a dual-issued pair.
+        busy = counters["SQ_BUSY_CYCLES"] / 32.0
+        out["issue_port_busy"] = round((counters["SQ_ACTIVE_INST_VALU"] - counters["SQ_ACTIVE_INST_VALU2"]) * 4.0 / 1024.0 / busy, 3)
+        out["dual_issued_share"] = round(counters["SQ_ACTIVE_INST_VALU2"] / counters["SQ_INSTS_VALU"], 3)
+        out["waves_per_simd"] = round(counters["SQ_WAVE_CYCLES"] * 4.0 / 1024.0 / busy, 2)
+        if "SQ_WAIT_ANY" in counters:
+            out["wave_time_in_s_waitcnt"] = round(counters["SQ_WAIT_ANY"] / counters["SQ_WAVE_CYCLES"], 3)
+    return dict(out, **{
             "note": "SQ_INSTS_VALU x 64 lanes / step time; peak = dual-issued VGPR-operand fp32 ops, 1.12 G wave64 "
                     "instructions/s/SIMD x 64 x 1024 SIMDs (tools/ubench/valu_rate.hip, profiles/r01/f_valu_issue_rates.txt); "
                     "an SGPR source, a conversion / compare (4.0-4.1 cycles) or a transcendental (8.1) issues slower, so the "
-                    "kernel's instruction mix cannot reach 1.0"}
+                    "kernel's instruction mix cannot reach 1.0.  issue_port_busy: the fraction of the launch's cycles in which a "
+                    "SIMD's vector issue port was occupied ((SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) x 4 / 1024 SIMDs / (SQ_BUSY_CYCLES "
+                    "/ 32)) — how close the launch (as profiled: one whole-frame launch per frame) is to the vector unit's roof"})
 
 
 def measure_config(name, device_index, width, height, K, W, lights=1, roughness=None, all_transmissive=False, with_record=False):

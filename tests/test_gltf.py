@@ -170,3 +170,103 @@ def test_jpeg_palette_and_grey_images(tmp_path):
     scene = gltf.load_gltf(path)
     assert scene.materials[0].textures.diffuse == 0 and scene.textures[0][1] is True
     np.testing.assert_array_equal(scene.textures[0][0][..., :3], want)
+
+
+def test_hand_written_adversarial_gltf(tmp_path):
+    """A .gltf written by hand, none of it through this repo's write_gltf: interleaved vertex data (byteStride), UNSIGNED_BYTE
+    indices, a `matrix` node under a TRS parent, a KHR_texture_transform whose offset and rotation must be IGNORED (the
+    reference multiplies uv by the scale only, src/model_loading.rs:85-92), a normalised UNSIGNED_SHORT uv set, a sparse
+    POSITION accessor (read like the gltf crate's iterators do), and a second primitive without TEXCOORD_0."""
+    import base64
+    import json
+    f32 = np.float32
+    # four vertices, position + normal interleaved (stride 24) — a unit quad in the xy plane, normals +z
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], f32)
+    nrm = np.tile(np.array([[0, 0, 1]], f32), (4, 1))
+    inter = np.concatenate([pos, nrm], axis=1).astype("<f4").tobytes()                    # 96 bytes
+    uv16 = np.array([[0, 0], [65535, 0], [65535, 65535], [0, 65535]], "<u2").tobytes()     # 16 bytes, normalised
+    idx8 = np.array([0, 1, 2, 0, 2, 3], np.uint8).tobytes() + b"\0\0"                      # 6 bytes (+ 2 padding)
+    sparse_idx = np.array([1, 2], "<u2").tobytes()                                         # 4 bytes: vertices 1 and 2 move
+    sparse_val = np.array([[2, 0, 0.5], [2, 1, 0.5]], "<f4").tobytes()                     # 24 bytes
+    blob = inter + uv16 + idx8 + sparse_idx + sparse_val
+    views = [
+        {"buffer": 0, "byteOffset": 0, "byteLength": 96, "byteStride": 24},       # 0 interleaved position | normal
+        {"buffer": 0, "byteOffset": 96, "byteLength": 16},                         # 1 uv (u16 normalised)
+        {"buffer": 0, "byteOffset": 112, "byteLength": 6},                         # 2 indices (u8)
+        {"buffer": 0, "byteOffset": 120, "byteLength": 4},                         # 3 sparse indices
+        {"buffer": 0, "byteOffset": 124, "byteLength": 24},                        # 4 sparse values
+    ]
+    accessors = [
+        {"bufferView": 0, "byteOffset": 0, "componentType": 5126, "count": 4, "type": "VEC3", "min": [0, 0, 0], "max": [2, 1, 0.5],
+         "sparse": {"count": 2, "indices": {"bufferView": 3, "componentType": 5123}, "values": {"bufferView": 4}}},
+        {"bufferView": 0, "byteOffset": 12, "componentType": 5126, "count": 4, "type": "VEC3"},
+        {"bufferView": 1, "componentType": 5123, "normalized": True, "count": 4, "type": "VEC2"},
+        {"bufferView": 2, "componentType": 5121, "count": 6, "type": "SCALAR"},
+        {"bufferView": 0, "byteOffset": 0, "componentType": 5126, "count": 4, "type": "VEC3"},      # the dense positions
+    ]
+    half = [0.5, 0, 0, 0,  0, 0.5, 0, 0,  0, 0, 0.5, 0,  3, 4, 5, 1]                               # column-major: scale 0.5, then translate
+    doc = {
+        "asset": {"version": "2.0"},
+        "extensionsUsed": ["KHR_texture_transform", "KHR_materials_transmission", "KHR_materials_volume", "KHR_materials_ior"],
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+        "bufferViews": views, "accessors": accessors,
+        "images": [{"uri": "data:image/png;base64," + base64.b64encode(_png_2x2()).decode()}],
+        "textures": [{"source": 0}],
+        "materials": [
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": 0, "extensions": {"KHR_texture_transform": {
+                "offset": [0.25, 0.75], "rotation": 1.0, "scale": [2.0, 3.0]}}}, "metallicFactor": 0.0}},
+            {"alphaMode": "MASK", "alphaCutoff": 0.3,
+             "extensions": {"KHR_materials_transmission": {"transmissionFactor": 0.75}, "KHR_materials_ior": {"ior": 1.33},
+                            "KHR_materials_volume": {"thicknessFactor": 0.2, "attenuationDistance": 4.0, "attenuationColor": [0.9, 0.8, 0.7]}}},
+        ],
+        "meshes": [{"primitives": [
+            {"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0},
+            {"attributes": {"POSITION": 4, "NORMAL": 1}, "indices": 3, "material": 1}]}],
+        "nodes": [{"translation": [10, 0, 0], "scale": [2, 2, 2], "children": [1]}, {"matrix": half, "mesh": 0}],
+        "scenes": [{"nodes": [0]}], "scene": 0,
+    }
+    path = str(tmp_path / "adversarial.gltf")
+    json.dump(doc, open(path, "w"))
+    sc = gltf.load_gltf(path, base_transform=gltf.Similarity(np.array([0, 2, 0], f32), 1.5))
+    geo = sc.geometry()
+    # vertices: primitive 0 with the sparse substitution applied, primitive 1 the dense ones (no uv: zeros)
+    want0 = pos.copy()
+    want0[1], want0[2] = [2, 0, 0.5], [2, 1, 0.5]
+    np.testing.assert_array_equal(geo["position"][:4], want0)
+    np.testing.assert_array_equal(geo["position"][4:8], pos)
+    np.testing.assert_array_equal(geo["normal"][:8], np.tile(nrm, (2, 1)))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], f32) * np.array([2.0, 3.0], f32)           # the scale only: no offset, no rotation
+    np.testing.assert_array_equal(geo["uv"][:4], uv)
+    np.testing.assert_array_equal(geo["uv"][4:8], np.zeros((4, 2), f32))
+    assert geo["index"].dtype == np.uint32
+    np.testing.assert_array_equal(geo["index"][:6], [0, 1, 2, 0, 2, 3])
+    # draw buffers: opaque textured -> 0, MASK + transmission -> 3
+    assert list(geo["primitives"]["draw_buffer_index"]) == [0, 3] and sc.max_draw_counts == [1, 0, 0, 1]
+    # transform: base (t = (0,2,0), s = 1.5) * parent (t = (10,0,0), s = 2) * matrix node (s = 0.5, t = (3,4,5))
+    inst = geo["instances"][0]
+    assert abs(float(inst["translation_and_scale"][3]) - 1.5) < 1e-6
+    np.testing.assert_allclose(inst["translation_and_scale"][:3], [0 + 1.5 * (10 + 2 * 3), 2 + 1.5 * (2 * 4), 1.5 * (2 * 5)], rtol=1e-6)
+    np.testing.assert_allclose(inst["rotation"], [0, 0, 0, 1], atol=1e-7)
+    # materials: the extensions' factors, attenuation distance pre-multiplied by the base scale (src/model_loading.rs:317)
+    m = sc.materials[1]
+    assert abs(m.index_of_refraction - 1.33) < 1e-6 and abs(m.transmission_factor - 0.75) < 1e-6 and abs(m.alpha_clipping_cutoff - 0.3) < 1e-6
+    assert abs(m.thickness_factor - 0.2) < 1e-6 and abs(m.attenuation_distance - 4.0 * 1.5) < 1e-5
+    assert sc.materials[0].textures.diffuse == 0 and sc.textures[0][1] is True and sc.textures[0][0].shape == (2, 2, 4)
+    # a sparse accessor whose indices are not increasing is refused
+    doc["accessors"][0]["sparse"]["indices"]["bufferView"] = 3
+    bad = np.array([2, 1], "<u2").tobytes()
+    blob2 = blob[:120] + bad + blob[124:]
+    doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob2).decode()
+    json.dump(doc, open(path, "w"))
+    with pytest.raises(gltf.GltfError):
+        gltf.load_gltf(path)
+
+
+def _png_2x2() -> bytes:
+    import struct
+    import zlib
+    rows = b"".join(b"\0" + bytes([r, g, 0, 255, g, r, 0, 255]) for r, g in ((255, 0), (0, 255)))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 2, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(rows)) + chunk(b"IEND", b"")

@@ -110,6 +110,10 @@ def _check_against_oracles(got32, got16, o32, o64, o16_64, what, o16_32=None, t3
     print(f"[parity] {what}: P0 {p0.max():.2e}  P1 rmse(gpu, oracle32) {p1:.2e} outside {int(ill.sum())} ill-conditioned "
           f"pixels of {ill.size} ({p1_all:.2e} over all)  rmse(oracle32, oracle64) {noise:.2e}")
     assert p1 <= 1e-4, (what, "P1 RMSE vs oracle32", p1, "ill-conditioned pixels excluded:", int(ill.sum()))
+    # ... and over ALL pixels, nothing excluded: the kernels may be no further from the pinned fp32 oracle than 1e-4 plus twice
+    # that oracle's own distance from the fp64 evaluation of the same formulas (on an ill-conditioned pixel neither fp32
+    # evaluation is right, and they are wrong independently)
+    assert p1_all <= 1e-4 + 2.0 * noise, (what, "P1 over all pixels", p1_all, "oracle32's own fp32 noise", noise)
     e64 = _norm_err(got32, o64)
     assert _rmse(e64).max() <= 1e-4, (what, "T1", _rmse(e64))
     assert np.abs(e64).max() <= 5e-3, (what, "T1 max", np.abs(e64).max())

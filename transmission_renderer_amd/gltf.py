@@ -85,15 +85,30 @@ class Document:
     def accessor(self, index: int) -> np.ndarray:
         """(count, components) array in the accessor's component type (no normalisation applied)."""
         a = self.json["accessors"][index]
-        if "sparse" in a:
-            raise GltfError("sparse accessors are not supported")
         dt = np.dtype(_COMPONENT[a["componentType"]]).newbyteorder("<")
         n = _NUM[a["type"]]
         count = a["count"]
         if "bufferView" not in a:
-            return np.zeros((count, n), dtype=dt)
-        data, stride = self.view_bytes(a["bufferView"])
-        off = a.get("byteOffset", 0)
+            dense = np.zeros((count, n), dtype=dt)
+        else:
+            dense = self._strided(a["bufferView"], a.get("byteOffset", 0), dt, n, count)
+        if "sparse" not in a:
+            return dense
+        # glTF 2.0 5.1.3: `sparse.count` elements of the (dense or all-zero) array are replaced; the gltf crate's
+        # accessor iterators (which the reference reads every attribute through, src/model_loading.rs:29, 96-137) apply it
+        sp = a["sparse"]
+        k = int(sp["count"])
+        idt = np.dtype(_COMPONENT[sp["indices"]["componentType"]]).newbyteorder("<")
+        where = self._strided(sp["indices"]["bufferView"], sp["indices"].get("byteOffset", 0), idt, 1, k).reshape(-1).astype(np.int64)
+        values = self._strided(sp["values"]["bufferView"], sp["values"].get("byteOffset", 0), dt, n, k)
+        if k and (where.min() < 0 or where.max() >= count or np.any(np.diff(where) <= 0)):
+            raise GltfError(f"accessor {index}: sparse indices must be strictly increasing and inside the accessor")
+        out = np.array(dense, copy=True)
+        out[where] = values
+        return out
+
+    def _strided(self, view: int, off: int, dt: np.dtype, n: int, count: int) -> np.ndarray:
+        data, stride = self.view_bytes(view)
         elem = dt.itemsize * n
         if stride in (0, elem):
             return np.frombuffer(data, dtype=dt, count=count * n, offset=off).reshape(count, n)
