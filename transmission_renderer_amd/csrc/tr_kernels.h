@@ -49,35 +49,25 @@
 #include "tr_texture_kernels.h"
 #include "tr_visibility.h"
 
-namespace tr {
-
-// Profiling builds (-DTR_ABLATION=1) honour fp.ablate (TR_ABLATE env) to switch phases off; in the product
-// build the switches do not exist: a branch around a load makes the s_waitcnt counters imprecise.
-#ifndef TR_ABLATION
+// Measurement hooks.  The product build defines every one of them away; profiling builds (tools/build_variant.py NAME
+// -DTR_ABLATION=1 / -DTR_TIMING=1 / -DTR_PROBE_MASK=n — never the product library, __graft_entry__.compile_library refuses)
+// get them from tr_probe.h: phases that can be switched off (TR_ABLATE) and per-wave wait-cycle counters (TR_PROBE_*).
+#if defined(TR_ABLATION) || defined(TR_TIMING) || defined(TR_PROBE_MASK)
+#include "tr_probe.h"
+#else
 #define TR_ABLATION 0
+#define TR_ABLATE(L, bit) false
+#define TR_PROBE_ARGS_DECL
+#define TR_PROBE_ARGS
+#define TR_PROBE_WAVE_BEGIN
+#define TR_PROBE_SINCE(name)
+#define TR_PROBE_DRAIN
+#define TR_PROBE_WAITED(slot, name)
+#define TR_PROBE_TILE_DONE
+#define TR_PROBE_WAVE_END
 #endif
-#ifdef TR_PROBE_MASK   // register-pressure probes (tools/kernel_stats.py -DTR_PROBE_MASK=n): a phase compiled out
-#define TR_ABLATE(L, bit) (((TR_PROBE_MASK) & (bit)) != 0)
-#else
-#define TR_ABLATE(L, bit) (TR_ABLATION && ((L)->fp.ablate & (bit)))
-#endif
-// Profiling builds (-DTR_TIMING=1, tools/ab_kernel.py): every wave adds the cycles it spent waiting for (0) the G-buffer
-// planes, (1) the cluster lists, (2) the refraction taps + LUT, and (3) its total loop time, (4) tiles, into
-// tr_timing_counters (read back with tr_debug_read_timing).  The waits are forced at the measuring points.
-#ifndef TR_TIMING
-#define TR_TIMING 0
-#endif
-#if TR_TIMING
-__device__ unsigned long long tr_timing_counters[8][1024];   // spread over 1024 slots: same-address atomics serialise
-__device__ __forceinline__ unsigned long long tr_now() { return __builtin_amdgcn_s_memtime(); }
-__device__ __forceinline__ void tr_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-struct tr_timer { unsigned long long wait[3]; };
-#define TR_TIMER_PARAM , tr_timer& timer
-#define TR_TIMER_ARG , timer
-#else
-#define TR_TIMER_PARAM
-#define TR_TIMER_ARG
-#endif
+
+namespace tr {
 
 // Issue priority rises through the phases of a tile: among the waves of a SIMD the one nearest to the end of its tile
 // wins the arbitration, finishes, and has its next tile's loads in flight while the others compute — without it the
@@ -214,8 +204,7 @@ struct tr_frame_params {
     uint32_t pyr_levels;
     uint32_t solo_full;          // TEX = 2 launch only: every uploaded material is of the full class, there is no TEX = 1
                                  // launch beside this one: it sweeps the whole rect and writes the clear colour itself
-    uint32_t ablate;             // profiling only (TR_ABLATE env): bit0 no pyramid taps, bit1 no LUT, bit2 no sun,
-                                 // bit3 no punctual lights, bit4 no refraction math
+    uint32_t ablate;             // profiling builds only (tr_probe.h): which phases are switched off; 0 in the product
 };
 
 typedef const TR_CONSTANT tr_dmat cdmat;
@@ -942,7 +931,7 @@ __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, 
 // normal mapping.
 template <bool TRANSMISSIVE, class MatP>
 __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index, float4 pd, float4 ns, uint32_t lane,
-                                          const cluster_list& cl TR_TIMER_PARAM) {
+                                          const cluster_list& cl TR_PROBE_ARGS_DECL) {
     // (roughness, ior and the LUT line are the table's: one level pair and one LUT line per wave)
     constexpr bool SCALAR_MATERIAL = std::is_same<MatP, cdmat*>::value || std::is_same<MatP, const lite_dmat*>::value;
     // ================= phase 1: frame of the pixel, cluster list request, refraction taps =================
@@ -1141,15 +1130,10 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
     // 129 -> 122 us on the 4K frame, profiles/r01).
     auto tail = [&]() -> f3 {
         tile_phase<2>();
-#if TR_TIMING
-        tr_drain();
-        const unsigned long long t_taps = tr_now();
-#endif
+        TR_PROBE_DRAIN
+        TR_PROBE_SINCE(t_taps)
         issue_taps();
-#if TR_TIMING
-        tr_drain();
-        timer.wait[2] += tr_now() - t_taps;
-#endif
+        TR_PROBE_WAITED(2, t_taps)
         tile_phase<3>();
         return finish();
     };
@@ -1174,7 +1158,7 @@ template <bool TRANSMISSIVE, uint32_t SLOTS /* the slots a material of this laun
 __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material, cdmat* dm, float4 pd, float4 ns,
                                                    float2 uv, const quad_derivs& qd, uint32_t lane,
                                                    const cluster_list& cl_in, const float* __restrict__ lds_srgb,
-                                                   float* lds_park TR_TIMER_PARAM) {
+                                                   float* lds_park TR_PROBE_ARGS_DECL) {
     L = launder(L);
     dm = launder(dm);
     // What the sampling front end does not read — the position, the pixel's cluster list — and what it
@@ -1344,7 +1328,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     cluster_list cl = cl_in;   // (the scalar members stay what they are)
     cl.cluster = __float_as_uint(get(4));
     cl.key = __float_as_uint(get(5));
-    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, material, pd2, ns, lane, cl TR_TIMER_ARG);
+    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, material, pd2, ns, lane, cl TR_PROBE_ARGS);
 }
 
 // ------------------------------------------------------------------------ one pixel of a "lite" textured material
@@ -1353,7 +1337,7 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
 template <bool TRANSMISSIVE>
 __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cdmat* dm, float4 pd, float4 ns, float2 uv,
                                                const uv_derivs& duv, uint32_t lane, const cluster_list& cl,
-                                               const float* __restrict__ lds_srgb TR_TIMER_PARAM) {
+                                               const float* __restrict__ lds_srgb TR_PROBE_ARGS_DECL) {
     L = launder(L);
     const TR_CONSTANT tr_material_info* mi = as_constant(L->materials) + material;
     cdtex* t = as_constant(L->textures) + mi->textures.diffuse;
@@ -1377,7 +1361,7 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
     // The colour is first USED at the end of the pixel; left to itself the optimiser sinks the whole filter down there
     // and keeps the eight taps, their weights and the decode look-ups alive across the light loop (+40 registers).
     asm volatile("" : "+v"(lm.diffuse[0]), "+v"(lm.diffuse[1]), "+v"(lm.diffuse[2]));
-    return shade_pixel<TRANSMISSIVE, const lite_dmat*>(L, &lm, material, pd, ns, lane, cl TR_TIMER_ARG);
+    return shade_pixel<TRANSMISSIVE, const lite_dmat*>(L, &lm, material, pd, ns, lane, cl TR_PROBE_ARGS);
 }
 
 // ------------------------------------------------------------------------ the shading kernel
@@ -1602,12 +1586,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
     };
 
-#if TR_TIMING
-    tr_timer timer = {{0ull, 0ull, 0ull}};
-    unsigned long long tiles_done = 0;
-    const unsigned long long t_loop = tr_now();
-    const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
-#endif
+    TR_PROBE_WAVE_BEGIN
     // Which tile next: static — the wave in slot w of its XCD takes the 16x4 tiles w, w + W, w + 2W, ... of the band
     // (W = waves of the XCD in the grid; four neighbouring waves cover one 64x4 block tile side by side, so their plane
     // rows are 1 KB contiguous and their stores 512 B).  Handing tiles out dynamically balances the waves (static: the
@@ -1619,12 +1598,9 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     while (j < wave_tiles) {
         tile_phase<0>();
         fetch(j, cur);
-#if TR_TIMING
-        const unsigned long long t_fetch = tr_now();
-        tr_drain();
-        timer.wait[0] += tr_now() - t_fetch;
-        ++tiles_done;
-#endif
+        TR_PROBE_SINCE(t_fetch)
+        TR_PROBE_WAITED(0, t_fetch)
+        TR_PROBE_TILE_DONE
         claunch* S = launder(L);
         const bool inside = cur.px < S->fp.rect_x1 && cur.py < S->fp.rect_y1;
         const bool active = inside && cur.mat != TR_NOT_COVERED;
@@ -1639,14 +1615,9 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             out = f3{cur.pd.x + cur.ns.x + (float)cur.mat, cur.pd.y + cur.ns.y + (float)cur.cluster_x, cur.pd.z + cur.ns.z + cur.pd.w + cur.ns.w};
         } else if (todo) {
             // the light lists of all 64 pixels are requested at once, before the wave splits by material
-#if TR_TIMING
-            const unsigned long long t_cluster = tr_now();
-#endif
+            TR_PROBE_SINCE(t_cluster)
             const cluster_list cl = cluster_lookup(S, cur.pd.w, cur.cluster_x + cur.cluster_y_term, key != TR_NOT_COVERED);
-#if TR_TIMING
-            tr_drain();
-            timer.wait[1] += tr_now() - t_cluster;
-#endif
+            TR_PROBE_WAITED(1, t_cluster)
             // One material at a time through the scalar unit; a wave that straddles k materials loops k times.
             quad_derivs qd;
             if constexpr (TEXTURED) {
@@ -1685,14 +1656,14 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 if (key == mk) {
                     if constexpr (TEX >= kTexFull) {
                         out = shade_pixel_textured<TRANSMISSIVE, TEX == kTexMid ? kSlotsMid : kSlotsAll>(
-                            L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb, lds_park TR_TIMER_ARG);
+                            L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb, lds_park TR_PROBE_ARGS);
                     } else if constexpr (TEX == kTexLite) {
                         if (dmats[m0].flags & 8u)
-                            out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane, cl, lds_srgb TR_TIMER_ARG);
+                            out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane, cl, lds_srgb TR_PROBE_ARGS);
                         else
-                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
+                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane, cl TR_PROBE_ARGS);
                     } else {
-                        out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane, cl TR_TIMER_ARG);
+                        out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane, cl TR_PROBE_ARGS);
                     }
                 }
             }
@@ -1778,18 +1749,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             }
         }
     }
-#if TR_TIMING
-    if (lane == 0) {
-        atomicAdd(&tr_timing_counters[0][blockIdx.x & 1023u], timer.wait[0]);
-        atomicAdd(&tr_timing_counters[1][blockIdx.x & 1023u], timer.wait[1]);
-        atomicAdd(&tr_timing_counters[2][blockIdx.x & 1023u], timer.wait[2]);
-        atomicAdd(&tr_timing_counters[3][blockIdx.x & 1023u], tr_now() - t_loop);
-        atomicAdd(&tr_timing_counters[4][blockIdx.x & 1023u], tiles_done);
-        atomicAdd(&tr_timing_counters[5][blockIdx.x & 1023u], 1ull);
-        atomicMax(&tr_timing_counters[6][blockIdx.x & 1023u], tr_now() - t_loop);
-        atomicAdd(&tr_timing_counters[7][blockIdx.x & 1023u], __builtin_amdgcn_s_memrealtime() - t_real);
-    }
-#endif
+    TR_PROBE_WAVE_END
 }
 
 // The block tiles (64x4 pixels, numbered like shade_kernel numbers the rect's) that hold a pixel of a full-class material,

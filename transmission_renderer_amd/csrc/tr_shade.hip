@@ -4,6 +4,12 @@
 // pyramid level table) in HBM, validates arguments, and enqueues kernels on the caller's
 // stream.  Nothing here computes pixels on the CPU; without a HIP device tr_context_create
 // fails with TR_ERR_NO_DEVICE and every other entry point needs a context.
+#if defined(TR_ABLATION) || defined(TR_TIMING) || defined(TR_PROBE_MASK)
+#define TR_PROBE_HOST 1     // profiling builds (tools/build_variant.py): tr_probe.h's host hooks; empty in the product
+#else
+#define TR_PROBE_FRAME_PARAMS(fp)
+#define TR_PROBE_GRID(bpx)
+#endif
 #include "tr_kernels.h"
 #include "tr_cluster_kernels.h"
 #include "tr_geometry_kernels.h"
@@ -486,9 +492,7 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
     fp->tiles_x_magic = (uint32_t)(0x100000000ull / fp->tiles_x > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->tiles_x);
     fp->stripe_tiles = fp->tiles_x * kStripeTileRows;
     fp->stripe_magic = (uint32_t)(0x100000000ull / fp->stripe_tiles > 0xFFFFFFFFull ? 0xFFFFFFFFull : 0x100000000ull / fp->stripe_tiles);
-#if TR_ABLATION
-    if (const char* e = std::getenv("TR_ABLATE")) fp->ablate = (uint32_t)std::atoi(e);  // profiling builds only
-#endif
+    TR_PROBE_FRAME_PARAMS(fp)
     fp->lut_wf = (float)ctx->lut_w;
     fp->lut_stride = ctx->lut_stride;
     fp->lut_height = ctx->lut_h;
@@ -504,9 +508,7 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
 uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles, bool vis = false) {
     const uint32_t per_xcd = (ntiles + 7u) / 8u;
     uint32_t bpx = vis ? ctx->blocks_per_xcd / kGridRounds * ctx->vis_grid_rounds : ctx->blocks_per_xcd;
-#if TR_ABLATION || TR_TIMING
-    if (const char* e = std::getenv("TR_GRID_QUARTERS")) bpx = bpx / kGridRounds * (uint32_t)std::atoi(e) / 4u;   // profiling builds only: quarters of the resident blocks
-#endif
+    TR_PROBE_GRID(bpx)
     uint32_t k = bpx < per_xcd ? bpx : per_xcd;
     if (k == 0) k = 1;
     return 8u * k;
@@ -1935,40 +1937,6 @@ tr_status tr_allgather_strips(tr_context* ctx, tr_comm* comm, void* frame, uint3
     return TR_OK;
 }
 
-#if TR_TIMING
-// profiling builds only (not declared in include/tr_shade.h): reads and clears the kernels' wait-cycle counters
-extern "C" int32_t tr_debug_read_timing(unsigned long long out[8]) {
-    static unsigned long long host[8][1024];
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tr_timing_counters), sizeof(host)) != hipSuccess) return -1;
-    for (int k = 0; k < 8; ++k) {
-        out[k] = 0;
-        for (int i = 0; i < 1024; ++i) out[k] += host[k][i];
-    }
-    unsigned long long longest = 0;   // the longest-lived wave
-    for (int i = 0; i < 1024; ++i) longest = std::max(longest, host[6][i]);
-    out[5] = out[5] | (longest << 32);
-    if (std::getenv("TR_TIMING_DUMP")) {   // per XCD: longest-lived wave, mean loop time, tiles
-        for (int x = 0; x < 8; ++x) {
-            unsigned long long mx = 0, sum = 0, waves = 0, tiles = 0;
-            for (int i = x; i < 1024; i += 8) {
-                mx = std::max(mx, host[6][i]);
-                sum += host[3][i];
-                waves += host[5][i];
-                tiles += host[4][i];
-            }
-            std::fprintf(stderr, "xcd %d: longest wave %llu, mean %llu, waves %llu, tiles %llu; per block slot (loop ticks/tiles):", x, mx, waves ? sum / waves : 0, waves, tiles);
-            for (int i = x; i < 1024; i += 8 * 8) std::fprintf(stderr, " %llu/%llu", host[5][i] ? host[3][i] / host[5][i] : 0, host[5][i] ? host[4][i] / host[5][i] : 0);
-            std::fprintf(stderr, "\n");
-        }
-    }
-    unsigned long long per_xcd[8] = {0};   // busy ticks per XCD (block b runs on XCD b % 8)
-    for (int i = 0; i < 1024; ++i) per_xcd[i & 7] += host[3][i];
-    out[6] = *std::max_element(per_xcd, per_xcd + 8) * 1000ull / (out[3] / 8ull + 1ull);   // most loaded XCD, per mille of the mean
-    // out[7]: sum of the waves' loop times in 100 MHz ticks
-    std::memset(host, 0, sizeof(host));
-    return hipMemcpyToSymbol(HIP_SYMBOL(tr_timing_counters), host, sizeof(host)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 tr_status tr_lottes_defaults(tr_lottes_params* out) {
     if (!out) return TR_ERR_INVALID_ARGUMENT;
