@@ -92,7 +92,9 @@ struct tr_draw_buffers {
 // bytes per primitive; one workgroup is latency-, not throughput-bound, up to ~1e6 primitives.
 // ZERO_COUNTS (the frame recorder's own buffer): every count is zeroed once it has been read, so the next frame's
 // culling finds the buffer clear without a fill launch of its own (src/main.rs:1668-1674 zeroes it per frame).
-template <bool ZERO_COUNTS>
+// NT: threads of the workgroup (1024, or 256 when the frame's first launch runs this behind its culling blocks: then the
+// counts are read with agent-scope loads — other XCDs' culling blocks have just incremented them by atomics).
+template <bool ZERO_COUNTS, uint32_t NT = 1024u, bool COUNTS_FROM_ATOMICS = false>
 __device__ __forceinline__ void demultiplex_draws_body(const tr_primitive_info* __restrict__ primitives,
                                                        uint32_t* __restrict__ instance_counts, uint32_t num_primitives,
                                                        uint32_t* __restrict__ draw_counts, const tr_draw_buffers& out) {
@@ -101,12 +103,13 @@ __device__ __forceinline__ void demultiplex_draws_body(const tr_primitive_info* 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x < TR_NUM_DRAW_BUFFERS) running[threadIdx.x] = 0u;
     __syncthreads();
-    for (uint32_t base = 0; base < num_primitives; base += 1024u) {
+    for (uint32_t base = 0; base < num_primitives; base += NT) {
         const uint32_t d = base + threadIdx.x;
         uint32_t n = 0, buffer = 0;
         tr_primitive_info prim;
         if (d < num_primitives) {
-            n = instance_counts[d];
+            if constexpr (COUNTS_FROM_ATOMICS) n = __hip_atomic_load(&instance_counts[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else n = instance_counts[d];
             if constexpr (ZERO_COUNTS) instance_counts[d] = 0u;
             prim = primitives[d];
             buffer = prim.draw_buffer_index < 3u ? prim.draw_buffer_index : 3u;   // the `_ =>` arm
@@ -134,7 +137,7 @@ __device__ __forceinline__ void demultiplex_draws_body(const tr_primitive_info* 
         __syncthreads();
         if (threadIdx.x < TR_NUM_DRAW_BUFFERS) {
             uint32_t t = 0;
-            for (uint32_t w = 0; w < 16u; ++w) t += wave_totals[w][threadIdx.x];
+            for (uint32_t w = 0; w < NT / 64u; ++w) t += wave_totals[w][threadIdx.x];
             running[threadIdx.x] += t;
         }
         __syncthreads();

@@ -44,8 +44,11 @@ struct tr_layer_counts {      // written by scan_draws / scan_items, read by the
 constexpr uint32_t kItemWidthBlocks = 8u;    // a work item spans at most 8 8x8 blocks horizontally (short items balance)
 
 // ------------------------------------------------------------------------ block-wide exclusive scan
-// 1024 threads; returns the exclusive prefix of `v` over the block and the block total (in every thread).
+// NT threads (1024, or 256 inside the frame's first launch); returns the exclusive prefix of `v` over the block and the
+// block total (in every thread).
+template <uint32_t NT = 1024u>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave /*[17]*/, uint32_t& total) {
+    constexpr int kWaves = (int)(NT / 64u);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = v;
 #pragma unroll
@@ -57,7 +60,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int w = 0; w < 16; ++w) {
+        for (int w = 0; w < kWaves; ++w) {
             const uint32_t t = lds_wave[w];
             lds_wave[w] = run;
             run += t;
@@ -72,6 +75,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 }
 
 // tri_base[d] = number of triangles before draw d of the layer's stream (first buffer's draws, then the second's)
+template <uint32_t NT = 1024u>
 __device__ __forceinline__ void raster_scan_draws_body(const tr_draw_command* __restrict__ draws_a,
                                                                  const tr_draw_command* __restrict__ draws_b,
                                                                  const uint32_t* __restrict__ draw_counts, uint32_t buffer_a,
@@ -83,7 +87,7 @@ __device__ __forceinline__ void raster_scan_draws_body(const tr_draw_command* __
     const uint32_t nb = min(draw_counts[buffer_a + 1u], capacity_draws - na);
     const uint32_t n = na + nb;
     uint32_t running = 0;
-    for (uint32_t base = 0; base < n; base += 1024u) {
+    for (uint32_t base = 0; base < n; base += NT) {
         const uint32_t d = base + threadIdx.x;
         uint32_t tris = 0;
         if (d < n) {
@@ -92,7 +96,7 @@ __device__ __forceinline__ void raster_scan_draws_body(const tr_draw_command* __
             tris = (uint32_t)min(t64, (uint64_t)capacity_triangles);
         }
         uint32_t total;
-        const uint32_t ex = block_exclusive_scan(tris, lds, total);
+        const uint32_t ex = block_exclusive_scan<NT>(tris, lds, total);
         if (d < n) tri_base[d] = min(running + ex, capacity_triangles);
         running = min(running + total, capacity_triangles);
     }
@@ -458,26 +462,6 @@ __device__ __forceinline__ void raster_resolve_body(const tr_raster_frame f, con
 
 
 
-// The frame recorder's fused launches (tr_record_frame / tr_draw_scene): every step of the front end is a tiny,
-// launch-latency-bound kernel (~4.5 us each back to back), so steps that run in ONE workgroup anyway share a launch.
-//   demultiplex_draws, then the draw scan of both layers: the same 1024 threads; the draw commands and counts the first
-//   step wrote are made visible to the whole device (fence) before the block barrier.
-__global__ __launch_bounds__(1024) void frame_demux_scan_kernel(const tr_primitive_info* __restrict__ primitives,
-                                                                uint32_t* __restrict__ instance_counts, uint32_t num_primitives,
-                                                                uint32_t* __restrict__ draw_counts, const tr_draw_buffers out,
-                                                                const tr_two_layers two) {
-    demultiplex_draws_body<true>(primitives, instance_counts, num_primitives, draw_counts, out);
-    __threadfence_block();   // (producer and consumer are this workgroup: a device-scope fence writes back the whole L2 of the XCD)
-    __syncthreads();
-    const volatile uint32_t* counts_now = draw_counts;   // (written above by this workgroup)
-    for (uint32_t layer = 0; layer < 2u; ++layer) {
-        TR_PICK_LAYER(two, layer);
-        if (W.capacity_triangles != 0u)
-            raster_scan_draws_body(W.draws_a, W.draws_b, const_cast<const uint32_t*>(counts_now), W.buffer_a, num_primitives,
-                                   W.capacity_triangles, W.tri_base, W.counts);
-        __syncthreads();
-    }
-}
 __global__ __launch_bounds__(1024) void raster_scan_draws_kernel(const tr_two_layers two, const uint32_t* __restrict__ draw_counts,
                                                                  uint32_t capacity_draws) {
     TR_PICK_LAYER(two, blockIdx.y);

@@ -33,15 +33,47 @@ namespace tr {
 // The frame recorder's first launch: frustum culling and light assignment are independent of each other, and each is
 // a few microseconds of launch latency on its own.  Blocks [0, cull_blocks) cull, the next assign_blocks assign lights,
 // the rest zero the rasteriser's tile coverage maps and list counters (a fill of their own is two more dispatches).
+// The culling block that FINISHES LAST also demultiplexes the draws and scans both layers' draw streams (one workgroup's
+// work that used to be the next launch): a ticket counts the culling blocks; what is handed over — the instance counts —
+// was written by atomics and is read back by agent-scope loads, so no fence is involved (a device-scope release writes
+// back the calling XCD's whole L2 on this chip; round 3's fence-and-ticket version of this launch took 115 us).
+struct tr_front_demux {
+    uint32_t* ticket;              // zero between frames
+    const tr_primitive_info* primitives;
+    uint32_t num_primitives;
+    uint32_t* draw_counts;
+    tr_draw_buffers out;
+    tr_two_layers two;
+};
 __global__ __launch_bounds__(256) void frame_front_kernel(const tr_cull_params cp, const tr_primitive_info* __restrict__ primitives,
                                                           const tr_instance* __restrict__ instances,
                                                           uint32_t* __restrict__ instance_counts, uint32_t cull_blocks,
                                                           const tr_assign_params ap, const tr_alight* __restrict__ lights,
                                                           const tr_cluster_aabb* __restrict__ clusters,
                                                           uint32_t* __restrict__ cluster_counts, uint32_t* __restrict__ light_indices,
-                                                          uint32_t assign_blocks, uint4* __restrict__ clear, uint32_t clear_vectors) {
+                                                          uint32_t assign_blocks, uint4* __restrict__ clear, uint32_t clear_vectors,
+                                                          const tr_front_demux dm) {
     if (blockIdx.x < cull_blocks) {
         frustum_culling_body(cp, primitives, instances, instance_counts, blockIdx.x);
+        __shared__ uint32_t last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's count atomics are performed ...
+        __syncthreads();                                     //  ... and every other wave's of the block)
+        if (threadIdx.x == 0u)
+            last = __hip_atomic_fetch_add(dm.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cull_blocks - 1u ? 1u : 0u;
+        __syncthreads();
+        if (last == 0u) return;
+        demultiplex_draws_body<true, 256u, true>(dm.primitives, instance_counts, dm.num_primitives, dm.draw_counts, dm.out);
+        __threadfence_block();     // (the draw scans below read what this workgroup has just written)
+        __syncthreads();
+        const volatile uint32_t* counts_now = dm.draw_counts;
+        for (uint32_t layer = 0; layer < 2u; ++layer) {
+            TR_PICK_LAYER(dm.two, layer);
+            if (W.capacity_triangles != 0u)
+                raster_scan_draws_body<256u>(W.draws_a, W.draws_b, const_cast<const uint32_t*>(counts_now), W.buffer_a, dm.num_primitives,
+                                             W.capacity_triangles, W.tri_base, W.counts);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0u) __hip_atomic_store(dm.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (blockIdx.x < cull_blocks + assign_blocks) {
         assign_lights_body(ap, lights, clusters, cluster_counts, light_indices, blockIdx.x - cull_blocks);
     } else {
@@ -92,6 +124,7 @@ struct tr_context {
     uint32_t max_triangles[2] = {0, 0};       // per layer, if every instance is visible
     size_t work_capacity = 0, work_draws = 0; // elements per layer in the rasteriser's work buffers
     uint32_t* d_instance_counts = nullptr;
+    uint32_t* d_front_ticket = nullptr;       // the frame's first launch: culling blocks done (zero between frames)
     uint32_t* d_draw_counts = nullptr;
     tr_draw_command* d_draws[TR_NUM_DRAW_BUFFERS] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* d_tri_base = nullptr;
@@ -726,9 +759,11 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         ctx->no_mid_class = std::getenv("TR_NO_MID_CLASS") != nullptr;   // tests only: the full-class launch's general build
         if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));  // tuning only
     }
-    if (hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
+    if (hipMalloc((void**)&ctx->d_front_ticket, 4u) != hipSuccess || hipMemset(ctx->d_front_ticket, 0, 4u) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_slice_thr, sizeof(float) * (TR_MAX_DEPTH_SLICES + 2)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_colour_tables, sizeof(tr_colour_tables)) != hipSuccess) {
+        (void)hipFree(ctx->d_front_ticket);
         (void)hipFree(ctx->d_levels);
         (void)hipFree(ctx->d_slice_thr);
         (void)hipFree(ctx->d_colour_tables);
@@ -770,6 +805,7 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_tex_arena);
     (void)hipFree(ctx->d_textures);
     (void)hipFree(ctx->d_colour_tables);
+    (void)hipFree(ctx->d_front_ticket);
     free_geometry(ctx);
     (void)hipFree(ctx->d_vis[0]);
     if (ctx->tables_event) (void)hipEventDestroy(ctx->tables_event);
@@ -1176,9 +1212,33 @@ inline size_t cover_clear_bytes(uint32_t w, uint32_t h) {
     return ((2u * cover_tiles + 2u) * 4u + 15u) & ~(size_t)15u;
 }
 
-// fused_demux: the caller has NOT demultiplexed: the first launch does it (from the context's own instance counts,
-// which it leaves zeroed) together with the draw scans of both layers.
-// resolve: write the TGB-v1 planes.  Without it the layers stay visibility words + triangle records, which the caller
+// The work buffers of both layers as the front-end kernels take them (after ensure_vis_buffers).
+void fill_two_layers(const tr_context* ctx, const void* const draws[TR_NUM_DRAW_BUFFERS], const tr_gbuffer_target* const targets[2],
+                     tr_two_layers& two) {
+    const size_t cap = ctx->work_capacity;
+    for (uint32_t layer = 0; layer < 2u; ++layer) {
+        tr_layer_work& W = two.l[layer];
+        W.draws_a = (const tr_draw_command*)draws[layer * 2u];
+        W.draws_b = (const tr_draw_command*)draws[layer * 2u + 1u];
+        W.buffer_a = layer * 2u;
+        W.capacity_triangles = ctx->max_triangles[layer];
+        W.tri_base = ctx->d_tri_base + layer * ctx->work_draws;
+        W.counts = ctx->d_layer_counts + layer;
+        W.records = ctx->d_records + layer * cap;
+        W.tri_planes = ctx->d_tri_planes + layer * cap;
+        W.item_base = ctx->d_item_base + layer * (cap + 1u);
+        W.vis = ctx->d_vis[layer];
+        W.planes.pos_depth = (float4*)targets[layer]->pos_depth;
+        W.planes.nrm_scale = (float4*)targets[layer]->nrm_scale;
+        W.planes.uv = (float2*)targets[layer]->uv;
+        W.planes.material_id = (uint32_t*)targets[layer]->material_id;
+        W.tile_cover = ctx->d_tile_cover[layer];
+    }
+}
+
+// fused_demux: the frame recorder's call — its first launch has demultiplexed the draws and scanned both layers' draw
+// streams behind its culling blocks (frame_front_kernel) and zeroed the coverage maps.
+// resolve: write the TGB-v1 planes.  Without it the layers stay visibility words + triangle planes, which the caller
 // hands to VIS shading launches (they zero the words; the caller sets ctx->vis_clean once both passes are enqueued).
 tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
                          const tr_push_constants* push, const tr_gbuffer_target* opaque,
@@ -1217,24 +1277,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     at.num_textures = ctx->num_textures;
     const size_t cap = ctx->work_capacity;
     tr_two_layers two;
-    for (uint32_t layer = 0; layer < 2u; ++layer) {
-        tr_layer_work& W = two.l[layer];
-        W.draws_a = (const tr_draw_command*)draws[layer * 2u];
-        W.draws_b = (const tr_draw_command*)draws[layer * 2u + 1u];
-        W.buffer_a = layer * 2u;
-        W.capacity_triangles = ctx->max_triangles[layer];
-        W.tri_base = ctx->d_tri_base + layer * ctx->work_draws;
-        W.counts = ctx->d_layer_counts + layer;
-        W.records = ctx->d_records + layer * cap;
-        W.tri_planes = ctx->d_tri_planes + layer * cap;
-        W.item_base = ctx->d_item_base + layer * (cap + 1u);
-        W.vis = ctx->d_vis[layer];
-        W.planes.pos_depth = (float4*)targets[layer]->pos_depth;
-        W.planes.nrm_scale = (float4*)targets[layer]->nrm_scale;
-        W.planes.uv = (float2*)targets[layer]->uv;
-        W.planes.material_id = (uint32_t*)targets[layer]->material_id;
-        W.tile_cover = ctx->d_tile_cover[layer];
-    }
+    fill_two_layers(ctx, draws, targets, two);
     // The visibility buffers are zero on entry: filled once after (re)allocation, and every resolve zeroes the words its
     // frame set (raster_resolve_body).  Per frame only the two tile coverage maps are cleared (260 KB at 4K).
     if (!ctx->vis_clean) TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u, stream));
@@ -1249,12 +1292,6 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     if (ensure_digested(ctx, stream) == TR_OK)
         mat_flags = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctx->d_dmats) + offsetof(tr_dmat, flags));
     TR_TRY(tables_acquire(ctx, stream));
-    if (fused_demux) {
-        tr_draw_buffers out;
-        for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k) out.draws[k] = (tr_draw_command*)draws[k];
-        hipLaunchKernelGGL(frame_demux_scan_kernel, dim3(1), dim3(1024), 0, stream, (const tr_primitive_info*)ctx->d_primitives,
-                           ctx->d_instance_counts, ctx->num_primitives, (uint32_t*)draw_counts, out, two);
-    }
     if (max_cap > 0u) {
         if (!fused_demux)
             hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1, 2), dim3(1024), 0, stream, two, (const uint32_t*)draw_counts,
@@ -2068,18 +2105,28 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         st = ensure_vis_buffers(ctx, w, h);
         if (st != TR_OK) return st;
         const uint32_t clear_vectors = (uint32_t)(cover_clear_bytes(w, h) / 16u), clear_blocks = (clear_vectors + 255u) / 256u;
+        tr_front_demux dm;
+        dm.ticket = ctx->d_front_ticket;
+        dm.primitives = ctx->d_primitives;
+        dm.num_primitives = ctx->num_primitives;
+        dm.draw_counts = ctx->d_draw_counts;
+        for (uint32_t k = 0; k < TR_NUM_DRAW_BUFFERS; ++k) dm.out.draws[k] = ctx->d_draws[k];
+        {
+            const tr_gbuffer_target* const layer_targets[2] = {&f->opaque_layer, &f->transmissive_layer};
+            fill_two_layers(ctx, draws, layer_targets, dm.two);
+        }
         hipLaunchKernelGGL(frame_front_kernel, dim3(cull_blocks + assign_blocks + clear_blocks), dim3(256), 0, s_, cp,
                            (const tr_primitive_info*)ctx->d_primitives, (const tr_instance*)ctx->d_instances,
                            ctx->d_instance_counts, cull_blocks, ap, (const tr_alight*)ctx->d_alights,
                            (const tr_cluster_aabb*)f->cluster_aabbs, (uint32_t*)f->cluster_light_counts, (uint32_t*)f->light_indices,
-                           assign_blocks, (uint4*)ctx->d_tile_cover[0], clear_vectors);
+                           assign_blocks, (uint4*)ctx->d_tile_cover[0], clear_vectors, dm);
         TR_HIP(ctx, hipGetLastError());
         ctx->cover_cleared = true;
         st = tr_set_cluster_tables(ctx, f->cluster_light_counts, f->light_indices, f->num_clusters);
         if (st != TR_OK) return st;
         st = rasterize_impl(ctx, ctx->d_draw_counts, draws, f->push, &f->opaque_layer, &f->transmissive_layer, stream, true, !use_vis);
         if (st != TR_OK) return st;
-        ctx->counts_clean = true;   // (the fused demultiplex zeroed what it read)
+        ctx->counts_clean = true;   // (the demultiplex behind the culling blocks zeroed what it read)
     } else {
     {   // "frustum culling" (zeroing the counts + "frustum culling compute shader")
         zone_scope z(rec, "frustum culling");
