@@ -76,8 +76,11 @@ def test_textured_launch_classes_keep_their_occupancy(kernels):
     for vis in (False, True):
         assert _shade(kernels, False, "uint2", 1, vis)["vgpr"] <= 72   # lite class, opaque: 7 waves
         assert _shade(kernels, True, "uint2", 1, vis)["vgpr"] <= 80    # lite class, transmissive: 6 waves
-        assert _shade(kernels, False, "uint2", 2, vis)["vgpr"] <= 96   # full class, opaque: 5 waves (LDS-parked front end)
-        assert _shade(kernels, True, "uint2", 2, vis)["vgpr"] <= 128   # full class, transmissive: 4 waves
+        for tex in (2, 3):                                             # full class (3: base colour + metallic-roughness + normal only)
+            for transmissive in (False, True):                         # 6 waves: tile inputs and late-read factors wait in LDS,
+                k = _shade(kernels, transmissive, "uint2", tex, vis)   # whose footprint must leave room for 24 waves per CU
+                assert k["vgpr"] <= 80, (tex, transmissive, vis, k)
+                assert k["lds"] <= 5 * 1280, (tex, transmissive, vis, k)
         assert _shade(kernels, False, "uint2", 3, vis)["vgpr"] <= 80   # ... its base-colour + metallic-roughness + normal build: 6 waves
         assert _shade(kernels, True, "uint2", 3, vis)["vgpr"] <= 96    #     transmissive: 5 waves
         # five one-wave workgroups per SIMD = 20 per CU must fit the CU's 160 KB of LDS

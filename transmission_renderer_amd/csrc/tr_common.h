@@ -28,6 +28,14 @@ __device__ __forceinline__ const TR_CONSTANT T* as_constant(const T* p) {
     return (const TR_CONSTANT T*)(p);
 }
 
+// The lane's index in its wave, derived on the spot (two instructions, opaque to the optimiser: neither hoisted nor
+// shared between uses) — for kernels that cannot afford a register for it across a long pixel.
+__device__ __forceinline__ uint32_t wave_lane() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // Makes a (uniform) pointer opaque to the optimiser: loads through the result cannot be hoisted above
 // this point, so their live ranges start here.
 template <class T>

@@ -77,7 +77,10 @@ __device__ __forceinline__ void tile_phase() {
     __builtin_amdgcn_s_setprio(P);
 }
 constexpr uint32_t kStripeTileRows = 4u;   // VIS / textured launches: tile rows per XCD stripe (1 ... 8 measure the same)
-constexpr uint32_t kParkedValues = 20u;    // full-class textured pixels: values parked in LDS, see shade_pixel_textured
+#ifndef TR_PARKED_VALUES
+#define TR_PARKED_VALUES 17u   // (A/B builds of tools/ raise it to measure what the LDS footprint costs in resident waves)
+#endif
+constexpr uint32_t kParkedValues = TR_PARKED_VALUES;    // full-class textured pixels: values parked in LDS, see shade_pixel_textured
 
 // ---------------------------------------------------------------- digested material (240 B)
 // Index 0 of every pair belongs to the basic_brdf lobe, index 1 to the transmission_btdf lobe.
@@ -929,9 +932,12 @@ __device__ __forceinline__ cluster_list cluster_lookup(claunch* L, float depth, 
 // MatP: `cdmat*` — the digested material in scalar registers (materials without textures), or
 // `const lane_dmat*` — per-lane values digested from the sampled textures; `ns.xyz` is then the normal after
 // normal mapping.
-template <bool TRANSMISSIVE, class MatP>
+struct nothing_to_reload {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <bool TRANSMISSIVE, class MatP, class Reload = nothing_to_reload>
 __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index, float4 pd, float4 ns, uint32_t lane,
-                                          const cluster_list& cl TR_PROBE_ARGS_DECL) {
+                                          const cluster_list& cl TR_PROBE_ARGS_DECL, Reload after_lights = Reload{}) {
     // (roughness, ior and the LUT line are the table's: one level pair and one LUT line per wave)
     constexpr bool SCALAR_MATERIAL = std::is_same<MatP, cdmat*>::value || std::is_same<MatP, const lite_dmat*>::value;
     // ================= phase 1: frame of the pixel, cluster list request, refraction taps =================
@@ -992,7 +998,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
             if (!TR_ABLATE(L, 1u)) pyramid_issue_record(pf, L->pyramid, as_constant(L->dtaps) + mat_index, tu, tv, L->fp.tap_row_lo, L->fp.tap_row_hi, L->tap_excess);
         } else {
             float lod = L->fp.log2_fb_width * m_rough_ior(*mb);
-            if (!TR_ABLATE(L, 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, lane, L->fp.tap_row_lo, L->fp.tap_row_hi, L->tap_excess);
+            if (!TR_ABLATE(L, 1u)) pyramid_issue(pf, L->pyramid, as_constant(L->levels), L->fp.pyr_levels, tu, tv, lod, wave_lane(), L->fp.tap_row_lo, L->fp.tap_row_hi, L->tap_excess);
         }
         if (TR_ABLATE(L, 1u)) { pf.r0[0] = pf.r0[1] = pf.r1[0] = pf.r1[1] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; pf.wx = pf.wy = splat(tu); pf.t = tv; pf.narrow0 = pf.narrow1 = false; }
         if constexpr (SCALAR_MATERIAL) {
@@ -1139,6 +1145,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
     };
     lights_phase();   // the sun
     punctual();
+    after_lights();   // (a per-lane record: what only the tail reads comes back from LDS, see shade_pixel_textured)
     return tail();
 }
 
@@ -1146,8 +1153,19 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
 // Differences inside the pixel's 2x2 quad of the two values the reference's shaders differentiate
 // (OpDPdx / OpDPdy): -view_vector (shader/src/lighting.rs:237) and uv (the implicit LOD of every texture fetch).
 struct quad_derivs {
-    f3 dp_dx, dp_dy;
-    uv_derivs uv;
+    uv_derivs uv;   // (full-class kernels: these and the differences of -view_vector wait in LDS, see kParkSlots)
+};
+// Full-class kernels: what a pixel's sampling front end reads of its tile — the quad differences, the interpolated normal
+// and scale, uv — is parked in the wave's LDS ONCE per tile, for all 64 lanes, before the wave splits by material: a lane's
+// column of slots is its own, so the lanes of the second material of a straddling tile find their inputs untouched by the
+// first material's pixels, and nothing of it is held in registers across a pixel (20 registers; reading the planes again
+// for the second material instead measured 3.5 % slower).  A lane's pixel then reuses its column for what it samples.
+enum : uint32_t {
+    kParkDp = 0u,        // 0-5   d(-view)/dx, d(-view)/dy           | 0-13 the sampled factors once the pixel is under way
+    kParkNormal = 6u,    // 6-9   interpolated normal, model scale
+    kParkUv = 10u,       // 10-11 uv
+    kParkDuv = 12u,      // 12-15 du/dx, dv/dx, du/dy, dv/dy        | 14-16 the mapped normal
+    kParkMapped = 14u,
 };
 
 // The front end of `fragment` / `fragment_transmission` for a material with texture slots (lib.rs:65-76, 120-124,
@@ -1155,21 +1173,22 @@ struct quad_derivs {
 // texture are issued together, then the sampled factors are digested per lane and the pixel continues through
 // the same shade_pixel as an untextured one.
 template <bool TRANSMISSIVE, uint32_t SLOTS /* the slots a material of this launch may bind: kSlotsAll / kSlotsMid */>
-__device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material, cdmat* dm, float4 pd, float4 ns,
-                                                   float2 uv, const quad_derivs& qd, uint32_t lane,
+__device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material, cdmat* dm, float4 pd, uint32_t lane,
                                                    const cluster_list& cl_in, const float* __restrict__ lds_srgb,
                                                    float* lds_park TR_PROBE_ARGS_DECL) {
     L = launder(L);
     dm = launder(dm);
-    // What the sampling front end does not read — the position, the pixel's cluster list — and what it
-    // produces slot by slot wait in the wave's LDS (one float per lane and value) instead of in registers: the front
-    // end's own state (quad differences, sampling geometry, eight taps, filter temporaries) is the kernel's peak.
+    // What the sampling front end produces slot by slot waits in the wave's LDS (one float per lane and value) instead of
+    // in registers, and what only the end of the pixel reads stays there across the light loop (after_lights below).
     float* const park = lds_park + lane;
     auto put = [&](uint32_t f, float v) { park[f * 64u] = v; };
     auto get = [&](uint32_t f) { return park[f * 64u]; };
-    put(0, pd.x); put(1, pd.y); put(2, pd.z); put(3, pd.w);
-    put(4, __uint_as_float(cl_in.cluster)); put(5, __uint_as_float(cl_in.key));
-    asm volatile("" ::: "memory");
+    constexpr uint32_t kNx = kParkMapped, kNy = kParkMapped + 1u, kNz = kParkMapped + 2u;
+    // the pixel's inputs, from the slots the kernel parked them in for the whole tile
+    float4 ns = float4{get(kParkNormal), get(kParkNormal + 1u), get(kParkNormal + 2u), get(kParkNormal + 3u)};
+    const float2 uv = float2{get(kParkUv), get(kParkUv + 1u)};
+    quad_derivs qd;
+    qd.uv = {get(kParkDuv), get(kParkDuv + 1u), get(kParkDuv + 2u), get(kParkDuv + 3u)};
     const TR_CONSTANT tr_material_info* mi = as_constant(L->materials) + material;
     cdtex* tex = as_constant(L->textures);
     const uint32_t* __restrict__ arena = L->tex_arena;
@@ -1216,74 +1235,8 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
     typedef std::integral_constant<int, 2> c2;
     typedef std::integral_constant<int, 3> c3;
 
-    lane_dmat lm;
-    // diffuse = diffuse_factor * sample (lib.rs:65-69)
-    float dr = mi->diffuse_factor[0], dg = mi->diffuse_factor[1], db = mi->diffuse_factor[2];
-    if (id_diffuse != -1) {
-        with_slot(std::integral_constant<int, 0>{}, [&](auto S) { dr *= S(c0{}); dg *= S(c1{}); db *= S(c2{}); });
-        asm volatile("" : "+v"(dr), "+v"(dg), "+v"(db));
-        slot_done();
-    }
-    put(6, dr); put(7, dg); put(8, db);
-    slot_done();
-    // get_material_params (lighting.rs:261-301)
-    float metallic = mi->metallic_factor, rough = mi->roughness_factor;
-    if (id_mr != -1) {
-        with_slot(std::integral_constant<int, 1>{}, [&](auto S) { metallic *= S(c2{}); rough *= S(c1{}); });   // "These two are switched!"
-        asm volatile("" : "+v"(metallic), "+v"(rough));
-        slot_done();
-    }
-    put(9, metallic); put(10, rough);
-    slot_done();
-    float scx = mi->specular_colour_factor[0], scy = mi->specular_colour_factor[1], scz = mi->specular_colour_factor[2];
-    if (id_spec_colour != -1) {
-        with_slot(std::integral_constant<int, 7>{}, [&](auto S) { scx *= S(c0{}); scy *= S(c1{}); scz *= S(c2{}); });
-        asm volatile("" : "+v"(scx), "+v"(scy), "+v"(scz));
-        slot_done();
-    }
-    if constexpr (may(7)) { put(11, scx); put(12, scy); put(13, scz); }
-    slot_done();
-    float specular_factor = mi->specular_factor;
-    if (id_specular != -1) {
-        with_slot(std::integral_constant<int, 6>{}, [&](auto S) { specular_factor *= S(c3{}); });
-        asm volatile("" : "+v"(specular_factor));
-        slot_done();
-    }
-    if constexpr (may(6)) put(14, specular_factor);
-    slot_done();
-    // get_emission (lighting.rs:303-313)
-    lm.emission[0] = mi->emissive_factor[0];
-    lm.emission[1] = mi->emissive_factor[1];
-    lm.emission[2] = mi->emissive_factor[2];
-    if (id_emissive != -1) {
-        with_slot(std::integral_constant<int, 3>{}, [&](auto S) { lm.emission[0] *= S(c0{}); lm.emission[1] *= S(c1{}); lm.emission[2] *= S(c2{}); });
-        asm volatile("" : "+v"(lm.emission[0]), "+v"(lm.emission[1]), "+v"(lm.emission[2]));
-        slot_done();
-    }
-    if constexpr (may(3)) { put(15, lm.emission[0]); put(16, lm.emission[1]); put(17, lm.emission[2]); }
-    slot_done();
-    lm.transmission_factor = mi->transmission_factor;               // lib.rs:71-77
-    if (id_transmission != -1) {
-        with_slot(std::integral_constant<int, 4>{}, [&](auto S) { lm.transmission_factor *= S(c0{}); });
-        asm volatile("" : "+v"(lm.transmission_factor));
-        slot_done();
-    }
-    if constexpr (may(4)) put(18, lm.transmission_factor);
-    slot_done();
-    lm.thickness = mi->thickness_factor;                            // lib.rs:120-124
-    if (id_thickness != -1) {
-        with_slot(std::integral_constant<int, 5>{}, [&](auto S) { lm.thickness *= S(c1{}); });
-        asm volatile("" : "+v"(lm.thickness));
-        slot_done();
-    }
-    if constexpr (may(5)) put(19, lm.thickness);
-    slot_done();
-    lm.eta = dm->eta;
-    lm.neg_atten_log2[0] = dm->neg_atten_log2[0];
-    lm.neg_atten_log2[1] = dm->neg_atten_log2[1];
-    lm.neg_atten_log2[2] = dm->neg_atten_log2[2];
-
-    // calculate_normal + compute_cotangent_frame (lighting.rs:222-259)
+    // calculate_normal + compute_cotangent_frame (lighting.rs:222-259) FIRST: the differences of the view vector and the
+    // interpolated normal end here, and the mapped normal waits in LDS while the other slots are sampled
     if (id_normal != -1) {
         const float inv_n = rsq(dot3(ns.x, ns.y, ns.z, ns.x, ns.y, ns.z));
         const f3 n = {ns.x * inv_n, ns.y * inv_n, ns.z * inv_n};
@@ -1297,7 +1250,8 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         asm volatile("" : "+v"(mx), "+v"(my), "+v"(mz));
         slot_done();
         auto cross = [](f3 a, f3 b) { return f3{fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y))}; };
-        const f3 dp2perp = cross(qd.dp_dy, n), dp1perp = cross(n, qd.dp_dx);
+        const f3 dp_dx = {get(kParkDp), get(kParkDp + 1u), get(kParkDp + 2u)}, dp_dy = {get(kParkDp + 3u), get(kParkDp + 4u), get(kParkDp + 5u)};
+        const f3 dp2perp = cross(dp_dy, n), dp1perp = cross(n, dp_dx);
         const f3 t = {fmaf(dp2perp.x, qd.uv.dudx, dp1perp.x * qd.uv.dudy), fmaf(dp2perp.y, qd.uv.dudx, dp1perp.y * qd.uv.dudy),
                       fmaf(dp2perp.z, qd.uv.dudx, dp1perp.z * qd.uv.dudy)};
         const f3 b = {fmaf(dp2perp.x, qd.uv.dvdx, dp1perp.x * qd.uv.dvdy), fmaf(dp2perp.y, qd.uv.dvdx, dp1perp.y * qd.uv.dvdy),
@@ -1309,26 +1263,104 @@ __device__ __forceinline__ f3 shade_pixel_textured(claunch* L, uint32_t material
         ns.z = fmaf(n.z, mz, fmaf(b.z, by_, t.z * tx));             // shade_pixel normalises
         asm volatile("" : "+v"(ns.x), "+v"(ns.y), "+v"(ns.z));
     }
+    put(kNx, ns.x); put(kNy, ns.y); put(kNz, ns.z);
+    slot_done();
+    lane_dmat lm;
+    // diffuse = diffuse_factor * sample (lib.rs:65-69)
+    float dr = mi->diffuse_factor[0], dg = mi->diffuse_factor[1], db = mi->diffuse_factor[2];
+    if (id_diffuse != -1) {
+        with_slot(std::integral_constant<int, 0>{}, [&](auto S) { dr *= S(c0{}); dg *= S(c1{}); db *= S(c2{}); });
+        asm volatile("" : "+v"(dr), "+v"(dg), "+v"(db));
+        slot_done();
+    }
+    put(0, dr); put(1, dg); put(2, db);
+    slot_done();
+    // get_material_params (lighting.rs:261-301)
+    float metallic = mi->metallic_factor, rough = mi->roughness_factor;
+    if (id_mr != -1) {
+        with_slot(std::integral_constant<int, 1>{}, [&](auto S) { metallic *= S(c2{}); rough *= S(c1{}); });   // "These two are switched!"
+        asm volatile("" : "+v"(metallic), "+v"(rough));
+        slot_done();
+    }
+    put(3, metallic); put(4, rough);
+    slot_done();
+    float scx = mi->specular_colour_factor[0], scy = mi->specular_colour_factor[1], scz = mi->specular_colour_factor[2];
+    if (id_spec_colour != -1) {
+        with_slot(std::integral_constant<int, 7>{}, [&](auto S) { scx *= S(c0{}); scy *= S(c1{}); scz *= S(c2{}); });
+        asm volatile("" : "+v"(scx), "+v"(scy), "+v"(scz));
+        slot_done();
+    }
+    if constexpr (may(7)) { put(5, scx); put(6, scy); put(7, scz); }
+    slot_done();
+    float specular_factor = mi->specular_factor;
+    if (id_specular != -1) {
+        with_slot(std::integral_constant<int, 6>{}, [&](auto S) { specular_factor *= S(c3{}); });
+        asm volatile("" : "+v"(specular_factor));
+        slot_done();
+    }
+    if constexpr (may(6)) put(8, specular_factor);
+    slot_done();
+    // get_emission (lighting.rs:303-313)
+    lm.emission[0] = mi->emissive_factor[0];
+    lm.emission[1] = mi->emissive_factor[1];
+    lm.emission[2] = mi->emissive_factor[2];
+    if (id_emissive != -1) {
+        with_slot(std::integral_constant<int, 3>{}, [&](auto S) { lm.emission[0] *= S(c0{}); lm.emission[1] *= S(c1{}); lm.emission[2] *= S(c2{}); });
+        asm volatile("" : "+v"(lm.emission[0]), "+v"(lm.emission[1]), "+v"(lm.emission[2]));
+        slot_done();
+    }
+    if constexpr (may(3)) { put(9, lm.emission[0]); put(10, lm.emission[1]); put(11, lm.emission[2]); }
+    slot_done();
+    lm.transmission_factor = mi->transmission_factor;               // lib.rs:71-77
+    if (id_transmission != -1) {
+        with_slot(std::integral_constant<int, 4>{}, [&](auto S) { lm.transmission_factor *= S(c0{}); });
+        asm volatile("" : "+v"(lm.transmission_factor));
+        slot_done();
+    }
+    if constexpr (may(4)) put(12, lm.transmission_factor);
+    slot_done();
+    lm.thickness = mi->thickness_factor;                            // lib.rs:120-124
+    if (id_thickness != -1) {
+        with_slot(std::integral_constant<int, 5>{}, [&](auto S) { lm.thickness *= S(c1{}); });
+        asm volatile("" : "+v"(lm.thickness));
+        slot_done();
+    }
+    if constexpr (may(5)) put(13, lm.thickness);
+    slot_done();
+    lm.eta = dm->eta;
+    lm.neg_atten_log2[0] = dm->neg_atten_log2[0];
+    lm.neg_atten_log2[1] = dm->neg_atten_log2[1];
+    lm.neg_atten_log2[2] = dm->neg_atten_log2[2];
+
     // The per-lane record is digested only now, when every slot has been sampled and the sampling geometry, the quad
     // differences and the taps are dead: the digest's twenty values and the sampling state are never live together.
     slot_done();
-    dr = get(6); dg = get(7); db = get(8);
-    metallic = get(9); rough = get(10);
-    if constexpr (may(7)) { scx = get(11); scy = get(12); scz = get(13); }
-    if constexpr (may(6)) specular_factor = get(14);
-    if constexpr (may(3)) { lm.emission[0] = get(15); lm.emission[1] = get(16); lm.emission[2] = get(17); }
-    if constexpr (may(4)) lm.transmission_factor = get(18);
-    if constexpr (may(5)) lm.thickness = get(19);
+    dr = get(0); dg = get(1); db = get(2);
+    metallic = get(3); rough = get(4);
+    if constexpr (may(7)) { scx = get(5); scy = get(6); scz = get(7); }
+    if constexpr (may(6)) specular_factor = get(8);
+    if constexpr (may(4)) lm.transmission_factor = get(12);
     lm.flags = (dm->flags & 1u) | (lm.transmission_factor != 0.0f ? 2u : 0u);
     digest_factors<false>(lm, metallic, rough, dm->ior_clamp, dm->f0_dielectric, specular_factor, scx, scy, scz, dr, dg, db,
                           L->fp.lut_height, L->fp.lut_stride);
     lm.metallic = metallic;
     lm.rough = rough;
-    const float4 pd2 = float4{get(0), get(1), get(2), get(3)};
-    cluster_list cl = cl_in;   // (the scalar members stay what they are)
-    cl.cluster = __float_as_uint(get(4));
-    cl.key = __float_as_uint(get(5));
-    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, material, pd2, ns, lane, cl TR_PROBE_ARGS);
+    const float4 ns2 = float4{get(kNx), get(kNy), get(kNz), ns.w};
+    // What only the end of the pixel reads — base colour, metallic, roughness, emission, transmission factor, thickness —
+    // stays in its LDS slot across the light loop and is read back behind it: ten registers the loop does not hold.
+    auto after_lights = [&]() {
+        // (through a laundered pointer: these are new loads to the optimiser, neither merged with the digest's reads of
+        //  the same slots nor a barrier to the scalar loads the tail wants early)
+        const float* again = park;
+        asm volatile("" : "+v"(again));
+        auto reget = [&](uint32_t f) { return again[f * 64u]; };
+        lm.diffuse[0] = reget(0); lm.diffuse[1] = reget(1); lm.diffuse[2] = reget(2);
+        lm.metallic = reget(3); lm.rough = reget(4);
+        if constexpr (may(3)) { lm.emission[0] = reget(9); lm.emission[1] = reget(10); lm.emission[2] = reget(11); }
+        if constexpr (may(4)) lm.transmission_factor = reget(12);
+        if constexpr (may(5)) lm.thickness = reget(13);
+    };
+    return shade_pixel<TRANSMISSIVE, const lane_dmat*>(L, &lm, material, pd, ns2, lane, cl_in TR_PROBE_ARGS, after_lights);
 }
 
 // ------------------------------------------------------------------------ one pixel of a "lite" textured material
@@ -1399,12 +1431,14 @@ struct tile_regs {
 };
 
 // Occupancy targets for the register allocator.  The untextured transmissive variant fed from visibility words fits 64
-// registers (8 waves) once told that eight waves are wanted; the full-class transmissive variant (97-100 left to itself:
-// 4 waves) fits 96 = 5 waves without a spill on planes, with two spilled registers when fed from visibility words.  Every
-// other variant is left to itself: forced up, the textured classes spill, and scratch costs more than the waves give
-// (tests/test_kernel_resources.py holds the line).
+// registers (8 waves) once told that eight waves are wanted.  The full-class variants hold 66-73 registers since their
+// tile inputs and late-read factors wait in LDS (kParkDp ...; round 3: 96-100 = 5 waves); LDS (17 slots + the sRGB table
+// = 5376 B per wave, allocated in 1280-byte granules: 22 or 26 slots measured alike, 8 % slower) then admits 25 waves per
+// CU, and the hint keeps the allocator from spending registers it has no use for.  Every other variant is left to
+// itself: forced up, the textured classes spill, and scratch costs more than the waves give (DESIGN.md 3.1;
+// tests/test_kernel_resources.py holds the line).
 #ifndef TR_WAVES_ATTR
-#define TR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((TEX == kTexNone && TRANSMISSIVE && VIS) ? 8 : (TEX == kTexFull && TRANSMISSIVE && !VIS) ? 5 : 1)))
+#define TR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((TEX == kTexNone && TRANSMISSIVE && VIS) ? 8 : (TEX >= kTexFull && TRANSMISSIVE) ? 6 : 1)))
 #endif
 // TEX: which material classes the launch shades (the host launches what the uploaded materials need, see tr_shade.hip):
 //   0  no uploaded material has a texture slot: every material through the scalar record;
@@ -1440,6 +1474,12 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         __syncthreads();
     }
     const uint32_t lx = lane & (kWaveTileW - 1u), ly = lane / kWaveTileW;   // position inside the wave's tile
+    // (full-class kernels, one wave per workgroup: the lane index is derived where it is used — wave_lane — instead of
+    //  held across the pixel, and so is everything that depends on it alone)
+    auto lane_here = [&]() -> uint32_t {
+        if constexpr (TEX >= kTexFull) return wave_lane();
+        else return lane;
+    };
 
     // One contiguous band of the rect's block tiles (row-major) per XCD.  Dealing the tiles to the XCDs in k smaller
     // chunks or in stripes of tile rows, to average the scene's cost variations over the XCDs (the most loaded XCD runs
@@ -1471,57 +1511,8 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // Out-of-rect lanes read a clamped (valid) pixel and are masked later.  There is no software prefetch of the
     // next tile: its 13 registers cost two of the eight resident waves per SIMD, and even scheduled so that nothing
     // younger is waited for during the light evaluation it measured slower (121 vs 113 us).
-    // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
-    auto fetch = [&](uint32_t j, tile_regs& t) {
-        claunch* F = launder(L);
-        uint32_t tile = listed ? as_constant(F->tile_list)[j >> 2] : band_start + (j >> 2);
-        if (striped) {   // local tile q of this XCD: stripe q / stripe_tiles of its own, i.e. stripe (that * 8 + xcd) of the frame
-            const uint32_t q = j >> 2, st = F->fp.stripe_tiles;
-            uint32_t own = __umulhi(q, F->fp.stripe_magic), off = q - own * st;
-            if (off >= st) {
-                off -= st;
-                ++own;
-            }
-            tile = (own * 8u + xcd) * st + off;
-        }
-        // tile / tiles_x without the vector unit: q = mulhi(tile, floor(2^32 / d)) is the quotient or one less
-        uint32_t tyi = __umulhi(tile, F->fp.tiles_x_magic);
-        uint32_t txi = tile - tyi * F->fp.tiles_x;
-        if (txi >= F->fp.tiles_x) {
-            txi -= F->fp.tiles_x;
-            ++tyi;
-        }
-        if (F->fp.strip_tile_rows != 0u) {   // (scalar) this rank's strips of a frame shared with other ranks
-            const uint32_t T = F->fp.strip_tile_rows;
-            uint32_t k = __umulhi(tyi, F->fp.strip_magic), r = tyi - k * T;
-            if (r >= T) {
-                r -= T;
-                ++k;
-            }
-            tyi = (k * F->fp.strip_world + F->fp.strip_rank) * T + r;
-        }
-        txi = txi * 4u + (j & 3u);
-        t.px = F->fp.rect_x0 + txi * kWaveTileW + lx;
-        t.py = F->fp.rect_y0 + tyi * kWaveTileH + ly;
-        // (scalar) the coverage word of the block tile, when the frame recorder rasterised the layer itself: 0 = nothing
-        // landed there; bit 1 / bit 2 = fragments of a full-class material / of any other (raster_resolve_body): a
-        // launch skips the tiles that hold nothing of the classes it shades without touching their planes
-        const uint32_t cover = F->tile_cover ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
-        t.cover = cover;
-        if constexpr (VIS && !TRANSMISSIVE) t.cover_front = F->cover_front ? as_constant(F->cover_front)[tile] : 0u;
-        if constexpr (TEX == kTexLite) {
-            // the tile may hold full-class fragments: listed for the TEX = 2 launch behind this one (once: by the wave of
-            // the tile's first quarter)
-            if (F->list_build && (cover & 2u) && cover != 0xFFFFFFFFu && (j & 3u) == 0u && lane == 0u)
-                F->list_build[atomicAdd(F->list_build_count, 1u)] = tile;
-        }
-        if (cover == 0u || (TEX >= kTexFull && !(cover & 2u))) {
-            t.mat = TR_NOT_COVERED;
-            t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
-            t.uv = float2{0.f, 0.f};
-            t.cluster_x = t.cluster_y_term = 0u;
-            return;
-        }
+    // The tile's per-pixel inputs (position, normal, uv, material id, cluster table entries) of the pixels t.px, t.py.
+    auto load_inputs = [&](claunch* F, tile_regs& t, uint32_t tile) {
         const uint32_t px_ = t.px, py_ = t.py;
         const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
         const uint32_t gpix = mad24(cy - F->fp.g_origin_y, F->fp.g_width, cx - F->fp.g_origin_x);
@@ -1585,6 +1576,67 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         t.cluster_x = (uint32_t)ld<uint16_t>(F->cluster_x, cx * 2u);
         t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
     };
+    // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
+    auto fetch = [&](uint32_t j, tile_regs& t) {
+        claunch* F = launder(L);
+        uint32_t tile = listed ? as_constant(F->tile_list)[j >> 2] : band_start + (j >> 2);
+        if (striped) {   // local tile q of this XCD: stripe q / stripe_tiles of its own, i.e. stripe (that * 8 + xcd) of the frame
+            const uint32_t q = j >> 2, st = F->fp.stripe_tiles;
+            uint32_t own = __umulhi(q, F->fp.stripe_magic), off = q - own * st;
+            if (off >= st) {
+                off -= st;
+                ++own;
+            }
+            tile = (own * 8u + xcd) * st + off;
+        }
+        // tile / tiles_x without the vector unit: q = mulhi(tile, floor(2^32 / d)) is the quotient or one less
+        uint32_t tyi = __umulhi(tile, F->fp.tiles_x_magic);
+        uint32_t txi = tile - tyi * F->fp.tiles_x;
+        if (txi >= F->fp.tiles_x) {
+            txi -= F->fp.tiles_x;
+            ++tyi;
+        }
+        if (F->fp.strip_tile_rows != 0u) {   // (scalar) this rank's strips of a frame shared with other ranks
+            const uint32_t T = F->fp.strip_tile_rows;
+            uint32_t k = __umulhi(tyi, F->fp.strip_magic), r = tyi - k * T;
+            if (r >= T) {
+                r -= T;
+                ++k;
+            }
+            tyi = (k * F->fp.strip_world + F->fp.strip_rank) * T + r;
+        }
+        txi = txi * 4u + (j & 3u);
+        if constexpr (TEX >= kTexFull) {
+            // (the lane's place in the tile is derived again per tile: two instructions instead of two registers held —
+            //  or spilled — across the whole pixel)
+            const uint32_t l = lane_here();
+            t.px = F->fp.rect_x0 + txi * kWaveTileW + (l & (kWaveTileW - 1u));
+            t.py = F->fp.rect_y0 + tyi * kWaveTileH + l / kWaveTileW;
+        } else {
+            t.px = F->fp.rect_x0 + txi * kWaveTileW + lx;
+            t.py = F->fp.rect_y0 + tyi * kWaveTileH + ly;
+        }
+        // (scalar) the coverage word of the block tile, when the frame recorder rasterised the layer itself: 0 = nothing
+        // landed there; bit 1 / bit 2 = fragments of a full-class material / of any other (raster_resolve_body): a
+        // launch skips the tiles that hold nothing of the classes it shades without touching their planes
+        const uint32_t cover = F->tile_cover ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
+        t.cover = cover;
+        if constexpr (VIS && !TRANSMISSIVE) t.cover_front = F->cover_front ? as_constant(F->cover_front)[tile] : 0u;
+        if constexpr (TEX == kTexLite) {
+            // the tile may hold full-class fragments: listed for the TEX = 2 launch behind this one (once: by the wave of
+            // the tile's first quarter)
+            if (F->list_build && (cover & 2u) && cover != 0xFFFFFFFFu && (j & 3u) == 0u && lane == 0u)
+                F->list_build[atomicAdd(F->list_build_count, 1u)] = tile;
+        }
+        if (cover == 0u || (TEX >= kTexFull && !(cover & 2u))) {
+            t.mat = TR_NOT_COVERED;
+            t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
+            t.uv = float2{0.f, 0.f};
+            t.cluster_x = t.cluster_y_term = 0u;
+            return;
+        }
+        load_inputs(F, t, tile);
+    };
 
     TR_PROBE_WAVE_BEGIN
     // Which tile next: static — the wave in slot w of its XCD takes the 16x4 tiles w, w + W, w + 2W, ... of the band
@@ -1631,16 +1683,23 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 const int mat_x = __builtin_amdgcn_ds_swizzle((int)cur.mat, 0x041F);
                 const int mat_y = __builtin_amdgcn_ds_swizzle((int)cur.mat, 0x401F);
                 const bool cov_x = covered & (mat_x != (int)TR_NOT_COVERED), cov_y = covered & (mat_y != (int)TR_NOT_COVERED);
-                const float sgn_x = (lane & 1u) ? -1.0f : 1.0f, sgn_y = (lane & kWaveTileW) ? -1.0f : 1.0f;
+                const uint32_t lq = lane_here();   // (derived per tile, not carried: see fetch)
+                const float sgn_x = (lq & 1u) ? -1.0f : 1.0f, sgn_y = (lq & kWaveTileW) ? -1.0f : 1.0f;
                 const float nvx = -(S->fp.view_position[0] - cur.pd.x), nvy = -(S->fp.view_position[1] - cur.pd.y),
                             nvz = -(S->fp.view_position[2] - cur.pd.z);
                 auto ddx = [&](float v) { const float d = (swz_x(v) - v) * sgn_x; return cov_x ? d : 0.0f; };
                 auto ddy = [&](float v) { const float d = (swz_y(v) - v) * sgn_y; return cov_y ? d : 0.0f; };
-                if constexpr (TEX >= kTexFull) {   // (only normal mapping differentiates the view vector)
-                    qd.dp_dx = {ddx(nvx), ddx(nvy), ddx(nvz)};
-                    qd.dp_dy = {ddy(nvx), ddy(nvy), ddy(nvz)};
-                }
                 qd.uv = {ddx(cur.uv.x), ddx(cur.uv.y), ddy(cur.uv.x), ddy(cur.uv.y)};
+                if constexpr (TEX >= kTexFull) {   // (only normal mapping differentiates the view vector; see kParkDp)
+                    float* const park = lds_park + lq;
+                    auto put = [&](uint32_t f, float v) { park[f * 64u] = v; };
+                    put(kParkDp, ddx(nvx)); put(kParkDp + 1u, ddx(nvy)); put(kParkDp + 2u, ddx(nvz));
+                    put(kParkDp + 3u, ddy(nvx)); put(kParkDp + 4u, ddy(nvy)); put(kParkDp + 5u, ddy(nvz));
+                    put(kParkNormal, cur.ns.x); put(kParkNormal + 1u, cur.ns.y); put(kParkNormal + 2u, cur.ns.z); put(kParkNormal + 3u, cur.ns.w);
+                    put(kParkUv, cur.uv.x); put(kParkUv + 1u, cur.uv.y);
+                    put(kParkDuv, qd.uv.dudx); put(kParkDuv + 1u, qd.uv.dvdx); put(kParkDuv + 2u, qd.uv.dudy); put(kParkDuv + 3u, qd.uv.dvdy);
+                    asm volatile("" ::: "memory");
+                }
             }
             while (todo) {
                 const int l0 = __ffsll((unsigned long long)todo) - 1;
@@ -1656,7 +1715,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 if (key == mk) {
                     if constexpr (TEX >= kTexFull) {
                         out = shade_pixel_textured<TRANSMISSIVE, TEX == kTexMid ? kSlotsMid : kSlotsAll>(
-                            L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd, lane, cl, lds_srgb, lds_park TR_PROBE_ARGS);
+                            L, m0, dmats + m0, cur.pd, lane_here(), cl, lds_srgb, lds_park TR_PROBE_ARGS);
                     } else if constexpr (TEX == kTexLite) {
                         if (dmats[m0].flags & 8u)
                             out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane, cl, lds_srgb TR_PROBE_ARGS);
@@ -1677,7 +1736,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         //  also writes the opaque pass's clear colour)
         bool write = TRANSMISSIVE ? active : inside;
         if constexpr (TEXTURED) {
-            const bool mine = ((shaded >> lane) & 1ull) != 0ull;
+            const bool mine = ((shaded >> lane_here()) & 1ull) != 0ull;
             const bool clears = TEX == kTexLite || S->fp.solo_full != 0u;   // (the launch that writes the opaque pass's clear colour)
             write = TRANSMISSIVE ? mine : (clears ? (inside && (mine || cur_mat_uncovered)) : mine);
         }
@@ -1690,7 +1749,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 // (scalar) a transmissive fragment landed in this tile: a pixel this launch shades knows its opaque depth —
                 // the transmissive winner stays only if it is nearer (depth GREATER, reversed Z)
                 bool owner = active;
-                if constexpr (TEXTURED) owner = ((shaded >> lane) & 1ull) != 0ull;
+                if constexpr (TEXTURED) owner = ((shaded >> lane_here()) & 1ull) != 0ull;
                 if (cur.cover_front != 0u && owner) {
                     claunch* V = launder(L);
                     const uint32_t at = mad24(out_py, V->fp.width, out_px) * 8u;
@@ -1713,7 +1772,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
 #pragma clang fp contract(off)
                 uint2 q = pack_rgba16f(out.x, out.y, out.z, 1.0f);
                 if constexpr (TEX >= kTexFull) {
-                    const bool mine = ((shaded >> lane) & 1ull) != 0ull;
+                    const bool mine = ((shaded >> lane_here()) & 1ull) != 0ull;
                     if (!M->fp.solo_full && !mine && inside) q = ld<uint2>(M->mip0, mad24(cur.py, M->fp.width, cur.px) * 8u);
                 }
                 const float c[4] = {h2f_lo(q.x), h2f_hi(q.x), h2f_lo(q.y), h2f_hi(q.y)};
@@ -1725,7 +1784,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                     const float below = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(hsum), 0x401F));               // lane ^ 16
                     s4[k] = hsum + below;
                 }
-                if ((lane & 17u) == 0u && inside)
+                if ((lane_here() & 17u) == 0u && inside)
                     st<uint2>(mip1, mad24(cur.py >> 1, M->fp.width >> 1, cur.px >> 1) * 8u, pack_rgba16f(s4[0], s4[1], s4[2], s4[3]));
             }
         }
