@@ -1448,11 +1448,14 @@ struct tile_regs {
 // A frame with textured materials is one launch of TEX = 1 (which also writes the opaque pass's clear colour) plus, when
 // a full-class material is uploaded, one of TEX = 2: the common materials do not pay for the registers of the eight-slot
 // sampling front end (120 VGPRs = 4 waves per SIMD; TEX = 1 holds 7-8).
-constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2, kTexMid = 3;
+constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2, kTexMid = 3, kTexAll = 4, kTexAllMid = 5;
 //   3  the FULL class again, for material sets whose full-class materials bind nothing but the base-colour, the
 //      metallic-roughness and the normal-map slot (the usual glTF set; the host knows: tr_upload_materials): what the other
 //      five slots would modulate stays the material record's scalar value instead of a per-lane one — fewer vector
 //      registers across the light loop, one more wave per SIMD
+//   4 / 5  EVERY class in one launch (5: the full class as in 3): since the full-class pixel holds no more registers than
+//      the lite one (its tile inputs and late-read factors wait in LDS), a material set that mixes classes is shaded by one
+//      launch — no tile list, no second launch's latency for a handful of tiles, no texels read back for level 1
 constexpr uint32_t kSlotsAll = 0xFFu, kSlotsMid = 0x07u;   // bit k: slot k of shade_pixel_textured's `ids` may be bound
 
 // VIS (the frame recorder's launches): a pixel's inputs are interpolated here from the rasteriser's visibility word and
@@ -1463,6 +1466,8 @@ constexpr uint32_t kSlotsAll = 0xFFu, kSlotsMid = 0x07u;   // bit k: slot k of s
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, int TEX = kTexNone, bool VIS = false>
 __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
     constexpr bool TEXTURED = TEX != kTexNone;
+    constexpr bool EVERY_CLASS = TEX >= kTexAll;            // plain + lite + full in this launch
+    constexpr bool LITE_ONLY = TEX == kTexLite, FULL_ONLY = TEX == kTexFull || TEX == kTexMid;
     constexpr uint32_t kPlanesNt = TR_PLANES_NT_MASK;   // which planes are loaded non-temporally (see fetch)
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
@@ -1491,7 +1496,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // A TEX = 2 launch inside the frame recorder walks the resolve's list of the block tiles that hold fragments of its
     // class instead of the rect: a whole-frame sweep that skips nearly every tile still pays the scalar round trips of
     // each (75 us at 4K for the demo frame's one small full-class object at 4 waves per SIMD).
-    const bool listed = TEX >= kTexFull && L->tile_list != nullptr;
+    const bool listed = FULL_ONLY && L->tile_list != nullptr;
     const uint32_t listed_tiles = listed ? as_constant(L->tile_list_count)[0] : 0u;
     // VIS launches (real frames, where whole screen regions are empty or cheap): the XCDs are dealt STRIPES of
     // kStripeTileRows tile rows in turn instead of one contiguous band each, so that every XCD gets its share of the
@@ -1550,7 +1555,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
             return;
         }
-        if (TEX >= kTexFull && !listed && !F->fp.solo_full) {
+        if (FULL_ONLY && !listed && !F->fp.solo_full) {
             // (a FULL-class launch beside a TEX = 1 launch without a tile list — the host always provides one, this is
             //  the safety net: material ids (4 B per pixel) and their class first, the other planes (40 B per pixel)
             //  only where one of the tile's pixels is this launch's to shade)
@@ -1622,13 +1627,13 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         const uint32_t cover = F->tile_cover ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
         t.cover = cover;
         if constexpr (VIS && !TRANSMISSIVE) t.cover_front = F->cover_front ? as_constant(F->cover_front)[tile] : 0u;
-        if constexpr (TEX == kTexLite) {
+        if constexpr (LITE_ONLY) {
             // the tile may hold full-class fragments: listed for the TEX = 2 launch behind this one (once: by the wave of
             // the tile's first quarter)
             if (F->list_build && (cover & 2u) && cover != 0xFFFFFFFFu && (j & 3u) == 0u && lane == 0u)
                 F->list_build[atomicAdd(F->list_build_count, 1u)] = tile;
         }
-        if (cover == 0u || (TEX >= kTexFull && !(cover & 2u))) {
+        if (cover == 0u || (FULL_ONLY && !(cover & 2u))) {
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
             t.uv = float2{0.f, 0.f};
@@ -1690,7 +1695,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 auto ddx = [&](float v) { const float d = (swz_x(v) - v) * sgn_x; return cov_x ? d : 0.0f; };
                 auto ddy = [&](float v) { const float d = (swz_y(v) - v) * sgn_y; return cov_y ? d : 0.0f; };
                 qd.uv = {ddx(cur.uv.x), ddx(cur.uv.y), ddy(cur.uv.x), ddy(cur.uv.y)};
-                if constexpr (TEX >= kTexFull) {   // (only normal mapping differentiates the view vector; see kParkDp)
+                if (TEX >= kTexFull && (FULL_ONLY || (cur.cover & 2u))) {   // (scalar: the tile holds full-class fragments; see kParkDp)
                     float* const park = lds_park + lq;
                     auto put = [&](uint32_t f, float v) { park[f * 64u] = v; };
                     put(kParkDp, ddx(nvx)); put(kParkDp + 1u, ddx(nvy)); put(kParkDp + 2u, ddx(nvz));
@@ -1709,11 +1714,20 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 todo &= ~group;
                 if constexpr (TEXTURED) {   // (scalar) is this material's class shaded by this launch?
                     const uint32_t cls = dmats[m0].flags & 12u;   // 0 untextured, 12 lite, 4 full
-                    if (TEX == kTexLite ? cls == 4u : cls != 4u) continue;
+                    if (!EVERY_CLASS && (LITE_ONLY ? cls == 4u : cls != 4u)) continue;
                     shaded |= group;
                 }
                 if (key == mk) {
-                    if constexpr (TEX >= kTexFull) {
+                    if constexpr (EVERY_CLASS) {
+                        const uint32_t fl = dmats[m0].flags;   // (scalar) 4: full class, 8: lite, neither: no texture slot
+                        if ((fl & 12u) == 4u)
+                            out = shade_pixel_textured<TRANSMISSIVE, TEX == kTexAllMid ? kSlotsMid : kSlotsAll>(
+                                L, m0, dmats + m0, cur.pd, lane_here(), cl, lds_srgb, lds_park TR_PROBE_ARGS);
+                        else if (fl & 8u)
+                            out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane_here(), cl, lds_srgb TR_PROBE_ARGS);
+                        else
+                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane_here(), cl TR_PROBE_ARGS);
+                    } else if constexpr (FULL_ONLY) {
                         out = shade_pixel_textured<TRANSMISSIVE, TEX == kTexMid ? kSlotsMid : kSlotsAll>(
                             L, m0, dmats + m0, cur.pd, lane_here(), cl, lds_srgb, lds_park TR_PROBE_ARGS);
                     } else if constexpr (TEX == kTexLite) {
@@ -1737,13 +1751,13 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         bool write = TRANSMISSIVE ? active : inside;
         if constexpr (TEXTURED) {
             const bool mine = ((shaded >> lane_here()) & 1ull) != 0ull;
-            const bool clears = TEX == kTexLite || S->fp.solo_full != 0u;   // (the launch that writes the opaque pass's clear colour)
+            const bool clears = !FULL_ONLY || S->fp.solo_full != 0u;   // (the launch that writes the opaque pass's clear colour)
             write = TRANSMISSIVE ? mine : (clears ? (inside && (mine || cur_mat_uncovered)) : mine);
         }
         if constexpr (VIS) {
             // the last reader of a visibility word leaves it zeroed for the next frame (see the template's comment)
             bool last = active;
-            if constexpr (TEX == kTexLite) last = active && (cur.cover & 2u) == 0u;   // (bit 1: the TEX = 2 launch visits the tile)
+            if constexpr (LITE_ONLY) last = active && (cur.cover & 2u) == 0u;   // (bit 1: the TEX = 2 launch visits the tile)
             if (last) st<unsigned long long>(launder(L)->vis, mad24(out_py, launder(L)->fp.width, out_px) * 8u, 0ull);
             if constexpr (!TRANSMISSIVE) {
                 // (scalar) a transmissive fragment landed in this tile: a pixel this launch shades knows its opaque depth —
@@ -1767,11 +1781,11 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             claunch* M = launder(L);
             uint2* const mip1 = M->mip1;
             bool tile_mine = mip1 != nullptr;
-            if constexpr (TEX == kTexLite) tile_mine = tile_mine && (cur.cover & 2u) == 0u;
+            if constexpr (LITE_ONLY) tile_mine = tile_mine && (cur.cover & 2u) == 0u;
             if (tile_mine) {
 #pragma clang fp contract(off)
                 uint2 q = pack_rgba16f(out.x, out.y, out.z, 1.0f);
-                if constexpr (TEX >= kTexFull) {
+                if constexpr (FULL_ONLY) {
                     const bool mine = ((shaded >> lane_here()) & 1ull) != 0ull;
                     if (!M->fp.solo_full && !mine && inside) q = ld<uint2>(M->mip0, mad24(cur.py, M->fp.width, cur.px) * 8u);
                 }

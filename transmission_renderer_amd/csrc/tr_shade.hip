@@ -210,6 +210,7 @@ struct tr_context {
     struct stream_seen { hipStream_t stream; uint64_t generation; };
     std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
     bool no_mid_class = false;                  // TR_NO_MID_CLASS (tests only), read once at context creation
+    uint32_t split_classes = 0;                 // TR_SPLIT_CLASSES (tests / A-B only): one launch per material class, as rounds 2-3 did (bit 0: opaque pass, bit 1: transmissive)
     uint32_t vis_grid_rounds = 3;               // see persistent_grid (TR_VIS_ROUNDS: tuning only)
 };
 
@@ -650,6 +651,13 @@ tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bo
     // the full-class launch: its kTexMid build when no full-class material binds a slot beyond base colour,
     // metallic-roughness and normal map (the transmission / thickness slots do not exist for the opaque pass)
     const bool mid = (ctx->full_slots & ~(TRANSMISSIVE ? kSlotsMid : (kSlotsMid | 0x30u))) == 0u && !ctx->no_mid_class;
+    if (ctx->any_plain_or_lite && ctx->any_full_textured && !(ctx->split_classes & (TRANSMISSIVE ? 2u : 1u))) {
+        // every class in ONE launch (kTexAll): the full-class pixel holds no more registers than the lite one
+        L.tile_list = L.tile_list_count = nullptr;
+        if (mid) launch_shade<TRANSMISSIVE, kTexAllMid>(L, half, grid, block, stream);
+        else launch_shade<TRANSMISSIVE, kTexAll>(L, half, grid, block, stream);
+        return TR_OK;
+    }
     if (ctx->any_plain_or_lite) {
         if (ctx->any_full_textured && L.tile_list) {   // (the frame recorder's buffers) the TEX = 1 launch lists the tiles itself
             L.list_build = const_cast<uint32_t*>(L.tile_list);
@@ -756,6 +764,8 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
             ctx->num_cus = (uint32_t)prop.multiProcessorCount;
         }
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
+        if (const char* e = std::getenv("TR_SPLIT_CLASSES"))
+            ctx->split_classes = std::strcmp(e, "opaque") == 0 ? 1u : std::strcmp(e, "transmissive") == 0 ? 2u : 3u;
         ctx->no_mid_class = std::getenv("TR_NO_MID_CLASS") != nullptr;   // tests only: the full-class launch's general build
         if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));  // tuning only
     }
