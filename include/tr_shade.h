@@ -606,7 +606,7 @@ tr_status tr_halo_rows(uint32_t total_rows, uint32_t rows_per_rank, uint32_t nra
  * size), strip s belongs to rank s % nranks.  After tr_set_strips, tr_shade_opaque / tr_shade_transmission called with a
  * rect that spans the whole frame height (and G-buffer planes that cover it) shade THIS RANK'S STRIPS in one launch
  * each, in place: colour targets are whole-frame buffers and every strip lands at its own rows.  tr_set_strips(ctx, 0,
- * 1, 0) turns it off.  Not combined with full-class textured materials' plane launches or tr_record_frame
+ * 1, 0) turns it off.  Any material set (one launch shades every material class); not combined with tr_record_frame
  * (TR_ERR_UNSUPPORTED).  SURVEY.md 8e; the reference is single-GPU (src/main.rs:243). */
 tr_status tr_set_strips(tr_context* ctx, uint32_t strip_rows, uint32_t nranks, uint32_t rank);
 /* Host only: rows [*y0, *y1) of the k-th strip of `rank` (strip k * nranks + rank of the frame), clipped to the frame;

@@ -36,19 +36,25 @@ def _whole_frame(r, scene, g, w, h):
     return hdr, pyr
 
 
-@pytest.mark.parametrize("w,h,world,strip_rows,coverage", [
-    (256, 200, 3, 16, "holes"),     # short last strip (200 = 12 * 16 + 8), uneven strip counts per rank
-    (320, 136, 2, 64, "full"),      # 3 strips on 2 ranks, the last one 8 rows
-    (130, 44, 8, 4, "holes"),       # ragged right edge, strips of one tile row, ranks 3..7 own a single strip
-    (64, 12, 8, 4, "full"),         # more ranks than strips: ranks 3..7 own nothing
-    (192, 200, 2, 4, "holes"),      # strips of one tile row, 25 strips per rank (strip_magic of T = 1 must not wrap to 0)
-    (128, 92, 3, 4, "full"),        # ... 23 strips on 3 ranks: 8 / 8 / 7
+@pytest.mark.parametrize("w,h,world,strip_rows,coverage,textured", [
+    (256, 200, 3, 16, "holes", False),     # short last strip (200 = 12 * 16 + 8), uneven strip counts per rank
+    (320, 136, 2, 64, "full", False),      # 3 strips on 2 ranks, the last one 8 rows
+    (130, 44, 8, 4, "holes", False),       # ragged right edge, strips of one tile row, ranks 3..7 own a single strip
+    (64, 12, 8, 4, "full", False),         # more ranks than strips: ranks 3..7 own nothing
+    (192, 200, 2, 4, "holes", False),      # strips of one tile row, 25 strips per rank (strip_magic of T = 1 must not wrap to 0)
+    (128, 92, 3, 4, "full", False),        # ... 23 strips on 3 ranks: 8 / 8 / 7
+    (256, 200, 3, 16, "holes", True),      # untextured, lite and full-class materials mixed (one launch shades every class:
+    (192, 120, 2, 4, "full", True),        #  round 3's full-class tile list, which numbered the rect's tiles, refused strips)
 ])
-def test_strips_in_place_equal_whole_frame(renderer, w, h, world, strip_rows, coverage):
+def test_strips_in_place_equal_whole_frame(renderer, w, h, world, strip_rows, coverage, textured):
     from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
     r = renderer
-    scene = synthetic.make_scene(w, h, num_point_lights=2, coverage=coverage)
+    scene = synthetic.make_scene(w, h, num_point_lights=2, coverage=coverage, textured=textured)
     _upload_scene(r, scene)
+    if textured:
+        classes = {(m.textures.normal_map != -1 or m.textures.metallic_roughness != -1, m.textures.diffuse != -1) for m in scene["materials"]}
+        assert len(classes) >= 2
+        r.upload_textures(scene["textures"])
     g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
     full, full_pyr = _whole_frame(r, scene, g, w, h)
 
@@ -111,9 +117,9 @@ def test_strips_4k_eight_ranks(renderer):
     assert torch.equal(got.view(torch.int16), full.view(torch.int16))
 
 
-def test_strips_lite_textured_and_refusals(ggx_lut):
-    """Strips work for the lite textured class (quads stay whole: strips are multiples of 4 rows); the full-class tile
-    list numbers the rect's tiles, so full-class materials are refused, and so is a rect that is not the frame."""
+def test_strips_textured_classes_and_refusals(ggx_lut):
+    """Strips work for a lite-only and for a full-class material set (quads stay whole: strips are multiples of 4 rows;
+    one launch shades every class); a rect that is not the frame is refused."""
     from transmission_renderer_amd import _lib
     from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer
     r = TransmissionRenderer(0)
@@ -133,19 +139,12 @@ def test_strips_lite_textured_and_refusals(ggx_lut):
         lite.append(m2)
     g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
     try:
-        for mats, ok in ((lite, True), (full_class, False)):
+        for mats in (lite, full_class):
             scene["materials"] = mats
             _upload_scene(r, scene)
             full, _ = _whole_frame(r, scene, g, w, h)
             hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
             pyr = OpaquePyramid(w, h, r.device)
-            if not ok:
-                r.set_strips(8, 2, 0)
-                with pytest.raises(_lib.TrError) as e:
-                    r.shade_opaque(g, scene["uniforms"], scene["push"], hdr, pyr, (0, 0, w, h))
-                assert e.value.status == 6            # TR_ERR_UNSUPPORTED
-                r.set_strips(0, 1, 0)
-                continue
             for rank in range(3):
                 r.set_strips(8, 3, rank)
                 r.shade_opaque(g, scene["uniforms"], scene["push"], hdr, pyr, (0, 0, w, h))

@@ -76,7 +76,7 @@ def test_textured_launch_classes_keep_their_occupancy(kernels):
     for vis in (False, True):
         assert _shade(kernels, False, "uint2", 1, vis)["vgpr"] <= 72   # lite class, opaque: 7 waves
         assert _shade(kernels, True, "uint2", 1, vis)["vgpr"] <= 80    # lite class, transmissive: 6 waves
-        for tex in (2, 3):                                             # full class (3: base colour + metallic-roughness + normal only)
+        for tex in (2, 3):                                             # every class incl. the full one (3: its usual glTF slot set only)
             for transmissive in (False, True):                         # 6 waves: tile inputs and late-read factors wait in LDS,
                 k = _shade(kernels, transmissive, "uint2", tex, vis)   # whose footprint must leave room for 24 waves per CU
                 assert k["vgpr"] <= 80, (tex, transmissive, vis, k)

@@ -62,7 +62,7 @@ def regions_of(path):
                  ("pixel:taps", r"auto issue_taps = "), ("pixel:sun", r"auto lights_phase = "), ("pixel:punctual", r"auto punctual = "),
                  ("pixel:finish", r"auto finish = "), ("pixel:tail", r"auto tail = "), ("textured_front_end", r"^struct quad_derivs"),
                  ("lite_front_end", r"f3 shade_pixel_lite\("), ("kernel:prologue", r"^#ifndef TR_PLANES_NT_MASK$"),
-                 ("kernel:fetch", r"auto fetch = "), ("kernel:vis_fetch", r"if constexpr \(VIS\) \{$"), ("kernel:plane_fetch", r"if \(TEX >= kTexFull && !listed && !F->fp.solo_full\)"),
+                 ("kernel:fetch", r"auto fetch = "), ("kernel:vis_fetch", r"if constexpr \(VIS\) \{$"), ("kernel:plane_fetch", r"t.mat = ld_plane<uint32_t"),
                  ("kernel:loop", r"const uint32_t wave_tiles = "), ("kernel:quad_derivs", r"quad_derivs qd;"),
                  ("kernel:material_loop", r"^            while \(todo\) \{"), ("kernel:store", r"const uint32_t out_px = cur.px"),
                  ("kernel:vis_zero", r"the last reader of a visibility word leaves it zeroed"),

@@ -205,8 +205,6 @@ struct tr_frame_params {
     uint32_t lut_stride;         // pair-table stride in entries (= lut_width + 2)
     uint32_t lut_height;
     uint32_t pyr_levels;
-    uint32_t solo_full;          // TEX = 2 launch only: every uploaded material is of the full class, there is no TEX = 1
-                                 // launch beside this one: it sweeps the whole rect and writes the clear colour itself
     uint32_t ablate;             // profiling builds only (tr_probe.h): which phases are switched off; 0 in the product
 };
 
@@ -247,12 +245,8 @@ struct tr_launch {
     const uint32_t* tex_arena;          // RGBA8 texels of every chain
     const float* srgb_to_linear;        // 256 entries
     const float* slice_thr;             // [slice_max + 2] depth thresholds of get_depth_slice, see depth_slice()
-    const uint32_t* tile_list;          // optional (TEX = 2 launches inside the frame recorder): the block tiles that hold
-    const uint32_t* tile_list_count;    // fragments of a full-class material, and their number
     const uint32_t* tile_cover;         // optional: one word per 64x4 block tile of the frame, 0 = the layer has no fragment there
                                         // (bit 1 / bit 2: fragments of a full-class material / of any other, raster_kernel)
-    uint32_t* list_build;               // optional (TEX = 1 launches inside the frame recorder): where this launch lists the
-    uint32_t* list_build_count;         // tiles whose coverage word has bit 1 set, for the TEX = 2 launch behind it
     // VIS launches (the frame recorder): the layer's visibility words and triangle records instead of the planes
     unsigned long long* vis;
     const tr_tri_planes* tri_planes;
@@ -1440,34 +1434,28 @@ struct tile_regs {
 #ifndef TR_WAVES_ATTR
 #define TR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((TEX == kTexNone && TRANSMISSIVE && VIS) ? 8 : (TEX >= kTexFull && TRANSMISSIVE) ? 6 : 1)))
 #endif
-// TEX: which material classes the launch shades (the host launches what the uploaded materials need, see tr_shade.hip):
-//   0  no uploaded material has a texture slot: every material through the scalar record;
-//   1  untextured materials and the LITE class (lite_dmat: only a base-colour texture, dielectric); pixels of FULL-class
-//      materials are left alone (their target texels too);
-//   2  the FULL class only (any other combination of texture slots: shade_pixel_textured), everything else left alone.
-// A frame with textured materials is one launch of TEX = 1 (which also writes the opaque pass's clear colour) plus, when
-// a full-class material is uploaded, one of TEX = 2: the common materials do not pay for the registers of the eight-slot
-// sampling front end (120 VGPRs = 4 waves per SIMD; TEX = 1 holds 7-8).
-constexpr int kTexNone = 0, kTexLite = 1, kTexFull = 2, kTexMid = 3, kTexAll = 4, kTexAllMid = 5;
-//   3  the FULL class again, for material sets whose full-class materials bind nothing but the base-colour, the
-//      metallic-roughness and the normal-map slot (the usual glTF set; the host knows: tr_upload_materials): what the other
-//      five slots would modulate stays the material record's scalar value instead of a per-lane one — fewer vector
-//      registers across the light loop, one more wave per SIMD
-//   4 / 5  EVERY class in one launch (5: the full class as in 3): since the full-class pixel holds no more registers than
-//      the lite one (its tile inputs and late-read factors wait in LDS), a material set that mixes classes is shaded by one
-//      launch — no tile list, no second launch's latency for a handful of tiles, no texels read back for level 1
+// TEX: which material classes the uploaded materials hold (the host knows: tr_upload_materials) — ONE launch shades them all:
+//   0  no material has a texture slot: every material through the scalar record;
+//   1  untextured materials and the LITE class (lite_dmat: only a base-colour texture, dielectric);
+//   2  every class, the FULL class among them (any other combination of texture slots: shade_pixel_textured).  Since the
+//      full-class pixel holds no more registers than the lite one (its tile inputs and late-read factors wait in LDS, see
+//      kParkDp), a material set that mixes classes no longer takes a launch per class (rounds 2-3: a TEX = 1 launch, a tile
+//      list, a full-class launch whose latency a handful of tiles could not fill — 4K mesh frame 222 -> 215 us, demo glTF
+//      229 -> 214);
+//   3  as 2, for material sets whose full-class materials bind nothing but the base-colour, the metallic-roughness and the
+//      normal-map slot (the usual glTF set): what the other five slots would modulate stays the material record's scalar
+//      value instead of a per-lane one.
+constexpr int kTexNone = 0, kTexLite = 1, kTexAll = 2, kTexAllMid = 3;
+constexpr int kTexFull = kTexAll;   // (>= kTexFull: the launch carries the full class's sampling front end)
 constexpr uint32_t kSlotsAll = 0xFFu, kSlotsMid = 0x07u;   // bit k: slot k of shade_pixel_textured's `ids` may be bound
 
 // VIS (the frame recorder's launches): a pixel's inputs are interpolated here from the rasteriser's visibility word and
 // triangle record (vis_interpolate, the resolve's own arithmetic) instead of being read from TGB-v1 planes, which the
 // frame then never writes: 60 B per covered pixel less traffic (8 B word read + zeroed instead of 8 + 8 + 44 written by
-// the resolve and 44 read back here).  The launch that shades a pixel — or, in a tile listed for the TEX = 2 launch, that
-// launch for every pixel, so that its quad partners of the other class are still there — zeroes the word for the next frame.
+// the resolve and 44 read back here).  The launch zeroes the word of every pixel it shades for the next frame.
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, int TEX = kTexNone, bool VIS = false>
 __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
     constexpr bool TEXTURED = TEX != kTexNone;
-    constexpr bool EVERY_CLASS = TEX >= kTexAll;            // plain + lite + full in this launch
-    constexpr bool LITE_ONLY = TEX == kTexLite, FULL_ONLY = TEX == kTexFull || TEX == kTexMid;
     constexpr uint32_t kPlanesNt = TR_PLANES_NT_MASK;   // which planes are loaded non-temporally (see fetch)
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
@@ -1493,15 +1481,10 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     const uint32_t ntiles = L->fp.tiles_x * L->fp.tiles_y;
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = ntiles >> 3, rem = ntiles & 7u;
-    // A TEX = 2 launch inside the frame recorder walks the resolve's list of the block tiles that hold fragments of its
-    // class instead of the rect: a whole-frame sweep that skips nearly every tile still pays the scalar round trips of
-    // each (75 us at 4K for the demo frame's one small full-class object at 4 waves per SIMD).
-    const bool listed = FULL_ONLY && L->tile_list != nullptr;
-    const uint32_t listed_tiles = listed ? as_constant(L->tile_list_count)[0] : 0u;
     // VIS launches (real frames, where whole screen regions are empty or cheap): the XCDs are dealt STRIPES of
     // kStripeTileRows tile rows in turn instead of one contiguous band each, so that every XCD gets its share of the
     // covered part of the screen (a frame whose upper half is sky left half of the XCDs idle).
-    const bool striped = (VIS || TEX != kTexNone) && !listed;
+    const bool striped = VIS || TEX != kTexNone;
     uint32_t stripes_own = 0u, striped_len = 0u;
     if (striped) {
         const uint32_t st = L->fp.stripe_tiles;
@@ -1510,15 +1493,14 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         const bool owns_last = stripes_own != 0u && ((nstripes - 1u) & 7u) == xcd;
         striped_len = stripes_own * st - (owns_last ? nstripes * st - ntiles : 0u);
     }
-    const uint32_t band_start = listed ? 0u : xcd * per + min(xcd, rem);
-    const uint32_t band_len = listed ? listed_tiles : striped ? striped_len : per + (xcd < rem ? 1u : 0u);
+    const uint32_t band_start = xcd * per + min(xcd, rem);
+    const uint32_t band_len = striped ? striped_len : per + (xcd < rem ? 1u : 0u);
 
     // Out-of-rect lanes read a clamped (valid) pixel and are masked later.  There is no software prefetch of the
     // next tile: its 13 registers cost two of the eight resident waves per SIMD, and even scheduled so that nothing
     // younger is waited for during the light evaluation it measured slower (121 vs 113 us).
     // The tile's per-pixel inputs (position, normal, uv, material id, cluster table entries) of the pixels t.px, t.py.
     auto load_inputs = [&](claunch* F, tile_regs& t, uint32_t tile) {
-        const uint32_t px_ = t.px, py_ = t.py;
         const uint32_t cx = min(t.px, F->fp.rect_x1 - 1u), cy = min(t.py, F->fp.rect_y1 - 1u);
         const uint32_t gpix = mad24(cy - F->fp.g_origin_y, F->fp.g_width, cx - F->fp.g_origin_x);
         if (TR_ABLATE(F, 64u)) {  // profiling only: no G-buffer traffic (synthetic per-lane inputs)
@@ -1555,26 +1537,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
             return;
         }
-        if (FULL_ONLY && !listed && !F->fp.solo_full) {
-            // (a FULL-class launch beside a TEX = 1 launch without a tile list — the host always provides one, this is
-            //  the safety net: material ids (4 B per pixel) and their class first, the other planes (40 B per pixel)
-            //  only where one of the tile's pixels is this launch's to shade)
-            const uint32_t id = ld<uint32_t>(F->material_id, gpix * 4u);
-            const bool in_rect = px_ < F->fp.rect_x1 && py_ < F->fp.rect_y1;
-            uint32_t cls = 0u;
-            if (id != TR_NOT_COVERED && in_rect)
-                cls = ld<uint32_t>(F->dmats, id * (uint32_t)sizeof(tr_dmat) + (uint32_t)offsetof(tr_dmat, flags)) & 12u;
-            if (ballot(cls == 4u) == 0ull) {
-                t.mat = TR_NOT_COVERED;
-                t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
-                t.uv = float2{0.f, 0.f};
-                t.cluster_x = t.cluster_y_term = 0u;
-                return;
-            }
-            t.mat = id;
-        } else {
-            t.mat = ld_plane<uint32_t, (kPlanesNt & 4u) != 0u>(F->material_id, gpix * 4u);
-        }
+        t.mat = ld_plane<uint32_t, (kPlanesNt & 4u) != 0u>(F->material_id, gpix * 4u);
         { const f4v a = ld_plane<f4v, (kPlanesNt & 1u) != 0u>(F->pos_depth, gpix * 16u); t.pd = float4{a.x, a.y, a.z, a.w}; }
         { const f4v a = ld_plane<f4v, (kPlanesNt & 2u) != 0u>(F->nrm_scale, gpix * 16u); t.ns = float4{a.x, a.y, a.z, a.w}; }
         if constexpr (TEXTURED) { const f2v a = ld_plane<f2v, (kPlanesNt & 8u) != 0u>(F->uv, gpix * 8u); t.uv = float2{a.x, a.y}; }
@@ -1584,7 +1547,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
     auto fetch = [&](uint32_t j, tile_regs& t) {
         claunch* F = launder(L);
-        uint32_t tile = listed ? as_constant(F->tile_list)[j >> 2] : band_start + (j >> 2);
+        uint32_t tile = band_start + (j >> 2);
         if (striped) {   // local tile q of this XCD: stripe q / stripe_tiles of its own, i.e. stripe (that * 8 + xcd) of the frame
             const uint32_t q = j >> 2, st = F->fp.stripe_tiles;
             uint32_t own = __umulhi(q, F->fp.stripe_magic), off = q - own * st;
@@ -1622,18 +1585,12 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             t.py = F->fp.rect_y0 + tyi * kWaveTileH + ly;
         }
         // (scalar) the coverage word of the block tile, when the frame recorder rasterised the layer itself: 0 = nothing
-        // landed there; bit 1 / bit 2 = fragments of a full-class material / of any other (raster_resolve_body): a
-        // launch skips the tiles that hold nothing of the classes it shades without touching their planes
+        // landed there (the tile is skipped without touching its inputs); bit 1 = fragments of a full-class material
+        // (their tile inputs are parked in LDS, see kParkDp), bit 2 = of any other (raster_kernel)
         const uint32_t cover = F->tile_cover ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
         t.cover = cover;
         if constexpr (VIS && !TRANSMISSIVE) t.cover_front = F->cover_front ? as_constant(F->cover_front)[tile] : 0u;
-        if constexpr (LITE_ONLY) {
-            // the tile may hold full-class fragments: listed for the TEX = 2 launch behind this one (once: by the wave of
-            // the tile's first quarter)
-            if (F->list_build && (cover & 2u) && cover != 0xFFFFFFFFu && (j & 3u) == 0u && lane == 0u)
-                F->list_build[atomicAdd(F->list_build_count, 1u)] = tile;
-        }
-        if (cover == 0u || (FULL_ONLY && !(cover & 2u))) {
+        if (cover == 0u) {
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
             t.uv = float2{0.f, 0.f};
@@ -1649,7 +1606,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // rows are 1 KB contiguous and their stores 512 B).  Handing tiles out dynamically balances the waves (static: the
     // longest-lived wave of the 4K frame runs 36 % longer than the mean) but measured slower.
     const uint32_t wave_tiles = band_len * 4u;
-    const uint32_t slot = listed ? blockIdx.x : (blockIdx.x >> 3);
+    const uint32_t slot = blockIdx.x >> 3;
     uint32_t j = slot;
     tile_regs cur;
     while (j < wave_tiles) {
@@ -1661,11 +1618,9 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         claunch* S = launder(L);
         const bool inside = cur.px < S->fp.rect_x1 && cur.py < S->fp.rect_y1;
         const bool active = inside && cur.mat != TR_NOT_COVERED;
-        const bool cur_mat_uncovered = cur.mat == TR_NOT_COVERED;
         const uint32_t key = inside ? cur.mat : TR_NOT_COVERED;   // the material of a lane that has work
         f3 out = {0.f, 0.f, 0.f};  // clear colour of the opaque pass (src/main.rs:1592-1601)
         uint64_t todo = ballot(key != TR_NOT_COVERED);
-        uint64_t shaded = 0ull;   // TEX != 0: the lanes whose material class this launch shades
         cdmat* dmats = as_constant(S->dmats);
         if (TR_ABLATE(S, 32u)) {  // profiling only: pure streaming skeleton
             todo = 0;
@@ -1695,7 +1650,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 auto ddx = [&](float v) { const float d = (swz_x(v) - v) * sgn_x; return cov_x ? d : 0.0f; };
                 auto ddy = [&](float v) { const float d = (swz_y(v) - v) * sgn_y; return cov_y ? d : 0.0f; };
                 qd.uv = {ddx(cur.uv.x), ddx(cur.uv.y), ddy(cur.uv.x), ddy(cur.uv.y)};
-                if (TEX >= kTexFull && (FULL_ONLY || (cur.cover & 2u))) {   // (scalar: the tile holds full-class fragments; see kParkDp)
+                if (TEX >= kTexFull && (cur.cover & 2u)) {   // (scalar: the tile holds full-class fragments; see kParkDp)
                     float* const park = lds_park + lq;
                     auto put = [&](uint32_t f, float v) { park[f * 64u] = v; };
                     put(kParkDp, ddx(nvx)); put(kParkDp + 1u, ddx(nvy)); put(kParkDp + 2u, ddx(nvz));
@@ -1712,29 +1667,16 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 const uint32_t m0 = opaque(mk);   // tables are indexed with m0, the branch compares mk (see opaque())
                 const uint64_t group = ballot(key == mk);
                 todo &= ~group;
-                if constexpr (TEXTURED) {   // (scalar) is this material's class shaded by this launch?
-                    const uint32_t cls = dmats[m0].flags & 12u;   // 0 untextured, 12 lite, 4 full
-                    if (!EVERY_CLASS && (LITE_ONLY ? cls == 4u : cls != 4u)) continue;
-                    shaded |= group;
-                }
                 if (key == mk) {
-                    if constexpr (EVERY_CLASS) {
+                    if constexpr (TEXTURED) {
                         const uint32_t fl = dmats[m0].flags;   // (scalar) 4: full class, 8: lite, neither: no texture slot
-                        if ((fl & 12u) == 4u)
+                        if (TEX >= kTexFull && (fl & 12u) == 4u)
                             out = shade_pixel_textured<TRANSMISSIVE, TEX == kTexAllMid ? kSlotsMid : kSlotsAll>(
                                 L, m0, dmats + m0, cur.pd, lane_here(), cl, lds_srgb, lds_park TR_PROBE_ARGS);
                         else if (fl & 8u)
                             out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane_here(), cl, lds_srgb TR_PROBE_ARGS);
                         else
                             out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane_here(), cl TR_PROBE_ARGS);
-                    } else if constexpr (FULL_ONLY) {
-                        out = shade_pixel_textured<TRANSMISSIVE, TEX == kTexMid ? kSlotsMid : kSlotsAll>(
-                            L, m0, dmats + m0, cur.pd, lane_here(), cl, lds_srgb, lds_park TR_PROBE_ARGS);
-                    } else if constexpr (TEX == kTexLite) {
-                        if (dmats[m0].flags & 8u)
-                            out = shade_pixel_lite<TRANSMISSIVE>(L, m0, dmats + m0, cur.pd, cur.ns, cur.uv, qd.uv, lane, cl, lds_srgb TR_PROBE_ARGS);
-                        else
-                            out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane, cl TR_PROBE_ARGS);
                     } else {
                         out = shade_pixel<TRANSMISSIVE>(L, dmats + m0, m0, cur.pd, cur.ns, lane, cl TR_PROBE_ARGS);
                     }
@@ -1744,27 +1686,16 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         // The next tile's plane loads are issued BEFORE this tile's store: memory operations complete in order, so a
         // load behind the store could not be waited for without waiting for the store's acknowledgement as well.
         const uint32_t out_px = cur.px, out_py = cur.py;
-        j += listed ? gridDim.x : (gridDim.x >> 3);
+        j += gridDim.x >> 3;
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
-        // (with textured materials uploaded: a launch writes the pixels of the classes it shades; the TEX = 1 launch
-        //  also writes the opaque pass's clear colour)
-        bool write = TRANSMISSIVE ? active : inside;
-        if constexpr (TEXTURED) {
-            const bool mine = ((shaded >> lane_here()) & 1ull) != 0ull;
-            const bool clears = !FULL_ONLY || S->fp.solo_full != 0u;   // (the launch that writes the opaque pass's clear colour)
-            write = TRANSMISSIVE ? mine : (clears ? (inside && (mine || cur_mat_uncovered)) : mine);
-        }
+        const bool write = TRANSMISSIVE ? active : inside;
         if constexpr (VIS) {
-            // the last reader of a visibility word leaves it zeroed for the next frame (see the template's comment)
-            bool last = active;
-            if constexpr (LITE_ONLY) last = active && (cur.cover & 2u) == 0u;   // (bit 1: the TEX = 2 launch visits the tile)
-            if (last) st<unsigned long long>(launder(L)->vis, mad24(out_py, launder(L)->fp.width, out_px) * 8u, 0ull);
+            // the reader of a visibility word leaves it zeroed for the next frame (see the template's comment)
+            if (active) st<unsigned long long>(launder(L)->vis, mad24(out_py, launder(L)->fp.width, out_px) * 8u, 0ull);
             if constexpr (!TRANSMISSIVE) {
                 // (scalar) a transmissive fragment landed in this tile: a pixel this launch shades knows its opaque depth —
                 // the transmissive winner stays only if it is nearer (depth GREATER, reversed Z)
-                bool owner = active;
-                if constexpr (TEXTURED) owner = ((shaded >> lane_here()) & 1ull) != 0ull;
-                if (cur.cover_front != 0u && owner) {
+                if (cur.cover_front != 0u && active) {
                     claunch* V = launder(L);
                     const uint32_t at = mad24(out_py, V->fp.width, out_px) * 8u;
                     const unsigned long long front = ld<unsigned long long>(V->vis_front, at);
@@ -1776,19 +1707,12 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         if constexpr (!TRANSMISSIVE && sizeof(OutT) == 8) {
             // Level 1 of the opaque pyramid straight from the values being stored: for even sizes a LINEAR blit is the
             // 2x2 box of the ROUNDED level-0 texels, (q00/4 + q10/4) + (q01/4 + q11/4) (box4 / the oracle), and a wave
-            // tile holds whole quads — the mip chain then never reads level 0 (66 of its 88 MB at 4K).  Tiles that also
-            // hold full-class fragments are left to the TEX = 2 launch, which reads the other lanes' texels back.
+            // tile holds whole quads — the mip chain then never reads level 0 (66 of its 88 MB at 4K).
             claunch* M = launder(L);
             uint2* const mip1 = M->mip1;
-            bool tile_mine = mip1 != nullptr;
-            if constexpr (LITE_ONLY) tile_mine = tile_mine && (cur.cover & 2u) == 0u;
-            if (tile_mine) {
+            if (mip1 != nullptr) {
 #pragma clang fp contract(off)
-                uint2 q = pack_rgba16f(out.x, out.y, out.z, 1.0f);
-                if constexpr (FULL_ONLY) {
-                    const bool mine = ((shaded >> lane_here()) & 1ull) != 0ull;
-                    if (!M->fp.solo_full && !mine && inside) q = ld<uint2>(M->mip0, mad24(cur.py, M->fp.width, cur.px) * 8u);
-                }
+                const uint2 q = pack_rgba16f(out.x, out.y, out.z, 1.0f);
                 const float c[4] = {h2f_lo(q.x), h2f_hi(q.x), h2f_lo(q.y), h2f_hi(q.y)};
                 float s4[4];
 #pragma unroll
@@ -1823,28 +1747,6 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         }
     }
     TR_PROBE_WAVE_END
-}
-
-// The block tiles (64x4 pixels, numbered like shade_kernel numbers the rect's) that hold a pixel of a full-class material,
-// for TEX = 2 launches outside the frame recorder (there the resolve makes the list): one workgroup per block tile.
-struct tr_classify_params {
-    uint32_t g_width, g_origin_x, g_origin_y;
-    uint32_t rect_x0, rect_y0, rect_x1, rect_y1, tiles_x;
-};
-__global__ __launch_bounds__(256) void classify_tiles_kernel(const uint32_t* __restrict__ material_id, const tr_classify_params p,
-                                                             const uint32_t* __restrict__ material_flags, uint32_t flags_stride,
-                                                             uint32_t num_materials, uint32_t* __restrict__ list,
-                                                             uint32_t* __restrict__ count) {
-    __shared__ uint32_t any;
-    if (threadIdx.x == 0) any = 0u;
-    __syncthreads();
-    const uint32_t px = p.rect_x0 + blockIdx.x * 64u + (threadIdx.x & 63u), py = p.rect_y0 + blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (px < p.rect_x1 && py < p.rect_y1) {
-        const uint32_t id = material_id[(size_t)(py - p.g_origin_y) * p.g_width + (px - p.g_origin_x)];
-        if (id != TR_NOT_COVERED && id < num_materials && (material_flags[(size_t)id * flags_stride] & 12u) == 4u) any = 1u;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && any) list[atomicAdd(count, 1u)] = blockIdx.y * p.tiles_x + blockIdx.x;
 }
 
 // LightClusterCoefficients::get_depth_slice over an array (tr_get_depth_slice): the passes' own device function.

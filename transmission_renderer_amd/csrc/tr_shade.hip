@@ -98,12 +98,9 @@ struct tr_context {
     bool dmats_dirty = false;
     std::vector<tr_material_info> stage_materials;
 
-    bool any_textured = false;      // some material has a texture slot: the TEX = 1 launch (untextured + lite class) runs
-    bool any_full_textured = false; // ... outside the lite class: the TEX = 2 launch runs as well
-    bool any_plain_or_lite = false; // some material is untextured or of the lite class (else the TEX = 2 launch runs alone)
+    bool any_textured = false;      // some material has a texture slot: the launches are the kTexLite build ...
+    bool any_full_textured = false; // ... or, with a material outside the lite class, kTexAll / kTexAllMid (tr_kernels.h, TEX)
     uint32_t full_slots = 0;        // the texture slots bound by any full-class material (bit k: slot k of the kernels' `ids`)
-    uint32_t* d_class_list = nullptr;   // TEX = 2 launches outside the frame recorder: [0] count, [1..] block tiles
-    size_t class_list_cap = 0;
     int32_t max_texture_id = -1;    // largest texture id a material refers to
 
     // material textures: one arena of RGBA8 mip chains + a descriptor table
@@ -138,16 +135,12 @@ struct tr_context {
     unsigned long long* d_vis[2] = {nullptr, nullptr};
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
-    const uint32_t* list_hint = nullptr;               // ... with it: the layer's list of full-class tiles
     bool cover_cleared = false;                        // the frame's first launch has zeroed the coverage maps already
     unsigned long long* vis_hint = nullptr;            // ... and, when the frame skipped the resolve, the layer's visibility
     const tr_tri_planes* planes_hint = nullptr;        //     words and triangle planes: the shading launches read those (VIS)
     unsigned long long* vis_front_hint = nullptr;      // opaque VIS launches: the transmissive layer's words and coverage map
     const uint32_t* cover_front_hint = nullptr;        //   (a transmissive winner behind the opaque surface is zeroed there)
-    const uint32_t* list_count_hint = nullptr;
     void* mip1_hint = nullptr;                         // ... and level 1 of the opaque pyramid, for the opaque launches to write
-    uint32_t* d_tile_list_counts = nullptr;            // (inside the d_vis allocation, cleared with the coverage maps)
-    uint32_t* d_tile_list[2] = {nullptr, nullptr};     // per layer: the tiles
     size_t vis_pixels = 0;
     bool vis_clean = false;                            // both visibility buffers are all zero (stream order)
     uint32_t vis_w = 0, vis_h = 0;                     // the frame size they are laid out for
@@ -210,7 +203,6 @@ struct tr_context {
     struct stream_seen { hipStream_t stream; uint64_t generation; };
     std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
     bool no_mid_class = false;                  // TR_NO_MID_CLASS (tests only), read once at context creation
-    uint32_t split_classes = 0;                 // TR_SPLIT_CLASSES (tests / A-B only): one launch per material class, as rounds 2-3 did (bit 0: opaque pass, bit 1: transmissive)
     uint32_t vis_grid_rounds = 3;               // see persistent_grid (TR_VIS_ROUNDS: tuning only)
 };
 
@@ -583,7 +575,6 @@ void free_geometry(tr_context* ctx) {
 // Passes that shade textured materials differentiate inside 2x2 pixel quads: the rect must hold whole quads.
 tr_status check_textured_launch(const tr_context* ctx, const tr_gbuffer* g, const tr_frame_params& fp) {
     if (!ctx->any_textured) return TR_OK;
-    if (fp.strip_tile_rows != 0u && ctx->any_full_textured) return TR_ERR_UNSUPPORTED;   // (the full-class tile list numbers the rect's tiles)
     if (!g->uv) return TR_ERR_INVALID_ARGUMENT;
     if (ctx->max_texture_id >= (int32_t)ctx->num_textures) return TR_ERR_INVALID_ARGUMENT;
     if ((fp.rect_x0 & 1u) || (fp.rect_y0 & 1u)) return TR_ERR_INVALID_ARGUMENT;
@@ -606,9 +597,6 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.tile_cover = (ctx->cover_hint && fp.rect_x0 == 0u && fp.rect_y0 == 0u && fp.g_origin_x == 0u && fp.g_origin_y == 0u &&
                     fp.rect_x1 == fp.width && fp.rect_y1 == fp.height && fp.g_width == fp.width)
                        ? ctx->cover_hint : nullptr;
-    L.tile_list = L.tile_cover ? ctx->list_hint : nullptr;
-    L.tile_list_count = L.tile_list ? ctx->list_count_hint : nullptr;
-    L.list_build = L.list_build_count = nullptr;
     L.vis = L.tile_cover ? ctx->vis_hint : nullptr;
     L.tri_planes = L.vis ? ctx->planes_hint : nullptr;
     L.vis_front = L.vis ? ctx->vis_front_hint : nullptr;
@@ -631,11 +619,6 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.srgb_to_linear = ctx->d_colour_tables ? ctx->d_colour_tables->srgb_to_linear : nullptr;
 }
 
-// The launches of a shading pass when textured materials are uploaded (shade_kernel's TEX classes):
-//   untextured + lite materials present: one TEX = 1 launch over the rect (it also writes the opaque pass's clear colour),
-//   full-class materials present: one TEX = 2 launch over the block tiles that hold their pixels — the frame recorder's
-//   resolve has listed them; otherwise a classification launch over the material-id plane lists them first —,
-//   only full-class materials: the TEX = 2 launch alone, sweeping the rect like an untextured pass.
 // One launch of shade_kernel<TRANSMISSIVE, ., TEX, .>: RGBA16F or RGBA32F target; planes, or (RGBA16F inside the frame
 // recorder) the rasteriser's visibility words.
 template <bool TRANSMISSIVE, int TEX>
@@ -646,64 +629,14 @@ void launch_shade(const tr_launch& L, bool half, dim3 grid, dim3 block, hipStrea
 }
 
 template <bool TRANSMISSIVE>
-tr_status launch_textured(tr_context* ctx, tr_launch& L, const tr_gbuffer* g, bool half, dim3 grid, dim3 block,
-                          hipStream_t stream) {
-    // the full-class launch: its kTexMid build when no full-class material binds a slot beyond base colour,
-    // metallic-roughness and normal map (the transmission / thickness slots do not exist for the opaque pass)
+void launch_textured(tr_context* ctx, const tr_launch& L, bool half, dim3 grid, dim3 block, hipStream_t stream) {
+    // ONE launch whatever classes the uploaded materials mix (tr_kernels.h, TEX).  With a full-class material: its kTexAllMid
+    // build when none binds a slot beyond base colour, metallic-roughness and normal map (the transmission / thickness
+    // slots do not exist for the opaque pass)
+    if (!ctx->any_full_textured) return launch_shade<TRANSMISSIVE, kTexLite>(L, half, grid, block, stream);
     const bool mid = (ctx->full_slots & ~(TRANSMISSIVE ? kSlotsMid : (kSlotsMid | 0x30u))) == 0u && !ctx->no_mid_class;
-    if (ctx->any_plain_or_lite && ctx->any_full_textured && !(ctx->split_classes & (TRANSMISSIVE ? 2u : 1u))) {
-        // every class in ONE launch (kTexAll): the full-class pixel holds no more registers than the lite one
-        L.tile_list = L.tile_list_count = nullptr;
-        if (mid) launch_shade<TRANSMISSIVE, kTexAllMid>(L, half, grid, block, stream);
-        else launch_shade<TRANSMISSIVE, kTexAll>(L, half, grid, block, stream);
-        return TR_OK;
-    }
-    if (ctx->any_plain_or_lite) {
-        if (ctx->any_full_textured && L.tile_list) {   // (the frame recorder's buffers) the TEX = 1 launch lists the tiles itself
-            L.list_build = const_cast<uint32_t*>(L.tile_list);
-            L.list_build_count = const_cast<uint32_t*>(L.tile_list_count);
-        }
-        launch_shade<TRANSMISSIVE, kTexLite>(L, half, grid, block, stream);
-        L.list_build = L.list_build_count = nullptr;
-        if (!ctx->any_full_textured) return TR_OK;
-        if (!L.tile_list) {
-            const size_t tiles = (size_t)L.fp.tiles_x * L.fp.tiles_y;
-            if (tiles + 1u > ctx->class_list_cap) {
-                TR_HIP(ctx, hipStreamSynchronize(stream));
-                (void)hipFree(ctx->d_class_list);
-                ctx->d_class_list = nullptr;
-                ctx->class_list_cap = 0;
-                TR_HIP(ctx, hipMalloc((void**)&ctx->d_class_list, (tiles + 1u) * 4u));
-                ctx->class_list_cap = tiles + 1u;
-            }
-            TR_HIP(ctx, hipMemsetAsync(ctx->d_class_list, 0, 4u, stream));
-            tr_classify_params cp;
-            cp.g_width = L.fp.g_width;
-            cp.g_origin_x = L.fp.g_origin_x;
-            cp.g_origin_y = L.fp.g_origin_y;
-            cp.rect_x0 = L.fp.rect_x0;
-            cp.rect_y0 = L.fp.rect_y0;
-            cp.rect_x1 = L.fp.rect_x1;
-            cp.rect_y1 = L.fp.rect_y1;
-            cp.tiles_x = L.fp.tiles_x;
-            hipLaunchKernelGGL(classify_tiles_kernel, dim3(L.fp.tiles_x, L.fp.tiles_y), dim3(256), 0, stream,
-                               (const uint32_t*)g->material_id, cp,
-                               reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctx->d_dmats) + offsetof(tr_dmat, flags)),
-                               (uint32_t)(sizeof(tr_dmat) / 4u), ctx->num_materials, ctx->d_class_list + 1, ctx->d_class_list);
-            L.tile_list = ctx->d_class_list + 1;
-            L.tile_list_count = ctx->d_class_list;
-        }
-        // as many waves as the chip holds of this kernel (4-5 per SIMD), each striding over the list
-        const dim3 grid2(ctx->num_cus * 20u);
-        if (mid) launch_shade<TRANSMISSIVE, kTexMid>(L, half, grid2, block, stream);
-        else launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid2, block, stream);
-        return TR_OK;
-    }
-    L.fp.solo_full = 1u;
-    L.tile_list = L.tile_list_count = nullptr;
-    if (mid) launch_shade<TRANSMISSIVE, kTexMid>(L, half, grid, block, stream);
-    else launch_shade<TRANSMISSIVE, kTexFull>(L, half, grid, block, stream);
-    return TR_OK;
+    if (mid) launch_shade<TRANSMISSIVE, kTexAllMid>(L, half, grid, block, stream);
+    else launch_shade<TRANSMISSIVE, kTexAll>(L, half, grid, block, stream);
 }
 
 bool tables_ready(const tr_context* ctx, bool need_lut) {
@@ -764,8 +697,6 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
             ctx->num_cus = (uint32_t)prop.multiProcessorCount;
         }
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
-        if (const char* e = std::getenv("TR_SPLIT_CLASSES"))
-            ctx->split_classes = std::strcmp(e, "opaque") == 0 ? 1u : std::strcmp(e, "transmissive") == 0 ? 2u : 3u;
         ctx->no_mid_class = std::getenv("TR_NO_MID_CLASS") != nullptr;   // tests only: the full-class launch's general build
         if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));  // tuning only
     }
@@ -809,7 +740,6 @@ tr_status tr_context_destroy(tr_context* ctx) {
     (void)hipFree(ctx->d_lut_lines);
     (void)hipFree(ctx->d_levels);
     (void)hipFree(ctx->d_slice_thr);
-    (void)hipFree(ctx->d_class_list);
     (void)hipFree(ctx->d_cluster_x);
     (void)hipFree(ctx->d_cluster_y_term);
     (void)hipFree(ctx->d_tex_arena);
@@ -847,7 +777,7 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
     if (!ctx || !materials_host || count == 0) return TR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
-    bool any_textured = false, any_full = false, any_other = false;
+    bool any_textured = false, any_full = false;
     uint32_t full_slots = 0;
     int32_t max_id = -1;
     for (uint32_t i = 0; i < count; ++i) {
@@ -871,12 +801,10 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
         // the same rule as digest_materials_kernel's lite class (flags bit 3)
         const bool full = textured && !(only_diffuse && materials_host[i].metallic_factor == 0.0f);
         any_full |= full;
-        any_other |= !full;
         if (full) full_slots |= slots;
     }
     ctx->any_textured = any_textured;
     ctx->any_full_textured = any_full;
-    ctx->any_plain_or_lite = any_other;
     ctx->full_slots = full_slots;
     ctx->max_texture_id = max_id;
     if (count > ctx->cap_materials) {
@@ -1187,8 +1115,7 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
 }  // extern "C"
 
 namespace {
-// The rasteriser's per-frame-size buffers: both layers' visibility words, behind them the two tile coverage maps, the two
-// counters of the full-class tile lists, then the lists.
+// The rasteriser's per-frame-size buffers: both layers' visibility words, behind them the two tile coverage maps.
 tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
     const size_t npix = (size_t)w * h;
     if (npix > ctx->vis_pixels) {
@@ -1197,7 +1124,7 @@ tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
         ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
         ctx->vis_pixels = 0;
         ctx->d_tile_cover[0] = ctx->d_tile_cover[1] = nullptr;
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 4u * (npix / 64u + 65536u + 16384u) * 4u + 64u));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 2u * (npix / 64u + 65536u + 16384u) * 4u + 64u));
         ctx->vis_pixels = npix;
         ctx->vis_clean = false;
     }
@@ -1210,16 +1137,12 @@ tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
     const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
     ctx->d_tile_cover[0] = (uint32_t*)(ctx->d_vis[0] + 2u * npix);
     ctx->d_tile_cover[1] = ctx->d_tile_cover[0] + cover_tiles;
-    ctx->d_tile_list_counts = ctx->d_tile_cover[1] + cover_tiles;
-    ctx->d_tile_list[0] = ctx->d_tile_list_counts + 2u;
-    ctx->d_tile_list[1] = ctx->d_tile_list[0] + cover_tiles;
     return TR_OK;
 }
-// what a frame zeroes before rasterising: the maps and the two counters, rounded up to whole 16-byte vectors (the round-up
-// reaches into the first list, which is rebuilt every frame)
+// what a frame zeroes before rasterising: the maps, rounded up to whole 16-byte vectors (into the allocation's slack)
 inline size_t cover_clear_bytes(uint32_t w, uint32_t h) {
     const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
-    return ((2u * cover_tiles + 2u) * 4u + 15u) & ~(size_t)15u;
+    return (2u * cover_tiles * 4u + 15u) & ~(size_t)15u;
 }
 
 // The work buffers of both layers as the front-end kernels take them (after ensure_vis_buffers).
@@ -1285,7 +1208,6 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     at.textures = ctx->d_textures;
     at.tex_arena = ctx->d_tex_arena;
     at.num_textures = ctx->num_textures;
-    const size_t cap = ctx->work_capacity;
     tr_two_layers two;
     fill_two_layers(ctx, draws, targets, two);
     // The visibility buffers are zero on entry: filled once after (re)allocation, and every resolve zeroes the words its
@@ -1468,9 +1390,8 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
         L.mip0 = (uint2*)opaque_mip0_out;
         L.mip1 = (L.vis && L.mip0 && format == TR_FORMAT_RGBA16F) ? (uint2*)ctx->mip1_hint : nullptr;   // (the frame recorder)
         const bool half = format == TR_FORMAT_RGBA16F;
-        if (ctx->any_textured) {   // one launch per material class (see launch_textured)
-            const tr_status ls = launch_textured<false>(ctx, L, g, half, grid, block, stream);
-            if (ls != TR_OK) return ls;
+        if (ctx->any_textured) {
+            launch_textured<false>(ctx, L, half, grid, block, stream);
         } else {
             launch_shade<false, kTexNone>(L, half, grid, block, stream);
         }
@@ -1628,9 +1549,8 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
         L.pyramid = (const uint2*)p->texels;
         L.hdr = hdr_inout;
         const bool half = format == TR_FORMAT_RGBA16F;
-        if (ctx->any_textured) {   // one launch per material class (see launch_textured)
-            const tr_status ls = launch_textured<true>(ctx, L, g, half, grid, block, stream);
-            if (ls != TR_OK) return ls;
+        if (ctx->any_textured) {
+            launch_textured<true>(ctx, L, half, grid, block, stream);
         } else {
             launch_shade<true, kTexNone>(L, half, grid, block, stream);
         }
@@ -2183,8 +2103,6 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     {
         zone_scope z(rec, "main opaque");
         ctx->cover_hint = ctx->d_tile_cover[0];
-        ctx->list_hint = ctx->d_tile_list[0];
-        ctx->list_count_hint = ctx->d_tile_list_counts;
         ctx->vis_hint = use_vis ? ctx->d_vis[0] : nullptr;
         ctx->planes_hint = ctx->d_tri_planes;
         ctx->vis_front_hint = use_vis ? ctx->d_vis[1] : nullptr;
@@ -2192,7 +2110,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->mip1_hint = fused_level1 ? (void*)((uint2*)f->pyramid.texels + f->pyramid.level_offset[1]) : nullptr;
         st = tr_shade_opaque(ctx, &layers[0], f->uniforms, f->push, f->hdr, f->hdr_format, f->pyramid.texels, whole, stream);
         ctx->mip1_hint = nullptr;
-        ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
+        ctx->cover_hint = nullptr;
         ctx->vis_hint = nullptr;
         ctx->planes_hint = nullptr;
         ctx->vis_front_hint = nullptr;
@@ -2207,12 +2125,10 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     {
         zone_scope z(rec, "opaque transmissive objects");
         ctx->cover_hint = ctx->d_tile_cover[1];
-        ctx->list_hint = ctx->d_tile_list[1];
-        ctx->list_count_hint = ctx->d_tile_list_counts + 1;
         ctx->vis_hint = use_vis ? ctx->d_vis[1] : nullptr;
         ctx->planes_hint = ctx->d_tri_planes + ctx->work_capacity;
         st = tr_shade_transmission(ctx, &layers[1], f->uniforms, f->push, &f->pyramid, f->hdr, f->hdr_format, whole, stream);
-        ctx->cover_hint = ctx->list_hint = ctx->list_count_hint = nullptr;
+        ctx->cover_hint = nullptr;
         ctx->vis_hint = nullptr;
         ctx->planes_hint = nullptr;
     }
