@@ -1522,6 +1522,9 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         if constexpr (VIS) {
             // (whole-frame launches only: the rect is the frame, its pitch the visibility buffer's)
             const unsigned long long key = ld<unsigned long long>(F->vis, gpix * 8u);
+            // (the cluster table entries do not depend on the word: requested with it, ahead of the triangle's planes)
+            t.cluster_x = (uint32_t)ld<uint16_t>(F->cluster_x, cx * 2u);
+            t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
             t.uv = float2{0.f, 0.f};
@@ -1533,8 +1536,6 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 if constexpr (TEXTURED) t.uv = float2{v.uv[0], v.uv[1]};
                 t.mat = v.material_id;
             }
-            t.cluster_x = (uint32_t)ld<uint16_t>(F->cluster_x, cx * 2u);
-            t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
             return;
         }
         t.mat = ld_plane<uint32_t, (kPlanesNt & 4u) != 0u>(F->material_id, gpix * 4u);
