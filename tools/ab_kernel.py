@@ -53,7 +53,7 @@ ts.sort()
 res = {"p50": ts[len(ts) // 2], "p10": ts[0], "min": ts[0]}
 try:   # -DTR_TIMING=1 builds: per-wave wait cycles (100 MHz s_memtime ticks) of one launch
     fn = r.lib.tr_debug_read_timing
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 12)()
     fn(buf)
     r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr); torch.cuda.synchronize()
     fn(buf)

@@ -42,5 +42,15 @@ for _ in range(8):
     b.record(); b.synchronize(); ts.append(a.elapsed_time(b) / 20)
 ts.sort()
 t = ts[len(ts) // 2]
+if hasattr(r.lib, "tr_debug_read_timing") and os.environ.get("TR_AB_LIB"):   # a -DTR_TIMING=1 build: where the shading waves wait
+    import ctypes as C
+    buf = (C.c_ulonglong * 12)()
+    torch.cuda.synchronize(); r.lib.tr_debug_read_timing(buf)
+    for _ in range(10): frame()
+    torch.cuda.synchronize(); r.lib.tr_debug_read_timing(buf)
+    w0, w1, w2, total, tiles, waves = list(buf)[:6]
+    print(f"shading waves of 10 frames (both passes), cycles per tile and wave: inputs wait {w0 / tiles:.0f}, cluster lists {w1 / tiles:.0f}, "
+          f"taps + LUT {w2 / tiles:.0f}, texture front end {buf[8] / tiles:.0f}, light loops {buf[9] / tiles:.0f}, whole tile {total / tiles:.0f}; "
+          f"{tiles / (waves & 0xFFFFFFFF):.2f} tiles per wave")
 print(f"{name} {w}x{h}, {len(geometry['index']) // 3} triangles: {t * 1e3:.1f} us per frame ({1e3 / t:.0f} frames/s), "
       f"culling -> rasteriser -> opaque -> mips -> transmissive -> tonemap, one tr_record_frame call per frame")

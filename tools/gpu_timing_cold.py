@@ -9,7 +9,7 @@ _lib.LIB_PATH = os.path.abspath(sys.argv[1])          # experiments only (the ti
 import bench
 wl = bench.PassWorkload(0, 3840, 2160, sets=4, split=1)
 fn = wl.r.lib.tr_debug_read_timing
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()
 for rotate in (True, False):
     wl.ramp(0.1)
     torch.cuda.synchronize(); fn(buf)

@@ -1137,8 +1137,10 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
         tile_phase<3>();
         return finish();
     };
+    TR_PROBE_SINCE(t_lights)
     lights_phase();   // the sun
     punctual();
+    TR_PROBE_WAITED(4, t_lights)
     after_lights();   // (a per-lane record: what only the tail reads comes back from LDS, see shade_pixel_textured)
     return tail();
 }
@@ -1369,6 +1371,7 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
     cdtex* t = as_constant(L->textures) + mi->textures.diffuse;
     tex_geom g;
     tex_taps taps;
+    TR_PROBE_SINCE(t_tex)
     tex_geom_compute(g, t, uv.x, uv.y, duv);
     const bool srgb = t->srgb != 0u;
     lite_dmat lm;
@@ -1387,6 +1390,7 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
     // The colour is first USED at the end of the pixel; left to itself the optimiser sinks the whole filter down there
     // and keeps the eight taps, their weights and the decode look-ups alive across the light loop (+40 registers).
     asm volatile("" : "+v"(lm.diffuse[0]), "+v"(lm.diffuse[1]), "+v"(lm.diffuse[2]));
+    TR_PROBE_WAITED(3, t_tex)
     return shade_pixel<TRANSMISSIVE, const lite_dmat*>(L, &lm, material, pd, ns, lane, cl TR_PROBE_ARGS);
 }
 
@@ -1612,8 +1616,8 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     tile_regs cur;
     while (j < wave_tiles) {
         tile_phase<0>();
+        TR_PROBE_SINCE(t_fetch)   // (from before the fetch: a VIS tile's inputs are two dependent round trips inside it)
         fetch(j, cur);
-        TR_PROBE_SINCE(t_fetch)
         TR_PROBE_WAITED(0, t_fetch)
         TR_PROBE_TILE_DONE
         claunch* S = launder(L);

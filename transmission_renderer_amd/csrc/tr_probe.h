@@ -6,7 +6,8 @@
 //                       (synthetic inputs), bit7 no stores
 //   -DTR_PROBE_MASK=n   the same phases compiled out (register-pressure probes, tools/kernel_stats.py)
 //   -DTR_TIMING=1       every wave adds the cycles it waited for (0) the planes, (1) the cluster lists, (2) taps + LUT, (3)
-//                       its loop time, (4) tiles into tr_timing_counters (tr_debug_read_timing; tools/gpu_timing_cold.py)
+//                       its loop time, (4) tiles into tr_timing_counters (tr_debug_read_timing; tools/gpu_timing_cold.py);
+//                       slots 8 / 9: the time in a textured material's sampling front end / in the light loops
 #pragma once
 
 #ifndef TR_ABLATION
@@ -23,15 +24,15 @@
 
 #if TR_TIMING
 namespace tr {
-__device__ unsigned long long tr_timing_counters[8][1024];   // spread over 1024 slots: same-address atomics serialise
+__device__ unsigned long long tr_timing_counters[12][1024];   // spread over 1024 slots: same-address atomics serialise
 __device__ __forceinline__ unsigned long long tr_now() { return __builtin_amdgcn_s_memtime(); }
 __device__ __forceinline__ void tr_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-struct tr_timer { unsigned long long wait[3]; };
+struct tr_timer { unsigned long long wait[5]; };
 }  // namespace tr
 #define TR_PROBE_ARGS_DECL , tr_timer& timer
 #define TR_PROBE_ARGS , timer
 #define TR_PROBE_WAVE_BEGIN                                                    \
-    tr_timer timer = {{0ull, 0ull, 0ull}};                                     \
+    tr_timer timer = {{0ull, 0ull, 0ull, 0ull, 0ull}};                                     \
     unsigned long long tiles_done = 0;                                         \
     const unsigned long long t_loop = tr_now();                                \
     const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();   /* constant 100 MHz */
@@ -51,6 +52,8 @@ struct tr_timer { unsigned long long wait[3]; };
         atomicAdd(&tr_timing_counters[5][blockIdx.x & 1023u], 1ull);                                             \
         atomicMax(&tr_timing_counters[6][blockIdx.x & 1023u], tr_now() - t_loop);                                \
         atomicAdd(&tr_timing_counters[7][blockIdx.x & 1023u], __builtin_amdgcn_s_memrealtime() - t_real);        \
+        atomicAdd(&tr_timing_counters[8][blockIdx.x & 1023u], timer.wait[3]);                                    \
+        atomicAdd(&tr_timing_counters[9][blockIdx.x & 1023u], timer.wait[4]);                                    \
     }
 #else
 #define TR_PROBE_ARGS_DECL
@@ -78,10 +81,10 @@ struct tr_timer { unsigned long long wait[3]; };
     if (const char* e_ = std::getenv("TR_GRID_QUARTERS")) (bpx) = (bpx) / tr::kGridRounds * (uint32_t)std::atoi(e_) / 4u;
 #if TR_TIMING
 // (not declared in include/tr_shade.h) reads and clears the kernels' wait-cycle counters
-extern "C" int32_t tr_debug_read_timing(unsigned long long out[8]) {
-    static unsigned long long host[8][1024];
+extern "C" int32_t tr_debug_read_timing(unsigned long long out[12]) {
+    static unsigned long long host[12][1024];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tr::tr_timing_counters), sizeof(host)) != hipSuccess) return -1;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 12; ++k) {
         out[k] = 0;
         for (int i = 0; i < 1024; ++i) out[k] += host[k][i];
     }
