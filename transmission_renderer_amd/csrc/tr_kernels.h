@@ -1467,8 +1467,14 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     __shared__ float lds_park[TEX >= kTexFull ? kParkedValues * 64u : 64u];
     const uint32_t lane = threadIdx.x;   // one wave per workgroup
     if constexpr (TEXTURED) {
-        for (uint32_t i = lane; i < 256u; i += 64u) lds_srgb[i] = L->srgb_to_linear[i];
-        __syncthreads();
+        // The sRGB decode table goes global -> LDS without passing through registers (global_load_lds, 4 x 64 dwords) and
+        // is not waited for here: the wave's first wait is for its first tile's inputs, requested behind these transfers,
+        // and vector memory returns in order — a wave's start costs one round trip less (a frame is ~24 000 waves of ~5 tiles).
+        const float* table = L->srgb_to_linear;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(table + k * 64u + lane),
+                                             (__attribute__((address_space(3))) void*)(lds_srgb + k * 64u), 4, 0, 0);
     }
     const uint32_t lx = lane & (kWaveTileW - 1u), ly = lane / kWaveTileW;   // position inside the wave's tile
     // (full-class kernels, one wave per workgroup: the lane index is derived where it is used — wave_lane — instead of
