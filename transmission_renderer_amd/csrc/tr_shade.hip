@@ -1943,7 +1943,7 @@ tr_status tr_tonemap(tr_context* ctx, const void* hdr, uint32_t width, uint32_t 
     const uint32_t n = width * height;
     if (((uintptr_t)hdr & 15u) || ((uintptr_t)out_rgba8 & 7u)) return TR_ERR_INVALID_ARGUMENT;   // 2 pixels per thread
     hipLaunchKernelGGL(tonemap_kernel, dim3((n + 511u) / 512u), dim3(256), 0, stream, (const uint2*)hdr,
-                       (uint32_t*)out_rgba8, n, *params, (int)bgra);
+                       (uint32_t*)out_rgba8, n, *params, (int)bgra, params->saturation / params->cross_saturation);
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
@@ -1956,7 +1956,7 @@ tr_status tr_tonemap_rgb8(tr_context* ctx, const void* hdr, uint32_t width, uint
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(tonemap_rgb8_kernel, dim3((n + 1023u) / 1024u), dim3(256), 0, stream, (const uint2*)hdr, (uint32_t*)out_rgb8, n,
-                       *params, (int)bgra);
+                       *params, (int)bgra, params->saturation / params->cross_saturation);
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
@@ -2145,7 +2145,8 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         tt.height = h;
         tt.tiles_x = (w + 63u) / 64u;
         hipLaunchKernelGGL(tonemap_tiles_kernel, dim3((tt.tiles_x + 1u) / 2u, (h + 3u) / 4u), dim3(256), 0, (hipStream_t)stream,
-                           (const uint2*)f->hdr, (uint32_t*)f->ldr_out, *f->tonemap, (int)f->bgra, tt);
+                           (const uint2*)f->hdr, (uint32_t*)f->ldr_out, *f->tonemap, (int)f->bgra, tt,
+                           f->tonemap->saturation / f->tonemap->cross_saturation);
         TR_HIP(ctx, hipGetLastError());
         st = TR_OK;
     }
