@@ -48,6 +48,20 @@ for n in (1, 2, 4, 8):
         for _ in range(400): fn()
         b.record(); torch.cuda.synchronize()
         res[name] = round(a.elapsed_time(b) / 400 * 1e3, 2)
+        # the same launches replayed from a HIP graph: no host call between them — what the GPU alone needs per launch
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            for _ in range(8): fn()
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(100): fn()
+            graph.replay(); side.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(side)
+            for _ in range(4): graph.replay()
+            b.record(side); side.synchronize()
+        res[name + "_graph"] = round(a.elapsed_time(b) / 400 * 1e3, 2)
     out[f"1/{n}"] = dict(res, rows=y1 - y0)
 os.environ["TR_ABLATE"] = "0"
 whole = out["1/1"]["band"]
