@@ -519,6 +519,19 @@ tr_status tr_transmission_btdf(tr_context* ctx, const void* params_dev, uint32_t
  * params_dev = tr_ibl_volume_refraction_params[count], rgb_dev = float[count][3]. */
 tr_status tr_ibl_volume_refraction(tr_context* ctx, const void* params_dev, uint32_t count, const tr_pyramid* framebuffer,
                                    void* rgb_dev, void* stream);
+/* ibl_volume_refraction<FSamp, GSamp> with the CALLER's samplers (:292-299).  A closure cannot cross a C ABI onto the device,
+ * so the generic function is offered as the two halves its closures cut it into:
+ *   tr_ibl_volume_refraction_requests: what the function asks of its closures (:326-341) — requests_dev = float[count][5]:
+ *       framebuffer_sampler's arguments texture_coords.x, texture_coords.y, framebuffer_lod, then ggx_lut_sampler's
+ *       normal_dot_view, perceptual_roughness;
+ *   tr_ibl_volume_refraction_resolve: the rest of the function (:338-353) given the closures' answers —
+ *       framebuffer_rgb_dev = float[count][3] (Vec3 of framebuffer_sampler), lut_ab_dev = float[count][2] (Vec2 of
+ *       ggx_lut_sampler) -> rgb_dev = float[count][3].
+ * tr_ibl_volume_refraction above is this pair with the reference caller's own closures in between. */
+tr_status tr_ibl_volume_refraction_requests(tr_context* ctx, const void* params_dev, uint32_t count, void* requests_dev,
+                                            void* stream);
+tr_status tr_ibl_volume_refraction_resolve(tr_context* ctx, const void* params_dev, uint32_t count,
+                                           const void* framebuffer_rgb_dev, const void* lut_ab_dev, void* rgb_dev, void* stream);
 /* light_direction_and_attenuation (:12-23): two float[count][3] arrays in, tr_light_direction[count] out. */
 tr_status tr_light_direction_and_attenuation(tr_context* ctx, const void* fragment_position_dev,
                                              const void* light_position_dev, uint32_t count, void* out_dev, void* stream);

@@ -90,6 +90,81 @@ def test_ibl_volume_refraction(api, ggx_lut):
         np.testing.assert_array_equal(api.ibl_volume_refraction(p[:n], pyr).cpu().numpy(), got[:n])
 
 
+def test_ibl_volume_refraction_with_the_callers_closures(api, ggx_lut):
+    """ibl_volume_refraction<FSamp, GSamp> (:292-299) as its two halves.  (1) The requests against an fp64 restatement of
+    :248-268 / :326-341; (2) with closures that return constants, the resolve equals the fused function run on a
+    constant-colour pyramid and a constant LUT (the pinned path) — the two must agree to rounding; (3) arbitrary closures
+    against an fp64 restatement of :338-353."""
+    from transmission_renderer_amd.renderer import OpaquePyramid
+    w, h = 320, 200
+    p = glam_cases.ibl_params(20_000, w, h)
+    dev = api.r.device
+    seen = {}
+
+    def fs(uv, lod):
+        seen["uv"], seen["lod"] = uv.cpu().numpy().astype(np.float64), lod.cpu().numpy().astype(np.float64)
+        return torch.stack([0.5 + 0.5 * torch.sin(7.0 * uv[:, 0]), 0.5 + 0.5 * torch.cos(5.0 * uv[:, 1]), 0.1 * lod + 0.2], dim=1)
+
+    def gs(nov, rough):
+        seen["nov"], seen["rough"] = nov.cpu().numpy().astype(np.float64), rough.cpu().numpy().astype(np.float64)
+        return torch.stack([0.9 - 0.5 * rough, 0.05 + 0.1 * nov.abs()], dim=1)
+
+    got = api.ibl_volume_refraction_with(p, fs, gs).cpu().numpy().astype(np.float64)
+    # (1) the requests
+    mp = p["material_params"]
+    n, v = p["normal"].astype(np.float64), p["view"].astype(np.float64)
+    ior = mp["index_of_refraction"].astype(np.float64)
+    eta = 1.0 / ior
+    ndi = -(n * v).sum(1)                                            # normal . incident, incident = -view
+    k = 1.0 - eta ** 2 * (1.0 - ndi ** 2)
+    ok = k > 1e-6
+    refr = eta[:, None] * -v - (eta * ndi + np.sqrt(np.where(ok, k, 1.0)))[:, None] * n
+    refr /= np.linalg.norm(refr, axis=1, keepdims=True)
+    length = (p["thickness"] * p["model_scale"]).astype(np.float64)
+    exit_point = p["position"].astype(np.float64) + refr * length[:, None]
+    M = p["proj_view_matrix"].astype(np.float64).reshape(-1, 4, 4)   # column-major: M[:, col, row]
+    clip = np.einsum("ncr,nc->nr", M, np.concatenate([exit_point, np.ones((len(p), 1))], axis=1))
+    ok &= np.abs(clip[:, 3]) > 1e-3
+    uv = (clip[:, :2] / clip[:, 3:4] + 1.0) / 2.0
+    lod = np.log2(p["framebuffer_size_x"].astype(np.float64)) * mp["perceptual_roughness"] * np.clip(ior * 2.0 - 2.0, 0.0, 1.0)
+    assert ok.mean() > 0.95
+    scale = np.maximum(np.abs(uv[ok]), 1.0)
+    assert (np.abs(seen["uv"][ok] - uv[ok]) / scale).max() <= 2e-4 and np.sqrt((((seen["uv"][ok] - uv[ok]) / scale) ** 2).mean()) <= 2e-5
+    assert np.abs(seen["lod"] - lod).max() <= 1e-5 * max(1.0, lod.max())
+    assert np.abs(seen["nov"] - (n * v).sum(1)).max() <= 1e-6 and np.abs(seen["rough"] - mp["perceptual_roughness"]).max() == 0.0
+    # (3) the rest of the function in fp64 from the closures' own answers
+    rgb = fs(torch.from_numpy(seen["uv"]).to(dev), torch.from_numpy(seen["lod"]).to(dev)).cpu().numpy().astype(np.float64)
+    ab = gs(torch.from_numpy(seen["nov"]).to(dev), torch.from_numpy(seen["rough"]).to(dev)).cpu().numpy().astype(np.float64)
+    finite = np.isfinite(p["attenuation_distance"])
+    coeff = np.where(finite[:, None], -np.log(p["attenuation_colour"].astype(np.float64)) / np.where(finite, p["attenuation_distance"], 1.0)[:, None], 0.0)
+    attenuated = np.exp(-coeff * length[:, None]) * rgb
+    base, spec_c = mp["diffuse_colour"].astype(np.float64), mp["specular_colour"].astype(np.float64)
+    metallic, spec_f = mp["metallic"].astype(np.float64)[:, None], mp["specular_factor"].astype(np.float64)[:, None]
+    f0d = (((ior - 1.0) / (ior + 1.0)) ** 2)[:, None]
+    dielectric = f0d * spec_c * spec_f
+    f0 = dielectric + (base - dielectric) * metallic                 # calculate_combined_f0 :425-431
+    f90 = spec_f + (1.0 - spec_f) * metallic                         # calculate_combined_f90 :433-435
+    want = (1.0 - (f0 * ab[:, 0:1] + f90 * ab[:, 1:2])) * attenuated * base
+    assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() <= 1e-5
+    # (2) constant closures == the fused function on a constant pyramid and a constant LUT
+    colour = np.array([0.75, 0.5, 0.25, 1.0], dtype=np.float16)
+    pyr = OpaquePyramid(w, h, dev)
+    pyr.texels.copy_(torch.from_numpy(np.broadcast_to(colour, (pyr.texels.shape[0], 4)).copy()).to(dev))
+    lut = np.zeros_like(ggx_lut)
+    lut[..., 0], lut[..., 1], lut[..., 3] = 204, 51, 255            # A = 0.8, B = 0.2 in every texel
+    api.r.upload_ggx_lut(lut)
+    try:
+        fused = api.ibl_volume_refraction(p, pyr).cpu().numpy()
+        const = api.ibl_volume_refraction_with(
+            p, lambda uv, lod: torch.tensor([0.75, 0.5, 0.25], device=dev).expand(uv.shape[0], 3),
+            lambda nov, rough: torch.tensor([204.0 / 255.0, 51.0 / 255.0], device=dev).expand(nov.shape[0], 2)).cpu().numpy()
+    finally:
+        api.r.upload_ggx_lut(ggx_lut)
+    both = np.isfinite(fused).all(axis=1)
+    assert both.mean() > 0.99
+    assert (np.abs(fused[both] - const[both]) / np.maximum(np.abs(fused[both]), 1.0)).max() <= 2e-6
+
+
 def test_small_functions(api):
     rng = np.random.default_rng(5)
     n = 100_000

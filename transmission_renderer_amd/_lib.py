@@ -21,7 +21,8 @@ SYMBOLS = (
     "tr_upload_geometry", "tr_rasterize", "tr_draw_scene",
     "tr_write_cluster_data", "tr_assign_lights_to_clusters", "tr_shade_opaque",
     "tr_generate_mips", "tr_shade_transmission", "tr_lottes_defaults", "tr_bake_lottes_params", "tr_tonemap", "tr_record_frame", "tr_record_frame_timed",
-    "tr_basic_brdf", "tr_transmission_btdf", "tr_ibl_volume_refraction", "tr_light_direction_and_attenuation", "tr_d_ggx",
+    "tr_basic_brdf", "tr_transmission_btdf", "tr_ibl_volume_refraction", "tr_ibl_volume_refraction_requests", "tr_ibl_volume_refraction_resolve",
+    "tr_light_direction_and_attenuation", "tr_d_ggx",
     "tr_v_smith_ggx_correlated", "tr_fresnel_schlick", "tr_compute_f0", "tr_get_depth_slice", "tr_depth_slice_thresholds",
     "tr_band_rows", "tr_comm_unique_id", "tr_comm_create", "tr_comm_from_nccl", "tr_comm_destroy", "tr_comm_last_error",
     "tr_allgather_frame", "tr_set_strips", "tr_strip_of_rank", "tr_allgather_strips",
@@ -160,6 +161,10 @@ def load() -> C.CDLL:
     lib.tr_tonemap_rgb8.argtypes = [vp, vp, u32, u32, C.POINTER(wire.TonemapParams), vp, i32, vp]
     lib.tr_ibl_volume_refraction.restype = i32
     lib.tr_ibl_volume_refraction.argtypes = [vp, vp, u32, C.POINTER(wire.Pyramid), vp, vp]
+    lib.tr_ibl_volume_refraction_requests.restype = i32
+    lib.tr_ibl_volume_refraction_requests.argtypes = [vp, vp, u32, vp, vp]
+    lib.tr_ibl_volume_refraction_resolve.restype = i32
+    lib.tr_ibl_volume_refraction_resolve.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     if lib.tr_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.tr_abi_version()} != 1")
     _lib = lib

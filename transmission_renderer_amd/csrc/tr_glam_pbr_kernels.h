@@ -105,41 +105,39 @@ struct tr_ibl_tables {
     uint32_t lut_width, lut_height, lut_stride;
 };
 
-__global__ __launch_bounds__(256) void ibl_volume_refraction_kernel(const tr_ibl_volume_refraction_params* __restrict__ params,
-                                                                    uint32_t count, const tr_ibl_tables t,
-                                                                    float* __restrict__ out) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    const bool live = i < count;
-    // (every lane of the wave runs the sampler: it splits the wave by mip level with ballots; the tail reads element 0)
-    const tr_ibl_volume_refraction_params p = load_element(params, live ? i : 0u);
-    lane_dmat lm;
-    digest_material_params(lm, p.material_params, t.lut_height, t.lut_stride);
+// The two halves the function's closures cut it into.  ibl_request: everything up to the closures' arguments (:326-341);
+// ibl_finish: everything behind their answers (:338-353).
+struct ibl_requests {
+    float tu, tv, lod;     // framebuffer_sampler(texture_coords, framebuffer_lod)
+    float nov, rough;      // ggx_lut_sampler(normal_dot_view, perceptual_roughness)
+    float len;             // ray_length (apply_volume_attenuation's transmission_distance)
+};
+__device__ __forceinline__ ibl_requests ibl_request(const tr_ibl_volume_refraction_params& p, const lane_dmat& lm) {
     const float* n = p.normal;
     const float* v = p.view;
-    const float nov_raw = dot3(n[0], n[1], n[2], v[0], v[1], v[2]);
+    ibl_requests q;
+    q.nov = dot3(n[0], n[1], n[2], v[0], v[1], v[2]);
     // refract(-v, n, ior) :248-256, unit length by construction; ray = that * thickness * model_scale :258-268
     const float eta = lm.eta;
-    const float k = fmaf(-eta * eta, fmaf(-nov_raw, nov_raw, 1.0f), 1.0f);
-    const float cn = fmaf(-eta, nov_raw, fast_sqrt(k));
-    const float len = p.thickness * p.model_scale;
-    const float ex = fmaf(fmaf(-eta, v[0], -cn * n[0]), len, p.position[0]);
-    const float ey = fmaf(fmaf(-eta, v[1], -cn * n[1]), len, p.position[1]);
-    const float ez = fmaf(fmaf(-eta, v[2], -cn * n[2]), len, p.position[2]);
+    const float k = fmaf(-eta * eta, fmaf(-q.nov, q.nov, 1.0f), 1.0f);
+    const float cn = fmaf(-eta, q.nov, fast_sqrt(k));
+    q.len = p.thickness * p.model_scale;
+    const float ex = fmaf(fmaf(-eta, v[0], -cn * n[0]), q.len, p.position[0]);
+    const float ey = fmaf(fmaf(-eta, v[1], -cn * n[1]), q.len, p.position[1]);
+    const float ez = fmaf(fmaf(-eta, v[2], -cn * n[2]), q.len, p.position[2]);
     const float* P = p.proj_view_matrix;
     const float cx = fmaf(P[8], ez, fmaf(P[4], ey, fmaf(P[0], ex, P[12])));
     const float cy = fmaf(P[9], ez, fmaf(P[5], ey, fmaf(P[1], ex, P[13])));
     const float cw = fmaf(P[11], ez, fmaf(P[7], ey, fmaf(P[3], ex, P[15])));
     const float hw = 0.5f * rcp(cw);
-    const float tu = fmaf(cx, hw, 0.5f), tv = fmaf(cy, hw, 0.5f);
-    const float lod = fast_log2((float)p.framebuffer_size_x) * m_rough_ior(lm);   // :334-335
-    pyramid_fetch pf;
-    pyramid_issue(pf, t.pyramid, as_constant(t.levels), t.pyr_levels, tu, tv, lod, lane);
-    lut_fetch lf;
-    uint32_t row0, row1;
-    lut_rows(lm.rough, t.lut_height, t.lut_stride, lf.fy, row0, row1);
-    lut_issue(lf, t.lut_pairs, (float)t.lut_width, row0, row1, nov_raw);
-    f3 T = pyramid_resolve(pf);
+    q.tu = fmaf(cx, hw, 0.5f);
+    q.tv = fmaf(cy, hw, 0.5f);
+    q.lod = fast_log2((float)p.framebuffer_size_x) * m_rough_ior(lm);   // :334-335
+    q.rough = lm.rough;
+    return q;
+}
+__device__ __forceinline__ void ibl_finish(const tr_ibl_volume_refraction_params& p, const lane_dmat& lm, f3 T, v2f AB, float len,
+                                           float* o) {
     if (!(p.attenuation_distance == __builtin_inff())) {   // apply_volume_attenuation :275-290
         const float att[3] = {p.attenuation_colour[0], p.attenuation_colour[1], p.attenuation_colour[2]};
         float tr[3];
@@ -152,13 +150,58 @@ __global__ __launch_bounds__(256) void ibl_volume_refraction_kernel(const tr_ibl
         T.y *= tr[1];
         T.z *= tr[2];
     }
-    const v2f AB = lut_resolve(lf, lf.fy);
     const float fb = lm.f90 * AB.y;
-    if (!live) return;
-    float* o = out + (size_t)i * 3u;
     o[0] = (1.0f - fmaf(lm.f0[0], AB.x, fb)) * T.x * lm.diffuse[0];
     o[1] = (1.0f - fmaf(lm.f0[1], AB.x, fb)) * T.y * lm.diffuse[1];
     o[2] = (1.0f - fmaf(lm.f0[2], AB.x, fb)) * T.z * lm.diffuse[2];
+}
+
+__global__ __launch_bounds__(256) void ibl_volume_refraction_kernel(const tr_ibl_volume_refraction_params* __restrict__ params,
+                                                                    uint32_t count, const tr_ibl_tables t,
+                                                                    float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool live = i < count;
+    // (every lane of the wave runs the sampler: it splits the wave by mip level with ballots; the tail reads element 0)
+    const tr_ibl_volume_refraction_params p = load_element(params, live ? i : 0u);
+    lane_dmat lm;
+    digest_material_params(lm, p.material_params, t.lut_height, t.lut_stride);
+    const ibl_requests q = ibl_request(p, lm);
+    pyramid_fetch pf;
+    pyramid_issue(pf, t.pyramid, as_constant(t.levels), t.pyr_levels, q.tu, q.tv, q.lod, lane);
+    lut_fetch lf;
+    uint32_t row0, row1;
+    lut_rows(lm.rough, t.lut_height, t.lut_stride, lf.fy, row0, row1);
+    lut_issue(lf, t.lut_pairs, (float)t.lut_width, row0, row1, q.nov);
+    const f3 T = pyramid_resolve(pf);
+    const v2f AB = lut_resolve(lf, lf.fy);
+    if (!live) return;
+    ibl_finish(p, lm, T, AB, q.len, out + (size_t)i * 3u);
+}
+
+// ibl_volume_refraction<FSamp, GSamp> with the CALLER's closures: the requests, then the rest given their answers.
+__global__ __launch_bounds__(256) void ibl_requests_kernel(const tr_ibl_volume_refraction_params* __restrict__ params, uint32_t count,
+                                                           float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const tr_ibl_volume_refraction_params p = load_element(params, i);
+    lane_dmat lm;
+    digest_material_params(lm, p.material_params, 1u, 0u);
+    const ibl_requests q = ibl_request(p, lm);
+    float* o = out + (size_t)i * 5u;
+    o[0] = q.tu; o[1] = q.tv; o[2] = q.lod; o[3] = q.nov; o[4] = q.rough;
+}
+__global__ __launch_bounds__(256) void ibl_resolve_kernel(const tr_ibl_volume_refraction_params* __restrict__ params, uint32_t count,
+                                                          const float* __restrict__ framebuffer_rgb, const float* __restrict__ lut_ab,
+                                                          float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const tr_ibl_volume_refraction_params p = load_element(params, i);
+    lane_dmat lm;
+    digest_material_params(lm, p.material_params, 1u, 0u);
+    const f3 T = {framebuffer_rgb[(size_t)i * 3u], framebuffer_rgb[(size_t)i * 3u + 1u], framebuffer_rgb[(size_t)i * 3u + 2u]};
+    const v2f AB = {lut_ab[(size_t)i * 2u], lut_ab[(size_t)i * 2u + 1u]};
+    ibl_finish(p, lm, T, AB, p.thickness * p.model_scale, out + (size_t)i * 3u);
 }
 
 // light_direction_and_attenuation (:12-23)

@@ -1618,6 +1618,28 @@ tr_status tr_ibl_volume_refraction(tr_context* ctx, const void* params, uint32_t
     return TR_OK;
 }
 
+tr_status tr_ibl_volume_refraction_requests(tr_context* ctx, const void* params, uint32_t count, void* requests, void* stream_) {
+    if (!batch_args_ok(ctx, count, {params, requests})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(ibl_requests_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_,
+                       (const tr_ibl_volume_refraction_params*)params, count, (float*)requests);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
+tr_status tr_ibl_volume_refraction_resolve(tr_context* ctx, const void* params, uint32_t count, const void* framebuffer_rgb,
+                                           const void* lut_ab, void* rgb, void* stream_) {
+    if (!batch_args_ok(ctx, count, {params, framebuffer_rgb, lut_ab, rgb})) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0) return TR_OK;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(ibl_resolve_kernel, dim3(batch_grid(count)), dim3(256), 0, (hipStream_t)stream_,
+                       (const tr_ibl_volume_refraction_params*)params, count, (const float*)framebuffer_rgb, (const float*)lut_ab,
+                       (float*)rgb);
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
+}
+
 tr_status tr_light_direction_and_attenuation(tr_context* ctx, const void* fragment_position, const void* light_position,
                                              uint32_t count, void* out, void* stream_) {
     if (!batch_args_ok(ctx, count, {fragment_position, light_position, out})) return TR_ERR_INVALID_ARGUMENT;

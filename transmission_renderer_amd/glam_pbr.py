@@ -73,6 +73,23 @@ class GlamPbr:
                                                         out.data_ptr(), self.r._stream()), "tr_ibl_volume_refraction")
         return out
 
+    def ibl_volume_refraction_with(self, params, framebuffer_sampler, ggx_lut_sampler) -> torch.Tensor:
+        """ibl_volume_refraction<FSamp, GSamp> (:292-299) with the CALLER'S closures: `framebuffer_sampler(uv (n, 2), lod (n,))
+        -> (n, 3)` and `ggx_lut_sampler(normal_dot_view (n,), perceptual_roughness (n,)) -> (n, 2)` are called once, on
+        device tensors, between the function's two halves (tr_ibl_volume_refraction_requests / _resolve)."""
+        p = self._records(params, wire.IBL_VOLUME_REFRACTION_PARAMS_DTYPE)
+        n = p.shape[0]
+        req = torch.empty((n, 5), dtype=torch.float32, device=self.r.device)
+        self.r._check(self.lib.tr_ibl_volume_refraction_requests(self.r._ctx, p.data_ptr(), n, req.data_ptr(), self.r._stream()),
+                      "tr_ibl_volume_refraction_requests")
+        rgb = framebuffer_sampler(req[:, 0:2], req[:, 2]).to(torch.float32).contiguous()
+        ab = ggx_lut_sampler(req[:, 3], req[:, 4]).to(torch.float32).contiguous()
+        assert rgb.shape == (n, 3) and ab.shape == (n, 2)
+        out = torch.empty((n, 3), dtype=torch.float32, device=self.r.device)
+        self.r._check(self.lib.tr_ibl_volume_refraction_resolve(self.r._ctx, p.data_ptr(), n, rgb.data_ptr(), ab.data_ptr(),
+                                                                out.data_ptr(), self.r._stream()), "tr_ibl_volume_refraction_resolve")
+        return out
+
     def light_direction_and_attenuation(self, fragment_position, light_position) -> torch.Tensor:
         """(:12-23): two (n, 3) arrays -> (n, 5): direction xyz, distance, attenuation"""
         f, l = self._floats(fragment_position, 3), self._floats(light_position, 3)
