@@ -2002,7 +2002,9 @@ struct tr_mip_tail_params {
     uint32_t first, levels;                  // produce levels first .. levels-1 (first >= 1)
     uint32_t offset[TR_MAX_MIP_LEVELS], width[TR_MAX_MIP_LEVELS], height[TR_MAX_MIP_LEVELS];
 };
-constexpr uint32_t kMipTailMaxTexels = 12288;   // first tail level must fit: 96 KiB + 24 KiB + ... of LDS
+// (a level of more than 4 096 texels is a launch of its own — downsample_kernel over as many workgroups as it takes: as the
+//  tail's first level the 120x67 level of a 4K frame kept ONE workgroup computing for 5 us; 4K frame 204 -> 200 us)
+constexpr uint32_t kMipTailMaxTexels = 4096;
 
 // One destination texel of a general LINEAR blit: taps and weights (downsample_kernel's arithmetic).
 struct blit_taps {
