@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
         // the signs of A and B; negative there = no pixel of the block is inside.  Exactly the blocks the per-pixel test
         // would find empty or a superset are visited: the result is unchanged.
         uint32_t blocks = (2u << (bend - bstart)) - 1u;   // bit b: block bstart + b
+        // the item's fragments tag the coverage words of the (at most two) 64-pixel tile columns it spans, upper and lower
+        // half: collected here (scalar) and written once behind the block loop instead of once per block
+        uint32_t cover_bits[2][2] = {{0u, 0u}, {0u, 0u}};
         if (bend - bstart >= 2u) {
             const float xl = (float)((bstart + (lane & 7u)) * 8u) + 0.5f, yl = (float)(by * 8u) + 0.5f;
             bool maybe = true;
@@ -378,12 +381,17 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             // conservative: a fragment that loses the depth test later has tagged its tile all the same).  The resolve
             // and the shading launches skip tiles by these words.
             const unsigned long long hits = ballot(hit);
-            if (hits != 0ull && lane == 0u) {
-                const uint32_t cover_w = (f.width + 63u) >> 6;
-                uint32_t* c = tile_cover + (size_t)(by * 2u) * cover_w + (bx >> 3);
-                const uint32_t bits = 1u | (rec.flags & 6u);
-                if ((uint32_t)hits != 0u) atomicOr(c, bits);
-                if ((uint32_t)(hits >> 32) != 0u) atomicOr(c + cover_w, bits);
+            const uint32_t col = (bx >> 3) - (bstart >> 3), bits = 1u | (rec.flags & 6u);
+            if ((uint32_t)hits != 0u) cover_bits[col][0] |= bits;
+            if ((uint32_t)(hits >> 32) != 0u) cover_bits[col][1] |= bits;
+        }
+        if (lane == 0u) {
+            const uint32_t cover_w = (f.width + 63u) >> 6;
+            uint32_t* c = tile_cover + (size_t)(by * 2u) * cover_w + (bstart >> 3);
+#pragma unroll
+            for (uint32_t col = 0; col < 2u; ++col) {
+                if (cover_bits[col][0] != 0u) atomicOr(c + col, cover_bits[col][0]);
+                if (cover_bits[col][1] != 0u) atomicOr(c + col + cover_w, cover_bits[col][1]);
             }
         }
       }
