@@ -13,7 +13,7 @@
 //   scan_draws     one workgroup: triangles per draw -> prefix, so triangle t of the layer's draw stream is known
 //   setup          one thread per triangle: vertex stage, clip-space edge functions, bounds, work-item count
 //   scan_items     work items per triangle -> prefix (chunk sums, prefix of the sums, per-chunk scan)
-//   raster         persistent waves; a work item is one 8-pixel-tall row of a triangle's bounds, at most 512 pixels
+//   raster         persistent waves; a work item is one 8-pixel-tall row of a triangle's bounds, at most 32 pixels
 //                  wide; a wave covers it in 8x8 pixel blocks and resolves visibility with one 64-bit atomicMax of
 //                  (depth bits << 32 | t) per covered pixel: reversed-Z GREATER, and among equal depths the
 //                  later-drawn triangle wins, independent of execution order (deterministic)
@@ -41,7 +41,10 @@ struct tr_layer_counts {      // written by scan_draws / scan_items, read by the
     uint32_t num_items;
 };
 
-constexpr uint32_t kItemWidthBlocks = 8u;    // a work item spans at most 8 8x8 blocks horizontally (short items balance)
+// (a work item spans at most 4 8x8 blocks horizontally: measured on the 4K mesh / glTF demo frames — 16: 207 / 205 us,
+//  8: 197 / 197, 4: 193 / 195, 3: 191 / 196, 2: 197 / 200, 1: 209 / 213; short items balance and hide each other's latency)
+constexpr uint32_t kItemWidthBlocks = 4u;
+constexpr uint32_t kItemTileColumns = (kItemWidthBlocks + 7u) / 8u + 1u;   // 64-pixel tile columns an item can span
 
 // ------------------------------------------------------------------------ block-wide exclusive scan
 // NT threads (1024, or 256 inside the frame's first launch); returns the exclusive prefix of `v` over the block and the
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
         uint32_t blocks = (2u << (bend - bstart)) - 1u;   // bit b: block bstart + b
         // the item's fragments tag the coverage words of the (at most two) 64-pixel tile columns it spans, upper and lower
         // half: collected here (scalar) and written once behind the block loop instead of once per block
-        uint32_t cover_bits[2][2] = {{0u, 0u}, {0u, 0u}};
+        uint32_t cover_bits[kItemTileColumns][2] = {};
         if (bend - bstart >= 2u) {
             const float xl = (float)((bstart + (lane & 7u)) * 8u) + 0.5f, yl = (float)(by * 8u) + 0.5f;
             bool maybe = true;
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             const uint32_t cover_w = (f.width + 63u) >> 6;
             uint32_t* c = tile_cover + (size_t)(by * 2u) * cover_w + (bstart >> 3);
 #pragma unroll
-            for (uint32_t col = 0; col < 2u; ++col) {
+            for (uint32_t col = 0; col < kItemTileColumns; ++col) {
                 if (cover_bits[col][0] != 0u) atomicOr(c + col, cover_bits[col][0]);
                 if (cover_bits[col][1] != 0u) atomicOr(c + col + cover_w, cover_bits[col][1]);
             }

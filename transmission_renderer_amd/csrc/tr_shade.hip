@@ -204,6 +204,8 @@ struct tr_context {
     std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
     bool no_mid_class = false;                  // TR_NO_MID_CLASS (tests only), read once at context creation
     uint32_t vis_grid_rounds = 3;               // see persistent_grid (TR_VIS_ROUNDS: tuning only)
+    uint32_t raster_wgs_per_cu = 6;             // raster_kernel's persistent grid: 4 -> 191 / 199 us (4K mesh / glTF demo frame), 6 -> 191 / 192,
+                                                // 8 -> 194 / 195, 12 -> 191 / 196, 16 -> 198 / 199 (TR_RASTER_WGS_PER_CU: tuning only)
 };
 
 namespace {
@@ -699,6 +701,7 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
         ctx->no_mid_class = std::getenv("TR_NO_MID_CLASS") != nullptr;   // tests only: the full-class launch's general build
         if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));  // tuning only
+        if (const char* e = std::getenv("TR_RASTER_WGS_PER_CU")) ctx->raster_wgs_per_cu = (uint32_t)std::max(1, std::atoi(e));  // tuning only
     }
     if (hipMalloc((void**)&ctx->d_front_ticket, 4u) != hipSuccess || hipMemset(ctx->d_front_ticket, 0, 4u) != hipSuccess ||
         hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
@@ -1246,7 +1249,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
             rl.tile_cover[layer] = ctx->d_tile_cover[layer];
             rl.enabled[layer] = ctx->max_triangles[layer] != 0u ? 1u : 0u;
         }
-        hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * 8u, 2), dim3(256), 0, stream, gv, fr, rl, at);
+        hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * ctx->raster_wgs_per_cu, 2), dim3(256), 0, stream, gv, fr, rl, at);
     }
     if (resolve) {
         hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u), dim3(256), 0, stream, fr, two,
