@@ -256,6 +256,14 @@ struct tr_launch {
     unsigned long long* vis_front;
     const uint32_t* cover_front;
     uint32_t* tap_excess;               // optional (tap window set): atomicMax of the level-0 rows a tap reached beyond the window
+    // VIS launches of a frame that is also presented (tr_record_frame with a tonemap target): the launch that writes a
+    // pixel's FINAL colour — the transmissive one, or the opaque one where no transmissive winner survives — tonemaps
+    // the RGBA16F value it stores (fragment_tonemap on the same bits) into `present`: the frame has no tonemap pass
+    // that reads the whole target back (99 MB of traffic at 4K, 17 us at the memory roofline)
+    uint32_t* present;
+    tr_tonemap_params present_params;
+    float present_e1;
+    int32_t present_bgra;
 };
 typedef const TR_CONSTANT tr_launch claunch;
 
@@ -1394,6 +1402,48 @@ __device__ __forceinline__ f3 shade_pixel_lite(claunch* L, uint32_t material, cd
     return shade_pixel<TRANSMISSIVE, const lite_dmat*>(L, &lm, material, pd, ns, lane, cl TR_PROBE_ARGS);
 }
 
+// ---- tonemap (SURVEY.md 8f row f5) ----------------------------------------------------------------------
+// fragment_tonemap (shader/src/lib.rs:683-697) + LottesTonemapper::tonemap (shader/src/tonemapping.rs:8-27);
+// the fullscreen triangle samples texel centres, so the input is the HDR texel itself.  pow = exp2(y log2 x).
+__device__ __forceinline__ float fast_pow(float x, float y) { return fast_exp2(y * fast_log2(x)); }
+
+// The sRGB target's encode (fixed function) of exp2(l), for l = log2 of a value already clamped to [0, 1] (l <= 0, -inf
+// for zero): one v_exp_f32 for either branch of the transfer function — 12.92 x below the knee, 1.055 x^(1/2.4) - 0.055 above.
+__device__ __forceinline__ uint32_t log2_to_srgb8(float l) {
+    const bool low = l <= -8.3192688f;                       // log2(0.0031308)
+    const float e = fast_exp2(low ? l : l * (1.0f / 2.4f));
+    const float v = low ? 12.92f * e : fmaf(1.055f, e, -0.055f);
+    return (uint32_t)fmaf(v, 255.0f, 0.5f);
+}
+
+// fragment_tonemap (shader/src/lib.rs:683-697, shader/src/tonemapping.rs:8-27) + the sRGB encode of the swapchain
+// format.  Two pixels per thread (16-byte loads, 8-byte stores).  The operator is a chain of powers: it is evaluated in
+// the log2 domain, so that consecutive powers share their logarithm — peak^a and (peak^a)^d both from log2(peak);
+// (ratio^cs * peak').clamp(0, 1) goes straight into the sRGB curve's own power as cs log2(ratio) + log2(peak') — 19
+// transcendental instructions per pixel instead of 26 (the kernel is bound by them), and fewer roundings.  Black pixels
+// (0 / 0 in the reference: NaN, which its min(1).max(0) turns into 1) come out the same way: log2(0) - log2(0) is NaN
+// and v_min_f32(NaN, 0) is 0.
+__device__ __forceinline__ uint32_t tonemap_pixel(uint32_t lo, uint32_t hi, const tr_tonemap_params& p, float e1, int bgra) {
+    const float r = h2f_lo(lo), g = h2f_hi(lo), b = h2f_lo(hi);
+    const float mx = fmaxf(r, fmaxf(g, b));
+    const float lmx = fast_log2(mx);
+    const float la = p.a * lmx;
+    const float z = fast_exp2(la);                                  // peak^a
+    const float tm = z * rcp(fmaf(fast_exp2(la * p.d), p.b, p.c));  // tonemap_inner: z / (z^d b + c)
+    const float ltm = fast_log2(tm);
+    const float t = fast_exp2(ltm * p.crosstalk);                   // tonemapped_max^crosstalk
+    const float c[3] = {r, g, b};
+    uint32_t out8[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float x = fast_exp2((fast_log2(c[k]) - lmx) * e1);          // (color / max)^(saturation / cross_saturation)
+        x = fmaf(1.0f - x, t, x);                                   // lerp(ratio, 1, tonemapped_max^crosstalk)
+        const float l = fmaf(fast_log2(x), p.cross_saturation, ltm);   // log2(ratio^cross_saturation * tonemapped_max)
+        out8[k] = log2_to_srgb8(fminf(l, 0.0f));                    // .min(ONE); .max(ZERO) is exp2's own range
+    }
+    return bgra ? (out8[2] | (out8[1] << 8) | (out8[0] << 16) | 0xFF000000u) : (out8[0] | (out8[1] << 8) | (out8[2] << 16) | 0xFF000000u);
+}
+
 // ------------------------------------------------------------------------ the shading kernel
 // Grid: 8 * k workgroups, k per XCD (hardware workgroup b runs on XCD b % 8), of one wave each, kGridRounds times what
 // is resident.  The 64x4-pixel block tiles of the rect are cut into 8
@@ -1700,18 +1750,25 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         j += gridDim.x >> 3;
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         const bool write = TRANSMISSIVE ? active : inside;
+        bool final_colour = true;   // (VIS) no later launch of the frame writes this pixel
         if constexpr (VIS) {
             // the reader of a visibility word leaves it zeroed for the next frame (see the template's comment)
-            if (active) st<unsigned long long>(launder(L)->vis, mad24(out_py, launder(L)->fp.width, out_px) * 8u, 0ull);
+            // (the zero is formed where it is stored: hoisted, it is a register pair held — or spilled — across the whole pixel)
+            unsigned long long zero = 0ull;
+            asm volatile("" : "+v"(zero));
+            if (active) st<unsigned long long>(launder(L)->vis, mad24(out_py, launder(L)->fp.width, out_px) * 8u, zero);
             if constexpr (!TRANSMISSIVE) {
                 // (scalar) a transmissive fragment landed in this tile: a pixel this launch shades knows its opaque depth —
-                // the transmissive winner stays only if it is nearer (depth GREATER, reversed Z)
-                if (cur.cover_front != 0u && active) {
-                    claunch* V = launder(L);
+                // the transmissive winner stays only if it is nearer (depth GREATER, reversed Z); over a pixel without an
+                // opaque fragment it always stays
+                claunch* V = launder(L);
+                if (cur.cover_front != 0u && (active || (V->present != nullptr && inside))) {
                     const uint32_t at = mad24(out_py, V->fp.width, out_px) * 8u;
                     const unsigned long long front = ld<unsigned long long>(V->vis_front, at);
-                    if (front != 0ull && !(__uint_as_float((uint32_t)(front >> 32)) > cur.pd.w))
-                        st<unsigned long long>(V->vis_front, at, 0ull);
+                    if (active && front != 0ull && !(__uint_as_float((uint32_t)(front >> 32)) > cur.pd.w))
+                        st<unsigned long long>(V->vis_front, at, zero);
+                    else
+                        final_colour = front == 0ull;
                 }
             }
         }
@@ -1747,6 +1804,13 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                     __builtin_nontemporal_store(u2v{o.x, o.y}, reinterpret_cast<u2v*>(static_cast<char*>(W->hdr) + pix * 8u));
                 } else {
                     st<uint2>(W->hdr, pix * 8u, o);
+                }
+                if constexpr (VIS) {
+                    if (W->present != nullptr && final_colour) {
+                        const tr_tonemap_params pp = {W->present_params.a, W->present_params.b, W->present_params.c, W->present_params.d,
+                                                      W->present_params.crosstalk, W->present_params.saturation, W->present_params.cross_saturation};
+                        st<uint32_t>(W->present, pix * 4u, tonemap_pixel(o.x, o.y, pp, W->present_e1, W->present_bgra));
+                    }
                 }
             } else {
                 st<OutT>(W->hdr, pix * 16u, OutT{out.x, out.y, out.z, 1.0f});
@@ -2099,48 +2163,7 @@ __global__ __launch_bounds__(1024) void mip_tail_kernel(uint2* __restrict__ pyr,
     }
 }
 
-// ---- tonemap (SURVEY.md 8f row f5) ----------------------------------------------------------------------
-// fragment_tonemap (shader/src/lib.rs:683-697) + LottesTonemapper::tonemap (shader/src/tonemapping.rs:8-27);
-// the fullscreen triangle samples texel centres, so the input is the HDR texel itself.  pow = exp2(y log2 x).
-__device__ __forceinline__ float fast_pow(float x, float y) { return fast_exp2(y * fast_log2(x)); }
-
-// The sRGB target's encode (fixed function) of exp2(l), for l = log2 of a value already clamped to [0, 1] (l <= 0, -inf
-// for zero): one v_exp_f32 for either branch of the transfer function — 12.92 x below the knee, 1.055 x^(1/2.4) - 0.055 above.
-__device__ __forceinline__ uint32_t log2_to_srgb8(float l) {
-    const bool low = l <= -8.3192688f;                       // log2(0.0031308)
-    const float e = fast_exp2(low ? l : l * (1.0f / 2.4f));
-    const float v = low ? 12.92f * e : fmaf(1.055f, e, -0.055f);
-    return (uint32_t)fmaf(v, 255.0f, 0.5f);
-}
-
-// fragment_tonemap (shader/src/lib.rs:683-697, shader/src/tonemapping.rs:8-27) + the sRGB encode of the swapchain
-// format.  Two pixels per thread (16-byte loads, 8-byte stores).  The operator is a chain of powers: it is evaluated in
-// the log2 domain, so that consecutive powers share their logarithm — peak^a and (peak^a)^d both from log2(peak);
-// (ratio^cs * peak').clamp(0, 1) goes straight into the sRGB curve's own power as cs log2(ratio) + log2(peak') — 19
-// transcendental instructions per pixel instead of 26 (the kernel is bound by them), and fewer roundings.  Black pixels
-// (0 / 0 in the reference: NaN, which its min(1).max(0) turns into 1) come out the same way: log2(0) - log2(0) is NaN
-// and v_min_f32(NaN, 0) is 0.
-__device__ __forceinline__ uint32_t tonemap_pixel(uint32_t lo, uint32_t hi, const tr_tonemap_params& p, float e1, int bgra) {
-    const float r = h2f_lo(lo), g = h2f_hi(lo), b = h2f_lo(hi);
-    const float mx = fmaxf(r, fmaxf(g, b));
-    const float lmx = fast_log2(mx);
-    const float la = p.a * lmx;
-    const float z = fast_exp2(la);                                  // peak^a
-    const float tm = z * rcp(fmaf(fast_exp2(la * p.d), p.b, p.c));  // tonemap_inner: z / (z^d b + c)
-    const float ltm = fast_log2(tm);
-    const float t = fast_exp2(ltm * p.crosstalk);                   // tonemapped_max^crosstalk
-    const float c[3] = {r, g, b};
-    uint32_t out8[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float x = fast_exp2((fast_log2(c[k]) - lmx) * e1);          // (color / max)^(saturation / cross_saturation)
-        x = fmaf(1.0f - x, t, x);                                   // lerp(ratio, 1, tonemapped_max^crosstalk)
-        const float l = fmaf(fast_log2(x), p.cross_saturation, ltm);   // log2(ratio^cross_saturation * tonemapped_max)
-        out8[k] = log2_to_srgb8(fminf(l, 0.0f));                    // .min(ONE); .max(ZERO) is exp2's own range
-    }
-    return bgra ? (out8[2] | (out8[1] << 8) | (out8[0] << 16) | 0xFF000000u) : (out8[0] | (out8[1] << 8) | (out8[2] << 16) | 0xFF000000u);
-}
-
+// ---- tonemap kernels (tonemap_pixel: above shade_kernel, whose frame-recorder launches present their pixels themselves)
 // (e1 = saturation / cross_saturation, formed once on the host: the same IEEE division, ten instructions per thread fewer)
 __global__ __launch_bounds__(256) void tonemap_kernel(const uint2* __restrict__ hdr, uint32_t* __restrict__ out,
                                                       uint32_t n, const tr_tonemap_params p, int bgra, const float e1) {

@@ -140,6 +140,9 @@ struct tr_context {
     const tr_tri_planes* planes_hint = nullptr;        //     words and triangle planes: the shading launches read those (VIS)
     unsigned long long* vis_front_hint = nullptr;      // opaque VIS launches: the transmissive layer's words and coverage map
     const uint32_t* cover_front_hint = nullptr;        //   (a transmissive winner behind the opaque surface is zeroed there)
+    uint32_t* present_hint = nullptr;                  // ... and the tonemapped frame its launches write final pixels to
+    tr_tonemap_params present_params_hint = {};
+    int32_t present_bgra_hint = 0;
     void* mip1_hint = nullptr;                         // ... and level 1 of the opaque pyramid, for the opaque launches to write
     size_t vis_pixels = 0;
     bool vis_clean = false;                            // both visibility buffers are all zero (stream order)
@@ -603,6 +606,10 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.tri_planes = L.vis ? ctx->planes_hint : nullptr;
     L.vis_front = L.vis ? ctx->vis_front_hint : nullptr;
     L.cover_front = L.vis ? ctx->cover_front_hint : nullptr;
+    L.present = L.vis ? ctx->present_hint : nullptr;
+    L.present_params = ctx->present_params_hint;
+    L.present_e1 = ctx->present_params_hint.saturation / ctx->present_params_hint.cross_saturation;   // (as tr_tonemap forms it)
+    L.present_bgra = ctx->present_bgra_hint;
     L.tap_excess = ctx->tap_excess;
     L.slice_thr = ctx->d_slice_thr;
     L.cluster_x = ctx->d_cluster_x;
@@ -2125,6 +2132,19 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     // Level 1 of the opaque pyramid comes out of the opaque launches themselves when they shade from visibility words and
     // both frame sizes are even (then the blit is the 2x2 box of a wave tile's own quads): the mip chain starts at level 2.
     const bool fused_level1 = use_vis && f->pyramid.levels >= 2u && (w & 1u) == 0u && (h & 1u) == 0u;
+    // A frame that is presented and not timed pass by pass: its VIS launches tonemap the pixels whose final colour they write
+    // (shade_kernel, `present`) — there is no tonemap pass.  The timed recorder keeps the reference's separate pass (its zone).
+    const bool present_in_passes = use_vis && f->ldr_out != nullptr && rec == nullptr;
+    if (f->ldr_out && (((uintptr_t)f->hdr & 15u) || ((uintptr_t)f->ldr_out & 7u))) return TR_ERR_INVALID_ARGUMENT;
+    if (present_in_passes) {
+        ctx->present_hint = (uint32_t*)f->ldr_out;
+        ctx->present_params_hint = *f->tonemap;
+        ctx->present_bgra_hint = (int32_t)f->bgra;
+    }
+    struct present_guard {   // (the hints never outlive the call)
+        tr_context* c;
+        ~present_guard() { c->present_hint = nullptr; }
+    } present_scope{ctx};
     {
         zone_scope z(rec, "main opaque");
         ctx->cover_hint = ctx->d_tile_cover[0];
@@ -2159,9 +2179,8 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     }
     if (st != TR_OK) return st;
     if (use_vis) ctx->vis_clean = true;   // (both passes enqueued: every visibility word the frame set is zeroed again)
-    if (f->ldr_out) {
+    if (f->ldr_out && !present_in_passes) {
         zone_scope z(rec, "tonemapping");
-        if (((uintptr_t)f->hdr & 15u) || ((uintptr_t)f->ldr_out & 7u)) return TR_ERR_INVALID_ARGUMENT;
         // (the tiles no fragment of either layer landed in hold the clear colour: tonemapped once per workgroup)
         tr_tonemap_tiles tt;
         tt.cover[0] = ctx->d_tile_cover[0];
