@@ -756,13 +756,12 @@ __device__ __forceinline__ v2f lut_resolve(const lut_fetch& lf, float fy) {
     return pk_fma(bot - top, splat(fy), top) * (1.0f / 255.0f);
 }
 
+// (as a 2-vector of _Float16: gfx950's v_cvt_pk_f16_f32 converts — round to nearest even — and packs a pair in ONE
+//  instruction; __floats2half2_rn compiles to two conversions and a v_perm_b32 whose selector sits in a register of its own)
 __device__ __forceinline__ uint2 pack_rgba16f(float r, float g, float b, float a) {
-    __half2 lo = __floats2half2_rn(r, g);
-    __half2 hi = __floats2half2_rn(b, a);
-    uint2 o;
-    o.x = *reinterpret_cast<uint32_t*>(&lo);
-    o.y = *reinterpret_cast<uint32_t*>(&hi);
-    return o;
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const half2v lo = {(_Float16)r, (_Float16)g}, hi = {(_Float16)b, (_Float16)a};
+    return uint2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
 }
 
 // shader/src/lib.rs:647-668
