@@ -255,11 +255,19 @@ struct tr_launch {
     // depth, zeroes that word where the fragment is not nearer than the opaque surface.
     unsigned long long* vis_front;
     const uint32_t* cover_front;
+    uint32_t* front_list_build;         // (see front_list below)
+    uint32_t* front_list_build_count;
     uint32_t* tap_excess;               // optional (tap window set): atomicMax of the level-0 rows a tap reached beyond the window
     // VIS launches of a frame that is also presented (tr_record_frame with a tonemap target): the launch that writes a
     // pixel's FINAL colour — the transmissive one, or the opaque one where no transmissive winner survives — tonemaps
     // the RGBA16F value it stores (fragment_tonemap on the same bits) into `present`: the frame has no tonemap pass
     // that reads the whole target back (99 MB of traffic at 4K, 17 us at the memory roofline)
+    // The transmissive layer usually covers a fraction of the screen.  The opaque VIS launch, which visits every block tile
+    // and reads the layer's coverage word anyway, lists the tiles that hold transmissive fragments (`front_list_build`, one
+    // atomic per such tile); the transmissive VIS launch walks that list (`front_list`) instead of the frame: dense work
+    // for its waves instead of five tiles each of which 70 % are skipped.
+    const uint32_t* front_list;
+    const uint32_t* front_list_count;
     uint32_t* present;
     tr_tonemap_params present_params;
     float present_e1;
@@ -1543,7 +1551,9 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // VIS launches (real frames, where whole screen regions are empty or cheap): the XCDs are dealt STRIPES of
     // kStripeTileRows tile rows in turn instead of one contiguous band each, so that every XCD gets its share of the
     // covered part of the screen (a frame whose upper half is sky left half of the XCDs idle).
-    const bool striped = VIS || TEX != kTexNone;
+    const bool listed = VIS && TRANSMISSIVE && L->front_list != nullptr;   // (scalar) walk the opaque launch's list of covered block tiles
+    const uint32_t listed_tiles = listed ? as_constant(L->front_list_count)[0] : 0u;
+    const bool striped = (VIS || TEX != kTexNone) && !listed;
     uint32_t stripes_own = 0u, striped_len = 0u;
     if (striped) {
         const uint32_t st = L->fp.stripe_tiles;
@@ -1552,8 +1562,8 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         const bool owns_last = stripes_own != 0u && ((nstripes - 1u) & 7u) == xcd;
         striped_len = stripes_own * st - (owns_last ? nstripes * st - ntiles : 0u);
     }
-    const uint32_t band_start = xcd * per + min(xcd, rem);
-    const uint32_t band_len = striped ? striped_len : per + (xcd < rem ? 1u : 0u);
+    const uint32_t band_start = listed ? 0u : xcd * per + min(xcd, rem);
+    const uint32_t band_len = listed ? listed_tiles : striped ? striped_len : per + (xcd < rem ? 1u : 0u);
 
     // Out-of-rect lanes read a clamped (valid) pixel and are masked later.  There is no software prefetch of the
     // next tile: its 13 registers cost two of the eight resident waves per SIMD, and even scheduled so that nothing
@@ -1607,7 +1617,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
     auto fetch = [&](uint32_t j, tile_regs& t) {
         claunch* F = launder(L);
-        uint32_t tile = band_start + (j >> 2);
+        uint32_t tile = listed ? as_constant(F->front_list)[j >> 2] : band_start + (j >> 2);
         if (striped) {   // local tile q of this XCD: stripe q / stripe_tiles of its own, i.e. stripe (that * 8 + xcd) of the frame
             const uint32_t q = j >> 2, st = F->fp.stripe_tiles;
             uint32_t own = __umulhi(q, F->fp.stripe_magic), off = q - own * st;
@@ -1649,7 +1659,14 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         // (their tile inputs are parked in LDS, see kParkDp), bit 2 = of any other (raster_kernel)
         const uint32_t cover = F->tile_cover ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
         t.cover = cover;
-        if constexpr (VIS && !TRANSMISSIVE) t.cover_front = F->cover_front ? as_constant(F->cover_front)[tile] : 0u;
+        if constexpr (VIS && !TRANSMISSIVE) {
+            const uint32_t* front_words = F->cover_front;
+            uint32_t* list = F->front_list_build;   // (both pointers in one scalar round trip: pinned together)
+            asm volatile("" : "+s"(front_words), "+s"(list));
+            t.cover_front = front_words ? as_constant(front_words)[tile] : 0u;
+            // (once per block tile: by the wave of its first quarter)
+            if (list && t.cover_front != 0u && (j & 3u) == 0u && lane_here() == 0u) list[atomicAdd(F->front_list_build_count, 1u)] = tile;
+        }
         if (cover == 0u) {
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
@@ -1666,7 +1683,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // rows are 1 KB contiguous and their stores 512 B).  Handing tiles out dynamically balances the waves (static: the
     // longest-lived wave of the 4K frame runs 36 % longer than the mean) but measured slower.
     const uint32_t wave_tiles = band_len * 4u;
-    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t slot = listed ? blockIdx.x : (blockIdx.x >> 3);
     uint32_t j = slot;
     tile_regs cur;
     while (j < wave_tiles) {
@@ -1746,7 +1763,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         // The next tile's plane loads are issued BEFORE this tile's store: memory operations complete in order, so a
         // load behind the store could not be waited for without waiting for the store's acknowledgement as well.
         const uint32_t out_px = cur.px, out_py = cur.py;
-        j += gridDim.x >> 3;
+        j += listed ? gridDim.x : (gridDim.x >> 3);
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         const bool write = TRANSMISSIVE ? active : inside;
         bool final_colour = true;   // (VIS) no later launch of the frame writes this pixel

@@ -134,6 +134,9 @@ struct tr_context {
     tr_layer_counts* d_layer_counts = nullptr;
     unsigned long long* d_vis[2] = {nullptr, nullptr};
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
+    uint32_t* d_front_list_count = nullptr;            // behind the maps: how many block tiles hold transmissive fragments, and which
+    uint32_t* d_front_list = nullptr;                  //   (listed by the opaque VIS launch, walked by the transmissive one)
+    bool front_list_hint = false;                      // set by tr_record_frame around its VIS shading calls
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
     bool cover_cleared = false;                        // the frame's first launch has zeroed the coverage maps already
     unsigned long long* vis_hint = nullptr;            // ... and, when the frame skipped the resolve, the layer's visibility
@@ -207,6 +210,7 @@ struct tr_context {
     std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
     bool no_mid_class = false;                  // TR_NO_MID_CLASS (tests only), read once at context creation
     uint32_t vis_grid_rounds = 3;               // see persistent_grid (TR_VIS_ROUNDS: tuning only)
+    uint32_t front_list_waves_per_cu = 48;      // the transmissive VIS launch's grid when it walks the list of covered tiles (TR_FRONT_LIST_WAVES: tuning only; 0: no list)
     uint32_t raster_wgs_per_cu = 6;             // raster_kernel's persistent grid: 4 -> 191 / 199 us (4K mesh / glTF demo frame), 6 -> 191 / 192,
                                                 // 8 -> 194 / 195, 12 -> 191 / 196, 16 -> 198 / 199 (TR_RASTER_WGS_PER_CU: tuning only)
 };
@@ -607,6 +611,8 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.vis_front = L.vis ? ctx->vis_front_hint : nullptr;
     L.cover_front = L.vis ? ctx->cover_front_hint : nullptr;
     L.present = L.vis ? ctx->present_hint : nullptr;
+    L.front_list_build = L.front_list_build_count = nullptr;
+    L.front_list = L.front_list_count = nullptr;
     L.present_params = ctx->present_params_hint;
     L.present_e1 = ctx->present_params_hint.saturation / ctx->present_params_hint.cross_saturation;   // (as tr_tonemap forms it)
     L.present_bgra = ctx->present_bgra_hint;
@@ -708,6 +714,7 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
         ctx->no_mid_class = std::getenv("TR_NO_MID_CLASS") != nullptr;   // tests only: the full-class launch's general build
         if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));  // tuning only
+        if (const char* e = std::getenv("TR_FRONT_LIST_WAVES")) ctx->front_list_waves_per_cu = (uint32_t)std::max(0, std::atoi(e));  // tuning only
         if (const char* e = std::getenv("TR_RASTER_WGS_PER_CU")) ctx->raster_wgs_per_cu = (uint32_t)std::max(1, std::atoi(e));  // tuning only
     }
     if (hipMalloc((void**)&ctx->d_front_ticket, 4u) != hipSuccess || hipMemset(ctx->d_front_ticket, 0, 4u) != hipSuccess ||
@@ -1134,7 +1141,7 @@ tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
         ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
         ctx->vis_pixels = 0;
         ctx->d_tile_cover[0] = ctx->d_tile_cover[1] = nullptr;
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 2u * (npix / 64u + 65536u + 16384u) * 4u + 64u));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 3u * (npix / 64u + 65536u + 16384u) * 4u + 128u));
         ctx->vis_pixels = npix;
         ctx->vis_clean = false;
     }
@@ -1147,12 +1154,15 @@ tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
     const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
     ctx->d_tile_cover[0] = (uint32_t*)(ctx->d_vis[0] + 2u * npix);
     ctx->d_tile_cover[1] = ctx->d_tile_cover[0] + cover_tiles;
+    ctx->d_front_list_count = ctx->d_tile_cover[1] + cover_tiles;   // (zeroed with the maps: cover_clear_bytes)
+    ctx->d_front_list = ctx->d_front_list_count + 4u;
     return TR_OK;
 }
-// what a frame zeroes before rasterising: the maps, rounded up to whole 16-byte vectors (into the allocation's slack)
+// what a frame zeroes before rasterising: the maps and the counter of the list of transmissive-covered tiles behind them,
+// rounded up to whole 16-byte vectors (the round-up reaches into the list, which is rebuilt every frame)
 inline size_t cover_clear_bytes(uint32_t w, uint32_t h) {
     const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
-    return (2u * cover_tiles * 4u + 15u) & ~(size_t)15u;
+    return ((2u * cover_tiles + 1u) * 4u + 15u) & ~(size_t)15u;
 }
 
 // The work buffers of both layers as the front-end kernels take them (after ensure_vis_buffers).
@@ -1399,6 +1409,10 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
         L.hdr = hdr_out;
         L.mip0 = (uint2*)opaque_mip0_out;
         L.mip1 = (L.vis && L.mip0 && format == TR_FORMAT_RGBA16F) ? (uint2*)ctx->mip1_hint : nullptr;   // (the frame recorder)
+        if (L.vis && L.cover_front && ctx->front_list_hint) {   // ... whose opaque launch lists the tiles with transmissive fragments
+            L.front_list_build = ctx->d_front_list;
+            L.front_list_build_count = ctx->d_front_list_count;
+        }
         const bool half = format == TR_FORMAT_RGBA16F;
         if (ctx->any_textured) {
             launch_textured<false>(ctx, L, half, grid, block, stream);
@@ -1554,7 +1568,12 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     // one-wave workgroups: blocks_per_xcd counts units of four waves
     tr_launch L;
     fill_launch(L, ctx, fp, g);
-    const dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y, L.vis != nullptr) * 4u), block(64);
+    dim3 grid(persistent_grid(ctx, fp.tiles_x * fp.tiles_y, L.vis != nullptr) * 4u), block(64);
+    if (L.vis && ctx->front_list_hint) {   // (the frame recorder) walk the opaque launch's list of covered tiles
+        L.front_list = ctx->d_front_list;
+        L.front_list_count = ctx->d_front_list_count;
+        grid = dim3(ctx->num_cus * ctx->front_list_waves_per_cu);
+    }
     {
         L.pyramid = (const uint2*)p->texels;
         L.hdr = hdr_inout;
@@ -2141,9 +2160,10 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ctx->present_params_hint = *f->tonemap;
         ctx->present_bgra_hint = (int32_t)f->bgra;
     }
+    ctx->front_list_hint = use_vis && ctx->front_list_waves_per_cu != 0u;
     struct present_guard {   // (the hints never outlive the call)
         tr_context* c;
-        ~present_guard() { c->present_hint = nullptr; }
+        ~present_guard() { c->present_hint = nullptr; c->front_list_hint = false; }
     } present_scope{ctx};
     {
         zone_scope z(rec, "main opaque");
