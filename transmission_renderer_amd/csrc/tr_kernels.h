@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             txi -= F->fp.tiles_x;
             ++tyi;
         }
-        if (F->fp.strip_tile_rows != 0u) {   // (scalar) this rank's strips of a frame shared with other ranks
+        if (!VIS && F->fp.strip_tile_rows != 0u) {   // (scalar) this rank's strips of a frame shared with other ranks (never a VIS launch)
             const uint32_t T = F->fp.strip_tile_rows;
             uint32_t k = __umulhi(tyi, F->fp.strip_magic), r = tyi - k * T;
             if (r >= T) {
@@ -1657,16 +1657,24 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         // (scalar) the coverage word of the block tile, when the frame recorder rasterised the layer itself: 0 = nothing
         // landed there (the tile is skipped without touching its inputs); bit 1 = fragments of a full-class material
         // (their tile inputs are parked in LDS, see kParkDp), bit 2 = of any other (raster_kernel)
-        const uint32_t cover = F->tile_cover ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
-        t.cover = cover;
+        uint32_t cover;
         if constexpr (VIS && !TRANSMISSIVE) {
+            // (a VIS launch always has its layer's map, and the opaque one the transmissive layer's: the pointers come in one
+            //  scalar round trip, pinned together, the two words in the next — no null checks in the chain)
+            const uint32_t* own_words = F->tile_cover;
             const uint32_t* front_words = F->cover_front;
-            uint32_t* list = F->front_list_build;   // (both pointers in one scalar round trip: pinned together)
-            asm volatile("" : "+s"(front_words), "+s"(list));
-            t.cover_front = front_words ? as_constant(front_words)[tile] : 0u;
+            uint32_t* list = F->front_list_build;
+            asm volatile("" : "+s"(own_words), "+s"(front_words), "+s"(list));
+            cover = as_constant(own_words)[tile];
+            t.cover_front = as_constant(front_words)[tile];
             // (once per block tile: by the wave of its first quarter)
             if (list && t.cover_front != 0u && (j & 3u) == 0u && lane_here() == 0u) list[atomicAdd(F->front_list_build_count, 1u)] = tile;
+        } else if constexpr (VIS) {
+            cover = as_constant(F->tile_cover)[tile];
+        } else {
+            cover = F->tile_cover ? as_constant(F->tile_cover)[tile] : 0xFFFFFFFFu;
         }
+        t.cover = cover;
         if (cover == 0u) {
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
