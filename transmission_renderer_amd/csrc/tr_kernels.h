@@ -1664,7 +1664,6 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             const uint32_t* own_words = F->tile_cover;
             const uint32_t* front_words = F->cover_front;
             uint32_t* list = F->front_list_build;
-            asm volatile("" : "+s"(own_words), "+s"(front_words), "+s"(list));
             cover = as_constant(own_words)[tile];
             t.cover_front = as_constant(front_words)[tile];
             // (once per block tile: by the wave of its first quarter)
