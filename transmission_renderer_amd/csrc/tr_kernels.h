@@ -76,6 +76,7 @@ template <int P>
 __device__ __forceinline__ void tile_phase() {
     __builtin_amdgcn_s_setprio(P);
 }
+constexpr uint32_t kFrontLists = 64u;      // sub-lists of the transmissive-covered tile list (tr_launch::front_list)
 constexpr uint32_t kStripeTileRows = 4u;   // VIS / textured launches: tile rows per XCD stripe (1 ... 8 measure the same)
 #ifndef TR_PARKED_VALUES
 #define TR_PARKED_VALUES 17u   // (A/B builds of tools/ raise it to measure what the LDS footprint costs in resident waves)
@@ -268,6 +269,9 @@ struct tr_launch {
     // for its waves instead of five tiles each of which 70 % are skipped.
     const uint32_t* front_list;
     const uint32_t* front_list_count;
+    uint32_t front_list_cap;            // entries per sub-list: the list is kFrontLists lists with a counter each (tile t goes into list
+                                        // t % kFrontLists: one counter would be a queue of same-address atomics, 11-14 ns apart —
+                                        // thousands of tiles per frame); the walking launch's workgroup b walks list b % kFrontLists
     uint32_t* present;
     tr_tonemap_params present_params;
     float present_e1;
@@ -1552,7 +1556,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // kStripeTileRows tile rows in turn instead of one contiguous band each, so that every XCD gets its share of the
     // covered part of the screen (a frame whose upper half is sky left half of the XCDs idle).
     const bool listed = VIS && TRANSMISSIVE && L->front_list != nullptr;   // (scalar) walk the opaque launch's list of covered block tiles
-    const uint32_t listed_tiles = listed ? as_constant(L->front_list_count)[0] : 0u;
+    const uint32_t listed_tiles = listed ? as_constant(L->front_list_count)[blockIdx.x & (kFrontLists - 1u)] : 0u;
     const bool striped = (VIS || TEX != kTexNone) && !listed;
     uint32_t stripes_own = 0u, striped_len = 0u;
     if (striped) {
@@ -1617,7 +1621,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
     auto fetch = [&](uint32_t j, tile_regs& t) {
         claunch* F = launder(L);
-        uint32_t tile = listed ? as_constant(F->front_list)[j >> 2] : band_start + (j >> 2);
+        uint32_t tile = listed ? as_constant(F->front_list)[(blockIdx.x & (kFrontLists - 1u)) * F->front_list_cap + (j >> 2)] : band_start + (j >> 2);
         if (striped) {   // local tile q of this XCD: stripe q / stripe_tiles of its own, i.e. stripe (that * 8 + xcd) of the frame
             const uint32_t q = j >> 2, st = F->fp.stripe_tiles;
             uint32_t own = __umulhi(q, F->fp.stripe_magic), off = q - own * st;
@@ -1667,7 +1671,10 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             cover = as_constant(own_words)[tile];
             t.cover_front = as_constant(front_words)[tile];
             // (once per block tile: by the wave of its first quarter)
-            if (list && t.cover_front != 0u && (j & 3u) == 0u && lane_here() == 0u) list[atomicAdd(F->front_list_build_count, 1u)] = tile;
+            if (list && t.cover_front != 0u && (j & 3u) == 0u && lane_here() == 0u) {
+                const uint32_t sub = tile & (kFrontLists - 1u);   // (at most ceil(tiles / kFrontLists) entries: front_list_cap)
+                list[sub * F->front_list_cap + atomicAdd(F->front_list_build_count + sub, 1u)] = tile;
+            }
         } else if constexpr (VIS) {
             cover = as_constant(F->tile_cover)[tile];
         } else {
@@ -1690,7 +1697,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     // rows are 1 KB contiguous and their stores 512 B).  Handing tiles out dynamically balances the waves (static: the
     // longest-lived wave of the 4K frame runs 36 % longer than the mean) but measured slower.
     const uint32_t wave_tiles = band_len * 4u;
-    const uint32_t slot = listed ? blockIdx.x : (blockIdx.x >> 3);
+    const uint32_t slot = listed ? blockIdx.x / kFrontLists : (blockIdx.x >> 3);
     uint32_t j = slot;
     tile_regs cur;
     while (j < wave_tiles) {
@@ -1770,7 +1777,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         // The next tile's plane loads are issued BEFORE this tile's store: memory operations complete in order, so a
         // load behind the store could not be waited for without waiting for the store's acknowledgement as well.
         const uint32_t out_px = cur.px, out_py = cur.py;
-        j += listed ? gridDim.x : (gridDim.x >> 3);
+        j += listed ? gridDim.x / kFrontLists : (gridDim.x >> 3);
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         const bool write = TRANSMISSIVE ? active : inside;
         bool final_colour = true;   // (VIS) no later launch of the frame writes this pixel

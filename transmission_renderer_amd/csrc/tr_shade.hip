@@ -135,7 +135,8 @@ struct tr_context {
     unsigned long long* d_vis[2] = {nullptr, nullptr};
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
     uint32_t* d_front_list_count = nullptr;            // behind the maps: how many block tiles hold transmissive fragments, and which
-    uint32_t* d_front_list = nullptr;                  //   (listed by the opaque VIS launch, walked by the transmissive one)
+    uint32_t* d_front_list = nullptr;                  //   (listed by the opaque VIS launch, walked by the transmissive one; kFrontLists sub-lists)
+    uint32_t front_list_cap = 0;
     bool front_list_hint = false;                      // set by tr_record_frame around its VIS shading calls
     const uint32_t* cover_hint = nullptr;              // set by tr_record_frame around its shading calls only
     bool cover_cleared = false;                        // the frame's first launch has zeroed the coverage maps already
@@ -613,6 +614,7 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
     L.present = L.vis ? ctx->present_hint : nullptr;
     L.front_list_build = L.front_list_build_count = nullptr;
     L.front_list = L.front_list_count = nullptr;
+    L.front_list_cap = 0u;
     L.present_params = ctx->present_params_hint;
     L.present_e1 = ctx->present_params_hint.saturation / ctx->present_params_hint.cross_saturation;   // (as tr_tonemap forms it)
     L.present_bgra = ctx->present_bgra_hint;
@@ -1141,7 +1143,7 @@ tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
         ctx->d_vis[0] = ctx->d_vis[1] = nullptr;
         ctx->vis_pixels = 0;
         ctx->d_tile_cover[0] = ctx->d_tile_cover[1] = nullptr;
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 3u * (npix / 64u + 65536u + 16384u) * 4u + 128u));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_vis[0], 2u * npix * 8u + 3u * (npix / 64u + 65536u + 16384u) * 4u + (kFrontLists * 65u + 64u) * 4u));
         ctx->vis_pixels = npix;
         ctx->vis_clean = false;
     }
@@ -1155,14 +1157,15 @@ tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
     ctx->d_tile_cover[0] = (uint32_t*)(ctx->d_vis[0] + 2u * npix);
     ctx->d_tile_cover[1] = ctx->d_tile_cover[0] + cover_tiles;
     ctx->d_front_list_count = ctx->d_tile_cover[1] + cover_tiles;   // (zeroed with the maps: cover_clear_bytes)
-    ctx->d_front_list = ctx->d_front_list_count + 4u;
+    ctx->d_front_list = ctx->d_front_list_count + kFrontLists;
+    ctx->front_list_cap = (uint32_t)(cover_tiles / kFrontLists + 1u);   // (tile t is listed in sub-list t % kFrontLists)
     return TR_OK;
 }
 // what a frame zeroes before rasterising: the maps and the counter of the list of transmissive-covered tiles behind them,
 // rounded up to whole 16-byte vectors (the round-up reaches into the list, which is rebuilt every frame)
 inline size_t cover_clear_bytes(uint32_t w, uint32_t h) {
     const size_t cover_tiles = (size_t)((w + 63u) / 64u) * ((h + 3u) / 4u);
-    return ((2u * cover_tiles + 1u) * 4u + 15u) & ~(size_t)15u;
+    return ((2u * cover_tiles + kFrontLists) * 4u + 15u) & ~(size_t)15u;
 }
 
 // The work buffers of both layers as the front-end kernels take them (after ensure_vis_buffers).
@@ -1412,6 +1415,7 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
         if (L.vis && L.cover_front && ctx->front_list_hint) {   // ... whose opaque launch lists the tiles with transmissive fragments
             L.front_list_build = ctx->d_front_list;
             L.front_list_build_count = ctx->d_front_list_count;
+            L.front_list_cap = ctx->front_list_cap;
         }
         const bool half = format == TR_FORMAT_RGBA16F;
         if (ctx->any_textured) {
@@ -1572,6 +1576,7 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
     if (L.vis && ctx->front_list_hint) {   // (the frame recorder) walk the opaque launch's list of covered tiles
         L.front_list = ctx->d_front_list;
         L.front_list_count = ctx->d_front_list_count;
+        L.front_list_cap = ctx->front_list_cap;
         grid = dim3(ctx->num_cus * ctx->front_list_waves_per_cu);
     }
     {
