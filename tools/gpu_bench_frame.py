@@ -52,5 +52,15 @@ if hasattr(r.lib, "tr_debug_read_timing") and os.environ.get("TR_AB_LIB"):   # a
     print(f"shading waves of 10 frames (both passes), cycles per tile and wave: inputs wait {w0 / tiles:.0f}, cluster lists {w1 / tiles:.0f}, "
           f"taps + LUT {w2 / tiles:.0f}, texture front end {buf[8] / tiles:.0f}, light loops {buf[9] / tiles:.0f}, whole tile {total / tiles:.0f}; "
           f"{tiles / (waves & 0xFFFFFFFF):.2f} tiles per wave")
+if hasattr(r.lib, "tr_debug_read_raster_timing") and os.environ.get("TR_AB_LIB"):   # a -DTR_RASTER_TIMING build: the opaque layer's raster waves
+    import ctypes as C
+    buf = (C.c_ulonglong * 10)()
+    torch.cuda.synchronize(); r.lib.tr_debug_read_raster_timing(buf)
+    frame()
+    torch.cuda.synchronize(); r.lib.tr_debug_read_raster_timing(buf)
+    s_, p_, bl, tot, items, waves, longest, nblocks, issue, most = [int(x) / 1.0 for x in buf]
+    print(f"raster waves {waves:.0f}: items {items:.0f} (most in a wave {most:.0f}), blocks visited {nblocks:.0f}; per wave mean: total {tot / waves / 100:.1f} us "
+          f"(issue {issue / waves / 100:.1f}), search {s_ / waves / 100:.1f}, item prologues {p_ / waves / 100:.1f}, block loops {bl / waves / 100:.1f}; "
+          f"longest wave {longest / 100:.1f} us")
 print(f"{name} {w}x{h}, {len(geometry['index']) // 3} triangles: {t * 1e3:.1f} us per frame ({1e3 / t:.0f} frames/s), "
       f"culling -> rasteriser -> opaque -> mips -> transmissive -> tonemap, one tr_record_frame call per frame")

@@ -38,3 +38,13 @@ for _ in range(10):
 cov = (o.material_id != -1).float().mean().item(), (t.material_id != -1).float().mean().item()
 print(f"{ntri} triangles, {w}x{h}: draw_scene (culling + demultiplex + 2 x (scan, setup, scan, raster, resolve)) p50 {sorted(ts)[5]:.3f} ms, "
       f"coverage opaque {cov[0]:.2f} transmissive {cov[1]:.2f}")
+if hasattr(r.lib, "tr_debug_read_raster_timing"):   # a -DTR_RASTER_TIMING build (tools/build_variant.py): the opaque layer's raster waves
+    import ctypes
+    buf = (ctypes.c_ulonglong * 10)()
+    torch.cuda.synchronize(); r.lib.tr_debug_read_raster_timing(buf)
+    r.draw_scene(culling, sc["push"], o, t)
+    torch.cuda.synchronize(); r.lib.tr_debug_read_raster_timing(buf)
+    s, p, bl, tot, items, waves, longest, nblocks, issue, most = [int(x) for x in buf]
+    us = lambda ticks: ticks / 100.0   # s_memtime runs at 100 MHz
+    print(f"  raster waves {waves}: items {items} (most in a wave {most}), blocks visited {nblocks}; per wave mean: total {us(tot) / waves:.1f} us "
+          f"(issue {us(issue) / waves:.1f}), search {us(s) / waves:.1f}, item prologues {us(p) / waves:.1f}, block loops {us(bl) / waves:.1f}; longest wave {us(longest):.1f} us")

@@ -282,6 +282,21 @@ struct tr_raster_layers {
     uint32_t* tile_cover[2];     // [ceil(h/4)][ceil(w/64)], zeroed
     uint32_t enabled[2];         // (a layer that cannot have triangles has no buffers)
 };
+#ifdef TR_RASTER_TIMING   // profiling builds only (tools/build_variant.py): where the raster waves spend their time
+__device__ unsigned long long tr_raster_timing[10][1024];
+#define TR_RT_NOW() __builtin_amdgcn_s_memtime()
+#define TR_RT(x) x
+#else
+#define TR_RT(x)
+#endif
+// The part of tr_tri_record the coverage and depth tests read (tr_visibility.h: the words before T), wave-uniform in
+// scalar registers.
+constexpr uint32_t kRasterRecordWords = 20u;
+static_assert(offsetof(tr_tri_record, T) == 76 && offsetof(tr_tri_record, flags) == 68, "raster_record follows tr_tri_record's layout");
+struct raster_record {
+    float A[3], B[3], C[3], z[3], w[3];
+    uint32_t x0, y0, x1, y1, flags;
+};
 __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_raster_layers rl,
                                                      const tr_alpha_tables alpha) {
 #pragma clang fp contract(off)
@@ -299,47 +314,88 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
     // Wave w owns the items w, w + W, w + 2W, ... (W = number of waves: neighbouring rows of a large triangle go to
     // different waves).  It takes 64 of them at a time: every lane finds the triangle of one item (a binary search
     // over the prefix array, 64 searches in flight together), then the wave works through the 64 items one by one.
+    TR_RT(unsigned long long rt_search = 0; unsigned long long rt_pro = 0; unsigned long long rt_blocks = 0; unsigned long long rt_items = 0;
+          unsigned long long rt_nblocks = 0; const unsigned long long rt_begin = TR_RT_NOW();)
     for (uint32_t batch = 0; first + (uint64_t)batch * 64u * waves < n_items; ++batch) {
+      TR_RT(const unsigned long long rt_t0 = TR_RT_NOW();)
       const uint64_t my_item64 = first + ((uint64_t)batch * 64u + lane) * waves;
       const uint32_t my_item = (uint32_t)min(my_item64, (uint64_t)0xFFFFFFFFu);
-      uint32_t my_t = 0u, my_local = 0u;
+      // Every lane prepares one item: the triangle (a binary search over the prefix array, 64 searches in flight
+      // together), what the rasteriser reads of its record (the first 76 bytes, into registers of the lane), the item's
+      // place in the triangle's bounds, and which of its blocks can hold a fragment at all.  Half of the blocks in a
+      // large triangle's bounds miss it, and in the bounds of a long thin one nearly all do: an edge function, evaluated
+      // as the pixel test evaluates it, is monotone in x and in y (every rounding is), so its largest value over a
+      // block's pixel centres is the one at the corner chosen by the signs of A and B; negative there = no pixel of the
+      // block is inside.  Exactly the blocks the per-pixel test would find empty or a superset are visited: the result
+      // is unchanged.  The wave then works through the items that have a block left, one by one — an item costs it 20
+      // v_readlane or so; the division, the block tests and the empty items (85 % of them in a scene of large triangles at a
+      // grazing angle: tools/gpu_raster_stress.py) cost one lane's work each, 64 at a time.
+      uint32_t my_t = 0u, my_place = 0u, my_blocks = 0u;     // my_place = block row | first block << 16; my_blocks bit b: block first + b
       const bool mine = my_item64 < n_items;
+      uint32_t my_rec[kRasterRecordWords] = {};
       if (mine) {
           my_t = upper_index(item_base, n_tris, my_item);
-          my_local = my_item - item_base[my_t];
+          const uint4* src = reinterpret_cast<const uint4*>(records + my_t);
+#pragma unroll
+          for (uint32_t q = 0; q < kRasterRecordWords / 4u; ++q) {
+              const uint4 v = src[q];
+              my_rec[q * 4u] = v.x; my_rec[q * 4u + 1u] = v.y; my_rec[q * 4u + 2u] = v.z; my_rec[q * 4u + 3u] = v.w;
+          }
+          const uint32_t local = my_item - item_base[my_t];
+          const uint32_t bx0 = (my_rec[15] & 0xFFFFu) >> 3, by0 = my_rec[15] >> 19, bx1 = (my_rec[16] & 0xFFFFu) >> 3;
+          const uint32_t groups = ((bx1 - bx0 + 1u) + kItemWidthBlocks - 1u) / kItemWidthBlocks;
+          const uint32_t row = local / groups, group = local - row * groups;
+          const uint32_t by = by0 + row;
+          const uint32_t bstart = bx0 + group * kItemWidthBlocks, bend = min(bstart + kItemWidthBlocks - 1u, bx1);
+          uint32_t blocks = (2u << (bend - bstart)) - 1u;   // bit b: block bstart + b
+          const float yl = (float)(by * 8u) + 0.5f;
+#pragma unroll
+          for (uint32_t b = 0; b < kItemWidthBlocks; ++b) {
+              const float xl = (float)((bstart + b) * 8u) + 0.5f;
+              bool maybe = true;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                  const float A = __uint_as_float(my_rec[i]), B = __uint_as_float(my_rec[3 + i]), C = __uint_as_float(my_rec[6 + i]);
+                  const float xc = A > 0.0f ? xl + 7.0f : xl, yc = B > 0.0f ? yl + 7.0f : yl;
+                  maybe &= (A * xc + B * yc) + C >= 0.0f;
+              }
+              if (!maybe) blocks &= ~(1u << b);
+          }
+          my_place = by | (bstart << 16);
+          my_blocks = blocks;
       }
-      const uint32_t in_chunk = (uint32_t)__popcll(__ballot(mine));   // items are taken in lane order: a prefix of the lanes
-      for (uint32_t k = 0; k < in_chunk; ++k) {
-        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)k);
-        const uint32_t local = (uint32_t)__builtin_amdgcn_readlane((int)my_local, (int)k);
-        const TR_CONSTANT tr_tri_record& rec = *as_constant(records + t);
-        const uint32_t bx0 = rec.x0 >> 3, by0 = rec.y0 >> 3, bx1 = rec.x1 >> 3;
-        const uint32_t groups = ((bx1 - bx0 + 1u) + kItemWidthBlocks - 1u) / kItemWidthBlocks;
-        const uint32_t row = local / groups, group = local - row * groups;
-        const uint32_t by = by0 + row;
-        const uint32_t bstart = bx0 + group * kItemWidthBlocks, bend = min(bstart + kItemWidthBlocks - 1u, bx1);
+      unsigned long long live = ballot(my_blocks != 0u);
+      TR_RT(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); rt_search += TR_RT_NOW() - rt_t0;)
+      while (live) {
+        TR_RT(const unsigned long long rt_t1 = TR_RT_NOW(); ++rt_items;)
+        const int k = __ffsll((unsigned long long)live) - 1;
+        live &= live - 1ull;
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, k);
+        const uint32_t place = (uint32_t)__builtin_amdgcn_readlane((int)my_place, k);
+        raster_record rec;
+        {
+            uint32_t words[18];
+#pragma unroll
+            for (uint32_t q = 0; q < 18u; ++q) words[q] = (uint32_t)__builtin_amdgcn_readlane((int)my_rec[q], k);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                rec.A[i] = __uint_as_float(words[i]);      rec.B[i] = __uint_as_float(words[3 + i]);
+                rec.C[i] = __uint_as_float(words[6 + i]);  rec.z[i] = __uint_as_float(words[9 + i]);
+                rec.w[i] = __uint_as_float(words[12 + i]);
+            }
+            rec.x0 = words[15] & 0xFFFFu; rec.y0 = words[15] >> 16; rec.x1 = words[16] & 0xFFFFu; rec.y1 = words[16] >> 16;
+            rec.flags = words[17];
+        }
+        const uint32_t by = place & 0xFFFFu, bstart = place >> 16;
+        uint32_t blocks = (uint32_t)__builtin_amdgcn_readlane((int)my_blocks, k);
         const uint32_t py = by * 8u + (lane >> 3);
         const bool alpha_clip = (rec.flags & 1u) != 0u;
-        // Half of the blocks in a large triangle's bounds miss it.  For an item of three or more blocks, lanes 0..7 first
-        // test one block each: an edge function, evaluated as the pixel test evaluates it, is monotone in x and in y
-        // (every rounding is), so its largest value over the block's pixel centres is the one at the corner chosen by
-        // the signs of A and B; negative there = no pixel of the block is inside.  Exactly the blocks the per-pixel test
-        // would find empty or a superset are visited: the result is unchanged.
-        uint32_t blocks = (2u << (bend - bstart)) - 1u;   // bit b: block bstart + b
         // the item's fragments tag the coverage words of the (at most two) 64-pixel tile columns it spans, upper and lower
         // half: collected here (scalar) and written once behind the block loop instead of once per block
         uint32_t cover_bits[kItemTileColumns][2] = {};
-        if (bend - bstart >= 2u) {
-            const float xl = (float)((bstart + (lane & 7u)) * 8u) + 0.5f, yl = (float)(by * 8u) + 0.5f;
-            bool maybe = true;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float xc = rec.A[i] > 0.0f ? xl + 7.0f : xl, yc = rec.B[i] > 0.0f ? yl + 7.0f : yl;
-                maybe &= (rec.A[i] * xc + rec.B[i] * yc) + rec.C[i] >= 0.0f;
-            }
-            blocks &= (uint32_t)ballot(maybe);
-        }
+        TR_RT(const unsigned long long rt_t2 = TR_RT_NOW(); rt_pro += rt_t2 - rt_t1;)
         while (blocks) {
+            TR_RT(++rt_nblocks;)
             const uint32_t bx = bstart + (uint32_t)(__ffs((int)blocks) - 1);
             blocks &= blocks - 1u;
             const uint32_t px = bx * 8u + (lane & 7u);
@@ -352,11 +408,12 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             if (hit && alpha_clip) {
                 // implicit-LOD fetch of the diffuse texture: uv at the two quad partners from the same triangle
                 // (what helper invocations compute), differences oriented like dFdx / dFdy
-                const tr_material_info& m = alpha.materials[rec.material_id];
+                const TR_CONSTANT tr_tri_record& whole = *as_constant(records + t);   // (not in `rec`: the material and the uv corners)
+                const tr_material_info& m = alpha.materials[whole.material_id];
                 float alpha_v = m.diffuse_factor[3];
                 const int32_t tex_id = m.textures.diffuse;
                 if (tex_id >= 0 && (uint32_t)tex_id < alpha.num_textures) {
-                    auto uv_at = [&](const float l[3], int c) { return (l[0] * rec.T[0][c] + l[1] * rec.T[1][c]) + l[2] * rec.T[2][c]; };
+                    auto uv_at = [&](const float l[3], int c) { return (l[0] * whole.T[0][c] + l[1] * whole.T[1][c]) + l[2] * whole.T[2][c]; };
                     float lx[3], ly[3], dd;
                     tri_pixel(rec, (float)(px ^ 1u) + 0.5f, (float)py + 0.5f, lx, dd);
                     tri_pixel(rec, (float)px + 0.5f, (float)(py ^ 1u) + 0.5f, ly, dd);
@@ -388,6 +445,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             if ((uint32_t)hits != 0u) cover_bits[col][0] |= bits;
             if ((uint32_t)(hits >> 32) != 0u) cover_bits[col][1] |= bits;
         }
+        TR_RT(rt_blocks += TR_RT_NOW() - rt_t2;)
         if (lane == 0u) {
             const uint32_t cover_w = (f.width + 63u) >> 6;
             uint32_t* c = tile_cover + (size_t)(by * 2u) * cover_w + (bstart >> 3);
@@ -399,6 +457,16 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
         }
       }
     }
+    TR_RT(const unsigned long long rt_issue = TR_RT_NOW() - rt_begin; asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long rt_total = TR_RT_NOW() - rt_begin;
+          if (lane == 0u && layer == 0u) {
+              const uint32_t s = blockIdx.x & 1023u;
+              atomicAdd(&tr_raster_timing[0][s], rt_search); atomicAdd(&tr_raster_timing[1][s], rt_pro);
+              atomicAdd(&tr_raster_timing[2][s], rt_blocks); atomicAdd(&tr_raster_timing[3][s], rt_total);
+              atomicAdd(&tr_raster_timing[4][s], rt_items);  atomicAdd(&tr_raster_timing[5][s], 1ull);
+              atomicMax(&tr_raster_timing[6][s], rt_total);  atomicAdd(&tr_raster_timing[7][s], rt_nblocks);
+              atomicAdd(&tr_raster_timing[8][s], rt_issue);  atomicMax(&tr_raster_timing[9][s], rt_items);
+          })
 }
 
 struct tr_layer_planes {

@@ -2253,3 +2253,17 @@ tr_status tr_record_frame_timed(tr_context* ctx, const tr_frame_desc* f, void* s
 }
 
 }  // extern "C"
+
+#ifdef TR_RASTER_TIMING
+// (profiling builds only, not declared in include/) sums and clears the raster waves' phase counters of the opaque layer
+extern "C" int32_t tr_debug_read_raster_timing(unsigned long long out[10]) {
+    static unsigned long long host[10][1024];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tr::tr_raster_timing), sizeof(host)) != hipSuccess) return -1;
+    for (int k = 0; k < 10; ++k) {
+        out[k] = 0;
+        for (int i = 0; i < 1024; ++i) out[k] = (k == 6 || k == 9) ? std::max(out[k], host[k][i]) : out[k] + host[k][i];
+    }
+    std::memset(host, 0, sizeof(host));
+    return hipMemcpyToSymbol(HIP_SYMBOL(tr::tr_raster_timing), host, sizeof(host)) == hipSuccess ? 0 : -1;
+}
+#endif
