@@ -195,6 +195,30 @@ def test_many_small_triangles_and_depth_ties(renderer):
     assert (want_o["material_id"] == 10).sum() > 50 and not (want_o["material_id"] == 8).any()
 
 
+def test_long_thin_triangles_at_a_grazing_angle(renderer):
+    """A floor of long slivers seen almost edge-on and coarse spheres close to the camera: most work items of such
+    triangles' bounds hold no fragment (the rasteriser drops them in the lanes' preparation phase, tr_raster_kernels.h);
+    coverage, depth and ids stay bit-exact, wide frame so that items span several 64-pixel tile columns."""
+    w, h = 1024, 160
+    _, view = wire.default_camera()
+    mb = meshes.ModelBuffers()
+    S = meshes.Similarity
+    f32 = np.float32
+    mb.add_primitive(meshes.plane(60.0, 60.0, cells=24), 0, [(S(np.array([0, 0.75, -8.0], f32)), 3)])
+    coarse = meshes.uv_sphere(1.0, 10, 5)
+    rng = np.random.default_rng(5)
+    mb.add_primitive(coarse, 0, [(S(np.array([rng.uniform(-4, 4), rng.uniform(0.9, 2.5), rng.uniform(-9, -2)], f32), rng.uniform(0.3, 0.9)),
+                                  int(rng.integers(0, 16))) for _ in range(12)])
+    mb.add_primitive(coarse, 2, [(S(np.array([0.3, 1.5, -1.6], f32), 0.5), 4)])
+    geo = mb.finish()
+    sc = _scene(w, h, view, alpha_cutoffs=(0.0, 0.0))
+    (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    (twin_o, twin_t), _ = _oracle_layers(geo, sc, w, h, view, fp64=True)
+    got_o, got_t = _gpu_layers(renderer, geo, sc, w, h, culling)
+    assert _compare(got_o, want_o, want64=twin_o) == 0 and _compare(got_t, want_t, want64=twin_t) == 0
+    assert (want_o["material_id"] == 3).mean() > 0.1 and (want_t["material_id"] == 4).any()
+
+
 def test_rasterize_then_shade_end_to_end(renderer, ggx_lut):
     """glTF-shaped path: geometry -> layers -> opaque pass -> mips -> transmissive pass, GPU vs the oracle doing the
     same from its own layers (T1-style bound on the final RGBA16F frame)."""
