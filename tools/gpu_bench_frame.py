@@ -54,13 +54,13 @@ if hasattr(r.lib, "tr_debug_read_timing") and os.environ.get("TR_AB_LIB"):   # a
           f"{tiles / (waves & 0xFFFFFFFF):.2f} tiles per wave")
 if hasattr(r.lib, "tr_debug_read_raster_timing") and os.environ.get("TR_AB_LIB"):   # a -DTR_RASTER_TIMING build: the opaque layer's raster waves
     import ctypes as C
-    buf = (C.c_ulonglong * 10)()
+    buf = (C.c_ulonglong * 12)()
     torch.cuda.synchronize(); r.lib.tr_debug_read_raster_timing(buf)
     frame()
     torch.cuda.synchronize(); r.lib.tr_debug_read_raster_timing(buf)
-    s_, p_, bl, tot, items, waves, longest, nblocks, issue, most = [int(x) / 1.0 for x in buf]
-    print(f"raster waves {waves:.0f}: items {items:.0f} (most in a wave {most:.0f}), blocks visited {nblocks:.0f}; per wave mean: total {tot / waves / 100:.1f} us "
-          f"(issue {issue / waves / 100:.1f}), search {s_ / waves / 100:.1f}, item prologues {p_ / waves / 100:.1f}, block loops {bl / waves / 100:.1f}; "
-          f"longest wave {longest / 100:.1f} us")
+    s_, p_, bl, tot, items, waves, longest, nblocks, issue, most, wg_longest = [int(x) / 1.0 for x in list(buf)[:11]]
+    print(f"raster waves {waves:.0f}: live items {items:.0f} (most in a wave {most:.0f}), blocks visited {nblocks:.0f}; s_memtime ticks per wave, mean: "
+          f"total {tot / waves:.0f} (issue {issue / waves:.0f}), preparation {s_ / waves:.0f}, item hand-over {p_ / waves:.0f}, block loops {bl / waves:.0f}; "
+          f"longest wave {longest:.0f}, busiest workgroup's mean wave {wg_longest:.0f}")
 print(f"{name} {w}x{h}, {len(geometry['index']) // 3} triangles: {t * 1e3:.1f} us per frame ({1e3 / t:.0f} frames/s), "
       f"culling -> rasteriser -> opaque -> mips -> transmissive -> tonemap, one tr_record_frame call per frame")

@@ -40,11 +40,11 @@ print(f"{ntri} triangles, {w}x{h}: draw_scene (culling + demultiplex + 2 x (scan
       f"coverage opaque {cov[0]:.2f} transmissive {cov[1]:.2f}")
 if hasattr(r.lib, "tr_debug_read_raster_timing"):   # a -DTR_RASTER_TIMING build (tools/build_variant.py): the opaque layer's raster waves
     import ctypes
-    buf = (ctypes.c_ulonglong * 10)()
+    buf = (ctypes.c_ulonglong * 12)()
     torch.cuda.synchronize(); r.lib.tr_debug_read_raster_timing(buf)
     r.draw_scene(culling, sc["push"], o, t)
     torch.cuda.synchronize(); r.lib.tr_debug_read_raster_timing(buf)
-    s, p, bl, tot, items, waves, longest, nblocks, issue, most = [int(x) for x in buf]
-    us = lambda ticks: ticks / 100.0   # s_memtime runs at 100 MHz
-    print(f"  raster waves {waves}: items {items} (most in a wave {most}), blocks visited {nblocks}; per wave mean: total {us(tot) / waves:.1f} us "
-          f"(issue {us(issue) / waves:.1f}), search {us(s) / waves:.1f}, item prologues {us(p) / waves:.1f}, block loops {us(bl) / waves:.1f}; longest wave {us(longest):.1f} us")
+    s, p, bl, tot, items, waves, longest, nblocks, issue, most, wg_longest = [int(x) for x in list(buf)[:11]]
+    print(f"  raster waves {waves}: live items {items} (most in a wave {most}), blocks visited {nblocks}; s_memtime ticks per wave, mean: total {tot / waves:.0f} "
+          f"(issue {issue / waves:.0f}), preparation {s / waves:.0f}, item hand-over {p / waves:.0f}, block loops {bl / waves:.0f}; longest wave {longest}, "
+          f"busiest workgroup's mean wave {wg_longest}")

@@ -305,7 +305,8 @@ struct tr_raster_layers {
     uint32_t enabled[2];         // (a layer that cannot have triangles has no buffers)
 };
 #ifdef TR_RASTER_TIMING   // profiling builds only (tools/build_variant.py): where the raster waves spend their time
-__device__ unsigned long long tr_raster_timing[10][1024];
+__device__ unsigned long long tr_raster_timing[12][1024];
+__device__ unsigned long long tr_raster_wave_log[8192][8];   // per wave of the opaque layer
 #define TR_RT_NOW() __builtin_amdgcn_s_memtime()
 #define TR_RT(x) x
 #else
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
     // different waves).  It takes 64 of them at a time: every lane finds the triangle of one item (a binary search
     // over the prefix array, 64 searches in flight together), then the wave works through the 64 items one by one.
     TR_RT(unsigned long long rt_search = 0; unsigned long long rt_pro = 0; unsigned long long rt_blocks = 0; unsigned long long rt_items = 0;
-          unsigned long long rt_nblocks = 0; const unsigned long long rt_begin = TR_RT_NOW();)
+          unsigned long long rt_nblocks = 0; unsigned long long rt_frags = 0; unsigned long long rt_alpha = 0; const unsigned long long rt_begin = TR_RT_NOW(); const unsigned long long rt_real0 = __builtin_amdgcn_s_memrealtime();)
     // one or two batches per wave: the search's round trips are exposed (the waves all search together), and the wide search
     // is 1.7 us of the 4K demo frame; with many batches the waves hide each other's trips and its sevenfold loads cost 4 %
     const bool few_batches = n_items <= 128u * waves;
@@ -415,12 +416,33 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
         uint32_t blocks = (uint32_t)__builtin_amdgcn_readlane((int)my_blocks, k);
         const uint32_t py = by * 8u + (lane >> 3);
         const bool alpha_clip = (rec.flags & 1u) != 0u;
+        // an alpha-clipped draw's item reads what its kill needs once, not once per block (the material, then the texture's
+        // descriptor: two of a block's four dependent round trips — the level offsets and the texels are the other two; such a
+        // block takes 4x the time of a plain one by the probe build's counters, and the waves that draw them end the launch)
+        float kill_factor = 1.0f, kill_cutoff = 0.0f, kill_T[3][2] = {};
+        int32_t kill_tex = -1;
+        tr_dtex_head kill_head = {};
+        const TR_CONSTANT uint32_t* kill_offsets = nullptr;
+        if (alpha_clip) {
+            const TR_CONSTANT tr_tri_record& whole = *as_constant(records + t);   // (not in `rec`: the material and the uv corners)
+            const TR_CONSTANT tr_material_info& m = *as_constant(alpha.materials + whole.material_id);
+            kill_factor = m.diffuse_factor[3];
+            kill_cutoff = m.alpha_clipping_cutoff;
+            kill_tex = m.textures.diffuse;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { kill_T[i][0] = whole.T[i][0]; kill_T[i][1] = whole.T[i][1]; }
+            if (kill_tex >= 0 && (uint32_t)kill_tex < alpha.num_textures) {
+                cdtex* d = as_constant(alpha.textures) + kill_tex;
+                kill_head = texture_head(d);
+                kill_offsets = d->offset;
+            }
+        }
         // the item's fragments tag the coverage words of the (at most two) 64-pixel tile columns it spans, upper and lower
         // half: collected here (scalar) and written once behind the block loop instead of once per block
         uint32_t cover_bits[kItemTileColumns][2] = {};
         TR_RT(const unsigned long long rt_t2 = TR_RT_NOW(); rt_pro += rt_t2 - rt_t1;)
         while (blocks) {
-            TR_RT(++rt_nblocks;)
+            TR_RT(++rt_nblocks; rt_alpha += alpha_clip ? 1ull : 0ull;)
             const uint32_t bx = bstart + (uint32_t)(__ffs((int)blocks) - 1);
             blocks &= blocks - 1u;
             const uint32_t px = bx * 8u + (lane & 7u);
@@ -433,12 +455,9 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             if (hit && alpha_clip) {
                 // implicit-LOD fetch of the diffuse texture: uv at the two quad partners from the same triangle
                 // (what helper invocations compute), differences oriented like dFdx / dFdy
-                const TR_CONSTANT tr_tri_record& whole = *as_constant(records + t);   // (not in `rec`: the material and the uv corners)
-                const tr_material_info& m = alpha.materials[whole.material_id];
-                float alpha_v = m.diffuse_factor[3];
-                const int32_t tex_id = m.textures.diffuse;
-                if (tex_id >= 0 && (uint32_t)tex_id < alpha.num_textures) {
-                    auto uv_at = [&](const float l[3], int c) { return (l[0] * whole.T[0][c] + l[1] * whole.T[1][c]) + l[2] * whole.T[2][c]; };
+                float alpha_v = kill_factor;
+                if (kill_offsets != nullptr) {
+                    auto uv_at = [&](const float l[3], int c) { return (l[0] * kill_T[0][c] + l[1] * kill_T[1][c]) + l[2] * kill_T[2][c]; };
                     float lx[3], ly[3], dd;
                     tri_pixel(rec, (float)(px ^ 1u) + 0.5f, (float)py + 0.5f, lx, dd);
                     tri_pixel(rec, (float)px + 0.5f, (float)(py ^ 1u) + 0.5f, ly, dd);
@@ -450,12 +469,12 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
                     dv.dudy = (uv_at(ly, 0) - u) * sy;
                     dv.dvdy = (uv_at(ly, 1) - v) * sy;
                     texture_fetch tf;
-                    texture_issue(tf, alpha.tex_arena, as_constant(alpha.textures) + tex_id, u, v, dv);
+                    texture_issue(tf, alpha.tex_arena, kill_head, kill_offsets, u, v, dv);
                     alpha_v *= texture_resolve_channel<3>(tf, false, nullptr);
-                } else if (tex_id != -1) {
+                } else if (kill_tex != -1) {
                     alpha_v = 0.0f;   // unbound slot reads as zero
                 }
-                hit = !(alpha_v < m.alpha_clipping_cutoff);
+                hit = !(alpha_v < kill_cutoff);
             }
             // (Testing the word with a plain or agent-scope load first and skipping fragments that already lose — the word only
             //  grows within a frame — measured SLOWER, 57.6 -> 62.5 us on the 4K mesh frame: the load costs an L2 channel slot
@@ -466,6 +485,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
             // conservative: a fragment that loses the depth test later has tagged its tile all the same).  The resolve
             // and the shading launches skip tiles by these words.
             const unsigned long long hits = ballot(hit);
+            TR_RT(rt_frags += (unsigned long long)__popcll(hits);)
             const uint32_t col = (bx >> 3) - (bstart >> 3), bits = 1u | (rec.flags & 6u);
             if ((uint32_t)hits != 0u) cover_bits[col][0] |= bits;
             if ((uint32_t)(hits >> 32) != 0u) cover_bits[col][1] |= bits;
@@ -484,14 +504,26 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
     }
     TR_RT(const unsigned long long rt_issue = TR_RT_NOW() - rt_begin; asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           const unsigned long long rt_total = TR_RT_NOW() - rt_begin;
+          if (lane == 0u && layer == 0u && first < 8192u) {
+              unsigned long long* w = tr_raster_wave_log[first];
+              w[0] = rt_total; w[1] = rt_search; w[2] = rt_blocks; w[3] = rt_items | (rt_nblocks << 16) | (rt_alpha << 32) | (rt_frags << 48 >> 48 << 48);
+              w[4] = rt_frags; w[5] = rt_real0; w[6] = __builtin_amdgcn_s_memrealtime(); w[7] = rt_pro;
+          }
           if (lane == 0u && layer == 0u) {
               const uint32_t s = blockIdx.x & 1023u;
               atomicAdd(&tr_raster_timing[0][s], rt_search); atomicAdd(&tr_raster_timing[1][s], rt_pro);
               atomicAdd(&tr_raster_timing[2][s], rt_blocks); atomicAdd(&tr_raster_timing[3][s], rt_total);
               atomicAdd(&tr_raster_timing[4][s], rt_items);  atomicAdd(&tr_raster_timing[5][s], 1ull);
               atomicMax(&tr_raster_timing[6][s], rt_total);  atomicAdd(&tr_raster_timing[7][s], rt_nblocks);
-              atomicAdd(&tr_raster_timing[8][s], rt_issue);  atomicMax(&tr_raster_timing[9][s], rt_items);
-          })
+              atomicAdd(&tr_raster_timing[8][s], rt_issue);  atomicAdd(&tr_raster_timing[9][s], rt_alpha);
+              atomicAdd(&tr_raster_timing[11][s], rt_frags);
+          }
+          __shared__ unsigned long long rt_wg[2];   // what pooling the workgroup's items would level: its waves' mean busy time
+          if (threadIdx.x == 0u) { rt_wg[0] = 0ull; rt_wg[1] = 0ull; }
+          __syncthreads();
+          if (lane == 0u) { atomicAdd(&rt_wg[0], rt_total - rt_search); atomicAdd(&rt_wg[1], rt_search); }
+          __syncthreads();
+          if (threadIdx.x == 0u && layer == 0u) atomicMax(&tr_raster_timing[10][blockIdx.x & 1023u], rt_wg[0] / 4ull + rt_wg[1] / 4ull);)
 }
 
 struct tr_layer_planes {

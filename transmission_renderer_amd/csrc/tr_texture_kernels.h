@@ -126,23 +126,33 @@ struct texture_fetch {
 // Issues the eight taps of texture.sample(sampler, uv) with implicit LOD (Vulkan 1.3 "Scale Factor Operation"):
 //   rho = max(|(du/dx w, dv/dx h)|, |(du/dy w, dv/dy h)|), lambda = log2(rho) clamped to [0, levels-1],
 //   LINEAR between floor(lambda) and the next level.
-__device__ __forceinline__ void texture_issue(texture_fetch& f, const uint32_t* __restrict__ arena, cdtex* t, float u,
-                                              float v, const uv_derivs& d) {
-    const float wf = t->wf, hf = t->hf;
+// (`head`: the descriptor's scalars, which a caller with several fetches of one texture reads once — the rasteriser's alpha kill)
+struct tr_dtex_head {
+    uint32_t width, height, levels;
+    float wf, hf, max_lod;
+};
+__device__ __forceinline__ tr_dtex_head texture_head(cdtex* t) { return {t->width, t->height, t->levels, t->wf, t->hf, t->max_lod}; }
+__device__ __forceinline__ void texture_issue(texture_fetch& f, const uint32_t* __restrict__ arena, const tr_dtex_head& t,
+                                              const TR_CONSTANT uint32_t* level_offset, float u, float v, const uv_derivs& d) {
+    const float wf = t.wf, hf = t.hf;
     const float mxx = d.dudx * wf, mxy = d.dvdx * hf, myx = d.dudy * wf, myy = d.dvdy * hf;
     const float rho2 = fmaxf(fmaf(mxx, mxx, mxy * mxy), fmaf(myx, myx, myy * myy));
     const float lambda = 0.5f * fast_log2(rho2);                   // log2(sqrt(rho2)); rho2 = 0 -> -inf -> level 0
-    const float l = fminf(fmaxf(lambda, 0.0f), t->max_lod);       // NaN -> 0
+    const float l = fminf(fmaxf(lambda, 0.0f), t.max_lod);        // NaN -> 0
     const float lf = floorf(l);
     f.frac = l - lf;
     const uint32_t l0 = (uint32_t)lf;
-    const uint32_t l1 = min(l0 + 1u, t->levels - 1u);
+    const uint32_t l1 = min(l0 + 1u, t.levels - 1u);
     // the level offsets are the only per-pixel table read: one 8-byte load of (offset[l0], offset[l0 + 1])
-    const u32x2_a4 o = *reinterpret_cast<const TR_CONSTANT u32x2_a4*>(t->offset + l0);
-    const uint32_t w = t->width, h = t->height;
+    const u32x2_a4 o = *reinterpret_cast<const TR_CONSTANT u32x2_a4*>(level_offset + l0);
+    const uint32_t w = t.width, h = t.height;
     const float uu = u - floorf(u), vv = v - floorf(v);
     texture_issue_level(f.q[0], arena + o.x, max(w >> l0, 1u), max(h >> l0, 1u), uu, vv);
     texture_issue_level(f.q[1], arena + o.y, max(w >> l1, 1u), max(h >> l1, 1u), uu, vv);
+}
+__device__ __forceinline__ void texture_issue(texture_fetch& f, const uint32_t* __restrict__ arena, cdtex* t, float u,
+                                              float v, const uv_derivs& d) {
+    texture_issue(f, arena, texture_head(t), t->offset, u, v, d);
 }
 
 // Filters channel `k` of the fetched taps.  sRGB channels are decoded through the LDS copy of the table before
