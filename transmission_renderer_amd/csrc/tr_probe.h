@@ -25,6 +25,7 @@
 #if TR_TIMING
 namespace tr {
 __device__ unsigned long long tr_timing_counters[12][1024];   // spread over 1024 slots: same-address atomics serialise
+__device__ unsigned long long tr_shade_wave_log[65536][4];     // per wave of the LAST opaque VIS launch: begin, end (100 MHz), tiles, covered tiles
 __device__ __forceinline__ unsigned long long tr_now() { return __builtin_amdgcn_s_memtime(); }
 __device__ __forceinline__ void tr_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 struct tr_timer { unsigned long long wait[5]; };
@@ -54,6 +55,12 @@ struct tr_timer { unsigned long long wait[5]; };
         atomicAdd(&tr_timing_counters[7][blockIdx.x & 1023u], __builtin_amdgcn_s_memrealtime() - t_real);        \
         atomicAdd(&tr_timing_counters[8][blockIdx.x & 1023u], timer.wait[3]);                                    \
         atomicAdd(&tr_timing_counters[9][blockIdx.x & 1023u], timer.wait[4]);                                    \
+        if (VIS && !TRANSMISSIVE && blockIdx.x < 65536u) {                                                       \
+            tr_shade_wave_log[blockIdx.x][0] = t_real;                                                           \
+            tr_shade_wave_log[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                                 \
+            tr_shade_wave_log[blockIdx.x][2] = tiles_done;                                                       \
+            tr_shade_wave_log[blockIdx.x][3] = timer.wait[0];                                                    \
+        }                                                                                                        \
     }
 #else
 #define TR_PROBE_ARGS_DECL
@@ -103,6 +110,16 @@ extern "C" int32_t tr_debug_read_timing(unsigned long long out[12]) {
             std::fprintf(stderr, "xcd %d: longest wave %llu, mean %llu, waves %llu, tiles %llu; per block slot (loop ticks/tiles):", x, mx, waves ? sum / waves : 0, waves, tiles);
             for (int i = x; i < 1024; i += 8 * 8) std::fprintf(stderr, " %llu/%llu", host[5][i] ? host[3][i] / host[5][i] : 0, host[5][i] ? host[4][i] / host[5][i] : 0);
             std::fprintf(stderr, "\n");
+        }
+    }
+    if (const char* path = std::getenv("TR_WAVE_LOG")) {   // per wave of the last opaque VIS launch, as text
+        static unsigned long long log[65536][4];
+        if (hipMemcpyFromSymbol(log, HIP_SYMBOL(tr::tr_shade_wave_log), sizeof(log)) == hipSuccess) {
+            if (FILE* fp = std::fopen(path, "w")) {
+                for (int i = 0; i < 65536; ++i)
+                    if (log[i][1]) std::fprintf(fp, "%d %llu %llu %llu %llu\n", i, log[i][0], log[i][1], log[i][2], log[i][3]);
+                std::fclose(fp);
+            }
         }
     }
     unsigned long long per_xcd[8] = {0};   // busy ticks per XCD (block b runs on XCD b % 8)
