@@ -304,13 +304,14 @@ struct tr_raster_layers {
     uint32_t* tile_cover[2];     // [ceil(h/4)][ceil(w/64)], zeroed
     uint32_t enabled[2];         // (a layer that cannot have triangles has no buffers)
 };
-#ifdef TR_RASTER_TIMING   // profiling builds only (tools/build_variant.py): where the raster waves spend their time
-__device__ unsigned long long tr_raster_timing[12][1024];
-__device__ unsigned long long tr_raster_wave_log[8192][8];   // per wave of the opaque layer
-#define TR_RT_NOW() __builtin_amdgcn_s_memtime()
-#define TR_RT(x) x
+// Measurement hooks of the rasteriser: the product build defines them away; tools/build_variant.py NAME -DTR_RASTER_TIMING=1
+// gets them from tr_raster_probe.h (per-wave phase counters and a per-wave log of the opaque layer's launch).
+#ifdef TR_RASTER_TIMING
+#include "tr_raster_probe.h"
 #else
 #define TR_RT(x)
+#define TR_RT_WAVE_BEGIN
+#define TR_RT_WAVE_END
 #endif
 // The part of tr_tri_record the coverage and depth tests read (tr_visibility.h: the words before T), wave-uniform in
 // scalar registers.
@@ -337,8 +338,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
     // Wave w owns the items w, w + W, w + 2W, ... (W = number of waves: neighbouring rows of a large triangle go to
     // different waves).  It takes 64 of them at a time: every lane finds the triangle of one item (a binary search
     // over the prefix array, 64 searches in flight together), then the wave works through the 64 items one by one.
-    TR_RT(unsigned long long rt_search = 0; unsigned long long rt_pro = 0; unsigned long long rt_blocks = 0; unsigned long long rt_items = 0;
-          unsigned long long rt_nblocks = 0; unsigned long long rt_frags = 0; unsigned long long rt_alpha = 0; const unsigned long long rt_begin = TR_RT_NOW(); const unsigned long long rt_real0 = __builtin_amdgcn_s_memrealtime();)
+    TR_RT_WAVE_BEGIN
     // one or two batches per wave: the search's round trips are exposed (the waves all search together), and the wide search
     // is 1.7 us of the 4K demo frame; with many batches the waves hide each other's trips and its sevenfold loads cost 4 %
     const bool few_batches = n_items <= 128u * waves;
@@ -502,28 +502,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, c
         }
       }
     }
-    TR_RT(const unsigned long long rt_issue = TR_RT_NOW() - rt_begin; asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          const unsigned long long rt_total = TR_RT_NOW() - rt_begin;
-          if (lane == 0u && layer == 0u && first < 8192u) {
-              unsigned long long* w = tr_raster_wave_log[first];
-              w[0] = rt_total; w[1] = rt_search; w[2] = rt_blocks; w[3] = rt_items | (rt_nblocks << 16) | (rt_alpha << 32) | (rt_frags << 48 >> 48 << 48);
-              w[4] = rt_frags; w[5] = rt_real0; w[6] = __builtin_amdgcn_s_memrealtime(); w[7] = rt_pro;
-          }
-          if (lane == 0u && layer == 0u) {
-              const uint32_t s = blockIdx.x & 1023u;
-              atomicAdd(&tr_raster_timing[0][s], rt_search); atomicAdd(&tr_raster_timing[1][s], rt_pro);
-              atomicAdd(&tr_raster_timing[2][s], rt_blocks); atomicAdd(&tr_raster_timing[3][s], rt_total);
-              atomicAdd(&tr_raster_timing[4][s], rt_items);  atomicAdd(&tr_raster_timing[5][s], 1ull);
-              atomicMax(&tr_raster_timing[6][s], rt_total);  atomicAdd(&tr_raster_timing[7][s], rt_nblocks);
-              atomicAdd(&tr_raster_timing[8][s], rt_issue);  atomicAdd(&tr_raster_timing[9][s], rt_alpha);
-              atomicAdd(&tr_raster_timing[11][s], rt_frags);
-          }
-          __shared__ unsigned long long rt_wg[2];   // what pooling the workgroup's items would level: its waves' mean busy time
-          if (threadIdx.x == 0u) { rt_wg[0] = 0ull; rt_wg[1] = 0ull; }
-          __syncthreads();
-          if (lane == 0u) { atomicAdd(&rt_wg[0], rt_total - rt_search); atomicAdd(&rt_wg[1], rt_search); }
-          __syncthreads();
-          if (threadIdx.x == 0u && layer == 0u) atomicMax(&tr_raster_timing[10][blockIdx.x & 1023u], rt_wg[0] / 4ull + rt_wg[1] / 4ull);)
+    TR_RT_WAVE_END
 }
 
 struct tr_layer_planes {

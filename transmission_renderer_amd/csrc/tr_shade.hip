@@ -2255,29 +2255,6 @@ tr_status tr_record_frame_timed(tr_context* ctx, const tr_frame_desc* f, void* s
 }  // extern "C"
 
 #ifdef TR_RASTER_TIMING
-// (profiling builds only, not declared in include/) sums and clears the raster waves' phase counters of the opaque layer
-extern "C" int32_t tr_debug_read_raster_timing(unsigned long long out[12]) {
-    static unsigned long long host[12][1024];
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tr::tr_raster_timing), sizeof(host)) != hipSuccess) return -1;
-    for (int k = 0; k < 12; ++k) {
-        out[k] = 0;
-        for (int i = 0; i < 1024; ++i) out[k] = (k == 6 || k == 10) ? std::max(out[k], host[k][i]) : out[k] + host[k][i];
-    }
-    if (const char* path = std::getenv("TR_WAVE_LOG")) {   // per wave: the raw log, as text
-        static unsigned long long log[8192][8];
-        if (hipMemcpyFromSymbol(log, HIP_SYMBOL(tr::tr_raster_wave_log), sizeof(log)) == hipSuccess) {
-            if (FILE* fp = std::fopen(path, "w")) {
-                for (int i = 0; i < 8192; ++i)
-                    std::fprintf(fp, "%d %llu %llu %llu %llu %llu %llu %llu %llu\n", i, log[i][0], log[i][1], log[i][2], log[i][3], log[i][4], log[i][5], log[i][6], log[i][7]);
-                std::fclose(fp);
-            }
-        }
-    }
-    if (std::getenv("TR_TIMING_DUMP")) {   // per block slot: mean wave ticks, blocks visited, live items
-        for (int i = 0; i < 1024; ++i)
-            std::fprintf(stderr, "slot %d %llu %llu %llu %llu %llu %llu %llu %llu\n", i, host[5][i] ? host[3][i] / host[5][i] : 0ull, host[7][i], host[4][i], host[5][i] ? host[0][i] / host[5][i] : 0ull, host[11][i], host[9][i], host[6][i], host[10][i]);
-    }
-    std::memset(host, 0, sizeof(host));
-    return hipMemcpyToSymbol(HIP_SYMBOL(tr::tr_raster_timing), host, sizeof(host)) == hipSuccess ? 0 : -1;
-}
+#define TR_RASTER_PROBE_HOST 1
+#include "tr_raster_probe.h"   // (profiling builds only) tr_debug_read_raster_timing
 #endif
