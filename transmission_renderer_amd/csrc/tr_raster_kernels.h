@@ -124,23 +124,17 @@ __device__ __forceinline__ uint32_t upper_index(const uint32_t* __restrict__ bas
 }
 
 // The same index by an 8-ary search: seven pivots are loaded together per step, so 1 000 entries take 4 dependent round
-// trips instead of 10 and 200 000 take 6 instead of 18.
+// trips instead of 10 and 200 000 take 6 instead of 18.  `base` has n + 1 entries and base[n] > x (the total): a pivot
+// beyond the interval is clamped to its end, whose entry is above x by the search's invariant — no bounds test per pivot.
 __device__ __forceinline__ uint32_t upper_index_wide(const uint32_t* __restrict__ base, uint32_t n, uint32_t x) {
     uint32_t lo = 0, hi = n;
     while (hi - lo > 1u) {
         const uint32_t step = (hi - lo + 7u) >> 3;
-        uint32_t v[7];
-#pragma unroll
-        for (uint32_t j = 0; j < 7u; ++j) {
-            const uint32_t p = lo + (j + 1u) * step;
-            v[j] = p < hi ? base[p] : 0xFFFFFFFFu;
-        }
         uint32_t c = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < 7u; ++j) c += (v[j] <= x && lo + (j + 1u) * step < hi) ? 1u : 0u;
-        const uint32_t nlo = lo + c * step;
-        hi = min(nlo + step, hi);
-        lo = nlo;
+        for (uint32_t j = 1; j <= 7u; ++j) c += ld<uint32_t>(base, min(lo + j * step, hi) * 4u) <= x ? 1u : 0u;
+        lo += c * step;
+        hi = min(lo + step, hi);
     }
     return lo;
 }
