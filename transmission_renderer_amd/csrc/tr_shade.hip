@@ -210,7 +210,7 @@ struct tr_context {
     struct stream_seen { hipStream_t stream; uint64_t generation; };
     std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
     bool no_mid_class = false;                  // TR_NO_MID_CLASS (tests only), read once at context creation
-    uint32_t vis_grid_rounds = 3;               // see persistent_grid (TR_VIS_ROUNDS: tuning only)
+    uint32_t vis_grid_rounds = 4;               // see persistent_grid (TR_VIS_ROUNDS: tuning only)
     uint32_t front_list_waves_per_cu = 48;      // the transmissive VIS launch's grid when it walks the list of covered tiles (TR_FRONT_LIST_WAVES: tuning only; 0: no list)
     uint32_t raster_wgs_per_cu = 6;             // raster_kernel's persistent grid: 4 -> 191 / 199 us (4K mesh / glTF demo frame), 6 -> 191 / 192,
                                                 // 8 -> 194 / 195, 12 -> 191 / 196, 16 -> 198 / 199 (TR_RASTER_WGS_PER_CU: tuning only)
@@ -540,7 +540,8 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
 // longer-lived waves — kVisGridRounds instead of kGridRounds times what is resident.  4K mesh frame by rounds
 // (TR_BLOCKS_PER_XCD sweep, all shading launches of the frame): 1 -> 243.8 us, 2 -> 227.0, 4 -> 227.0, 7 -> 228.9,
 // 8 -> 232.1, 16 -> 247.0: a wave's start (kernarg loads, the sRGB table into LDS) is paid per wave, and a frame's covered
-// tiles are spread evenly over the stripes anyway.  The synthetic G-buffer's plane launches keep 8 (§3.1 of DESIGN.md).
+// tiles are spread evenly over the stripes anyway.  (End of round 4, frame at 172 us: 2 and 3 -> 172.2, 4 -> 170.6, 5 -> 172.2;
+// glTF demo 176.0 / 173.9 / 173.6: 4.)  The synthetic G-buffer's plane launches keep 8 (§3.1 of DESIGN.md).
 uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles, bool vis = false) {
     const uint32_t per_xcd = (ntiles + 7u) / 8u;
     uint32_t bpx = vis ? ctx->blocks_per_xcd / kGridRounds * ctx->vis_grid_rounds : ctx->blocks_per_xcd;
