@@ -219,6 +219,61 @@ def test_long_thin_triangles_at_a_grazing_angle(renderer):
     assert (want_o["material_id"] == 3).mean() > 0.1 and (want_t["material_id"] == 4).any()
 
 
+def test_screen_filling_degenerate_and_off_screen_triangles(renderer):
+    """Two triangles that fill the frame from close up (bounds clamped to the frame: the most work items a triangle can
+    have), zero-area triangles (a strip of zero width: no work item may produce a fragment), a sphere whose instance passes
+    the frustum test while most of its triangles lie off screen (empty bounds: zero work items in the prefix array) and a
+    layer without any triangle: bit-exact."""
+    w, h = 640, 360
+    _, view = wire.default_camera()
+    mb = meshes.ModelBuffers()
+    S = meshes.Similarity
+    f32 = np.float32
+    wall = meshes.quat_from_axis_angle([1, 0, 0], np.pi / 2)       # the plane turned to face the camera
+    mb.add_primitive(meshes.plane(40.0, 40.0, cells=1), 0, [(S(np.array([0, 1.5, -9.0], f32), 1.0, wall), 5)])
+    mb.add_primitive(meshes.plane(0.0, 3.0, cells=4), 0, [(S(np.array([0, 1.5, -3.0], f32), 1.0, wall), 6)])
+    mb.add_primitive(meshes.uv_sphere(1.0, 24, 12), 0, [(S(np.array([-6.4, 1.5, -5.0], f32), 1.6), 9), (S(np.array([0.4, 4.9, -4.0], f32), 1.2), 1)])
+    geo = mb.finish()
+    sc = _scene(w, h, view, alpha_cutoffs=(0.0, 0.0))
+    (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    got_o, got_t = _gpu_layers(renderer, geo, sc, w, h, culling)
+    assert _compare(got_o, want_o) == 0 and _compare(got_t, want_t) == 0
+    ids = want_o["material_id"].view(np.int32)
+    assert (ids != -1).all() and (ids == 5).mean() > 0.5 and not (ids == 6).any()     # the wall fills the frame, the strip draws nothing
+    assert (ids == 9).any() and (ids == 1).any()                                       # both spheres reach into the frame
+    assert (want_t["material_id"].view(np.int32) == -1).all()
+
+
+def test_rasterising_entries_refuse_a_capturing_stream(renderer):
+    """tr_draw_scene (and tr_rasterize / tr_record_frame through the same check) carries a per-call frame counter as a launch
+    argument: under stream capture it is refused (status 6) before anything is enqueued, and the context works on afterwards."""
+    from transmission_renderer_amd import _lib
+    w, h = 256, 128
+    view = wire.default_camera()[1]
+    geo = meshes.make_mesh_scene()
+    sc = _scene(w, h, view, alpha_cutoffs=(0.0, 0.0))
+    (want_o, want_t), culling = _oracle_layers(geo, sc, w, h, view)
+    got_o, _ = _gpu_layers(renderer, geo, sc, w, h, culling)          # (uploads; a first, uncaptured call)
+    o, t = renderer.new_layer(w, h), renderer.new_layer(w, h)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    status = None
+    with torch.cuda.stream(side):
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            try:
+                renderer.draw_scene(culling, sc["push"], o, t)
+            except _lib.TrError as e:
+                status = e.status
+            torch.zeros(4, device=renderer.device).add_(1.0)           # (something to capture, so that the graph is not empty)
+    torch.cuda.synchronize()
+    assert status == 6
+    renderer.draw_scene(culling, sc["push"], o, t)
+    torch.cuda.synchronize()
+    assert np.array_equal(o.material_id.cpu().numpy().view(np.uint32), got_o["material_id"])
+    assert _compare(got_o, want_o) == 0
+
+
 def test_rasterize_then_shade_end_to_end(renderer, ggx_lut):
     """glTF-shaped path: geometry -> layers -> opaque pass -> mips -> transmissive pass, GPU vs the oracle doing the
     same from its own layers (T1-style bound on the final RGBA16F frame)."""

@@ -1193,6 +1193,13 @@ void fill_two_layers(const tr_context* ctx, const void* const draws[TR_NUM_DRAW_
     }
 }
 
+// The set-up launch's epoch is a launch argument: a graph replay would repeat it (stale look-back words would read as current).
+// The entries that rasterise refuse a capturing stream before they enqueue anything.
+bool stream_is_capturing(void* stream) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing((hipStream_t)stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone;
+}
+
 // fused_demux: the frame recorder's call — its first launch has demultiplexed the draws and scanned both layers' draw
 // streams behind its culling blocks (frame_front_kernel) and zeroed the coverage maps.
 // resolve: write the TGB-v1 planes.  Without it the layers stay visibility words + triangle planes, which the caller
@@ -1211,6 +1218,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     if (!ctx->d_position || ctx->num_materials == 0) return TR_ERR_TABLES_MISSING;
     if (ctx->max_texture_id >= (int32_t)ctx->num_textures) return TR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
+    if (stream_is_capturing(stream_)) return TR_ERR_UNSUPPORTED;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)w * h;
     {
@@ -1294,6 +1302,7 @@ tr_status tr_draw_scene(tr_context* ctx, const tr_culling_push_constants* cullin
                         const tr_gbuffer_target* opaque, const tr_gbuffer_target* transmissive, void* stream) {
     if (!ctx || !culling || !push) return TR_ERR_INVALID_ARGUMENT;
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
+    if (stream_is_capturing(stream)) return TR_ERR_UNSUPPORTED;
     tr_status st = tr_frustum_culling(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instances, ctx->num_instances,
                                       culling, ctx->d_instance_counts, stream);
     if (st != TR_OK) return st;
@@ -2064,6 +2073,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (w == 0 || h == 0 || w > 65535u || h > 65535u) return TR_ERR_INVALID_ARGUMENT;
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
     if (ctx->strip_rows != 0u) return TR_ERR_UNSUPPORTED;   // (the frame recorder renders whole frames)
+    if (stream_is_capturing(stream)) return TR_ERR_UNSUPPORTED;
     ctx->cover_cleared = false;
     // RGBA16F frames are shaded straight from the rasteriser's visibility words (shade_kernel's VIS launches): no resolve,
     // the work planes of the descriptor stay untouched.  RGBA32F frames go through the planes.
