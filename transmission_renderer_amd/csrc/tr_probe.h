@@ -7,7 +7,9 @@
 //   -DTR_PROBE_MASK=n   the same phases compiled out (register-pressure probes, tools/kernel_stats.py)
 //   -DTR_TIMING=1       every wave adds the cycles it waited for (0) the planes, (1) the cluster lists, (2) taps + LUT, (3)
 //                       its loop time, (4) tiles into tr_timing_counters (tr_debug_read_timing; tools/gpu_timing_cold.py);
-//                       slots 8 / 9: the time in a textured material's sampling front end / in the light loops
+//                       slots 8 / 9: the time in a textured material's sampling front end / in the light loops; every wave of
+//                       the frame recorder's opaque launch (-DTR_TIMING=2: of its transmissive launch) also logs its begin and
+//                       end on the 100 MHz clock and its tiles (tr_shade_wave_log; TR_WAVE_LOG=path writes it as text)
 #pragma once
 
 #ifndef TR_ABLATION
@@ -55,7 +57,7 @@ struct tr_timer { unsigned long long wait[5]; };
         atomicAdd(&tr_timing_counters[7][blockIdx.x & 1023u], __builtin_amdgcn_s_memrealtime() - t_real);        \
         atomicAdd(&tr_timing_counters[8][blockIdx.x & 1023u], timer.wait[3]);                                    \
         atomicAdd(&tr_timing_counters[9][blockIdx.x & 1023u], timer.wait[4]);                                    \
-        if (VIS && !TRANSMISSIVE && blockIdx.x < 65536u) {                                                       \
+        if (VIS && TRANSMISSIVE == (TR_TIMING == 2) && blockIdx.x < 65536u) {   /* -DTR_TIMING=2: the transmissive VIS launch instead */                                                       \
             tr_shade_wave_log[blockIdx.x][0] = t_real;                                                           \
             tr_shade_wave_log[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                                 \
             tr_shade_wave_log[blockIdx.x][2] = tiles_done;                                                       \
