@@ -286,7 +286,7 @@ def test_debug_clusters_and_cluster_lookup_exact(renderer, ggx_lut):
     assert len(np.unique(np.round(o32.reshape(-1, 4), 4), axis=0)) >= 8      # several clusters / counts in view
 
 
-@pytest.mark.parametrize("w,h", [(256, 256), (250, 130), (1920, 1080), (3, 5)])
+@pytest.mark.parametrize("w,h", [(256, 256), (250, 130), (1920, 1080), (3, 5), (3840, 2160), (2047, 1025), (400, 164)])
 def test_mip_chain_bit_exact(renderer, w, h):
     from transmission_renderer_amd.renderer import OpaquePyramid
     r = renderer
