@@ -194,6 +194,9 @@ struct tr_frame_params {
     uint32_t rect_x0, rect_y0, rect_x1, rect_y1;
     uint32_t tiles_x, tiles_y;   // 64x4 tiles covering the rect
     uint32_t tiles_x_magic;      // floor(2^32 / tiles_x): tile / tiles_x on the scalar unit (one fix-up step)
+    uint32_t j_step;             // waves of the grid per XCD (per sub-list when the launch walks the front list): what a wave's tile
+                                 // index advances by — from the host: read through the hidden grid-size argument, its pointer
+                                 // occupies a scalar register pair across the whole tile
     uint32_t stripe_tiles;       // VIS launches: block tiles per stripe of kStripeTileRows tile rows, and
     uint32_t stripe_magic;       // floor(2^32 / stripe_tiles)
     // Rank-interleaved strips (tr_set_strips; 0 tile rows = off): the rect is the frame, tile row r of the launch is the
@@ -229,7 +232,7 @@ struct tr_launch {
     const float4* lut_lines;            // per material: the LUT at the material's roughness, (A,B)[x-1], (A,B)[x] per entry
     const tr_level_table* levels;
     const tr_dtap* dtaps;               // per material, see tr_dtap
-    const uint16_t* cluster_x;          // [frame width]  u32(frag_coord.x / cluster_size.x)
+    const uint32_t* cluster_x;          // [frame width]  u32(frag_coord.x / cluster_size.x)
     const uint32_t* cluster_y_term;     // [frame height] u32(frag_coord.y / cluster_size.y) * num_clusters.x
     const float4* pos_depth;
     const float4* nrm_scale;
@@ -995,9 +998,10 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
         float k = fmaf(m_neg_eta2(*mb), fmaf(-nov_raw, nov_raw, 1.0f), 1.0f);
         float cn = fmaf(-eta, nov_raw, fast_sqrt(k));   // eta * n.i + sqrt(k), n.i = -n.v
         len = mb->thickness * ns.w;                      // thickness * model_scale :264
-        float ex = fmaf(fmaf(-eta, v.x, -cn * n.x), len, pos.x);
-        float ey = fmaf(fmaf(-eta, v.y, -cn * n.y), len, pos.y);
-        float ez = fmaf(fmaf(-eta, v.z, -cn * n.z), len, pos.z);
+        const float len_exit = TR_ABLATE(L, 256u) ? 0.0f : len;   // (profiling: the taps at the pixel's own place, a streaming pattern)
+        float ex = fmaf(fmaf(-eta, v.x, -cn * n.x), len_exit, pos.x);
+        float ey = fmaf(fmaf(-eta, v.y, -cn * n.y), len_exit, pos.y);
+        float ez = fmaf(fmaf(-eta, v.z, -cn * n.z), len_exit, pos.z);
         const TR_CONSTANT float* P = L->fp.proj_view;   // column-major
         float cx = fmaf(P[8], ez, fmaf(P[4], ey, fmaf(P[0], ex, P[12])));
         float cy = fmaf(P[9], ez, fmaf(P[5], ey, fmaf(P[1], ex, P[13])));
@@ -1005,6 +1009,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
         float hw = 0.5f * rcp(cw);                      // (clip.xy / clip.w + 1) / 2  :330-332
         float tu = fmaf(cx, hw, 0.5f);
         float tv = fmaf(cy, hw, 0.5f);
+        if (TR_ABLATE(L, 512u)) tu = tv = 0.5f;   // (profiling: every tap the same texels: no tap traffic, the same instructions)
         // lod = log2(framebuffer width) * roughness * clamp(2 ior - 2, 0, 1) (:334-335): the material's alone when it
         // has no texture slots (its tap record), per lane otherwise
         if constexpr (SCALAR_MATERIAL) {
@@ -1067,8 +1072,19 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
             }
         } while (pending != 0ull);
     };
-    // ================= phase 4: resolve the taps, composite =================
-    auto finish = [&]() -> f3 {
+    // ================= phase 4: the refraction taps, their resolve, the composite =================
+    // Order: lights first, then the refraction taps and their resolve.  Issuing the taps before the light loop
+    // would hide their latency inside the wave, but holds 16 + 6 vector registers across the loop; without them
+    // the kernel fits 64 VGPRs = 8 waves per SIMD, and the other seven waves hide the latency better (measured:
+    // 129 -> 122 us on the 4K frame, profiles/r01).
+    // The light sums are resolved into the pixel's value FIRST (fifteen accumulators become three before the taps'
+    // sixteen registers are requested), and the two sides of `transmits` meet again only at the emission: with one `if`
+    // around the taps and another around their resolve the compiler's wait bookkeeping must assume the taps in flight on
+    // the path that never issued them.
+    auto tail = [&]() -> f3 {
+        tile_phase<2>();
+        TR_PROBE_DRAIN
+        TR_PROBE_SINCE(t_taps)
         claunch* L4 = launder(L);
         MatP mo = launder(m);                  // what a base-colour texture changes is read through `mo`,
         const auto m4 = mat_base(mo);          // every other constant from the record
@@ -1081,6 +1097,15 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
                    fmaf(m4->ks_df[2], acc.sp.z, m4->ks_f0[2] * acc.s.z)};            // specular: sum I nol D*V F
             if (diffuse_on) out = {fmaf(kd[0], acc.d.x, out.x), fmaf(kd[1], acc.d.y, out.y), fmaf(kd[2], acc.d.z, out.z)};
             if (transmits) {
+                out.x = fmaf(m4->kta[0], acc.ta.x, out.x);
+                out.y = fmaf(m4->kta[1], acc.ta.y, out.y);
+                out.z = fmaf(m4->kta[2], acc.ta.z, out.z);
+                out.x = fmaf(-m4->ktb[0], acc.tb.x, out.x);
+                out.y = fmaf(-m4->ktb[1], acc.tb.y, out.y);
+                out.z = fmaf(-m4->ktb[2], acc.tb.z, out.z);
+                issue_taps();
+                TR_PROBE_WAITED(2, t_taps)
+                tile_phase<3>();
                 // ---- ibl_volume_refraction, part 2 (:337-353)
                 f3 T = pyramid_resolve(pf);
                 if (m4->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
@@ -1090,15 +1115,12 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
                 }
                 const v2f AB = lut_line_resolve(lf);
                 const float w = fmaf(-m4->f90, AB.y, 1.0f);      // 1 - (f0 A + f90 B), channel by channel
-                out.x = fmaf(m4->kta[0], acc.ta.x, out.x);
-                out.y = fmaf(m4->kta[1], acc.ta.y, out.y);
-                out.z = fmaf(m4->kta[2], acc.ta.z, out.z);
-                out.x = fmaf(-m4->ktb[0], acc.tb.x, out.x);
-                out.y = fmaf(-m4->ktb[1], acc.tb.y, out.y);
-                out.z = fmaf(-m4->ktb[2], acc.tb.z, out.z);
                 out.x = fmaf(m4->kt[0], fmaf(-m4->f0[0], AB.x, w) * T.x, out.x);
                 out.y = fmaf(m4->kt[1], fmaf(-m4->f0[1], AB.x, w) * T.y, out.y);
                 out.z = fmaf(m4->kt[2], fmaf(-m4->f0[2], AB.x, w) * T.z, out.z);
+            } else {
+                TR_PROBE_WAITED(2, t_taps)
+                tile_phase<3>();
             }
             out = {out.x + m4->emission[0], out.y + m4->emission[1], out.z + m4->emission[2]};
         } else {
@@ -1107,6 +1129,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
                          fmaf(m4->ks_df[2], acc.sp.z, m4->ks_f0[2] * acc.s.z)};
             f3 diffuse = {acc.d.x * mat_c_diff(mo, 0), acc.d.y * mat_c_diff(mo, 1), acc.d.z * mat_c_diff(mo, 2)};
             if (transmits) {
+                issue_taps();
+                TR_PROBE_WAITED(2, t_taps)
+                tile_phase<3>();
                 // ---- ibl_volume_refraction, part 2 (:337-353)
                 f3 T = pyramid_resolve(pf);
                 if (m4->flags & 1u) {  // apply_volume_attenuation (Beer's law) :275-290
@@ -1130,6 +1155,9 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
                 diffuse.x = fmaf(fmaf(tf, tx, -diffuse.x), tf, diffuse.x);
                 diffuse.y = fmaf(fmaf(tf, ty, -diffuse.y), tf, diffuse.y);
                 diffuse.z = fmaf(fmaf(tf, tz, -diffuse.z), tf, diffuse.z);
+            } else {
+                TR_PROBE_WAITED(2, t_taps)
+                tile_phase<3>();
             }
             out = {diffuse.x + acc.s.x + m4->emission[0], diffuse.y + acc.s.y + m4->emission[1],
                    diffuse.z + acc.s.z + m4->emission[2]};
@@ -1141,20 +1169,6 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
             }
         }
         return out;
-    };
-
-    // Order: lights first, then the refraction taps and their resolve.  Issuing the taps before the light loop
-    // would hide their latency inside the wave, but holds 16 + 6 vector registers across the loop; without them
-    // the kernel fits 64 VGPRs = 8 waves per SIMD, and the other seven waves hide the latency better (measured:
-    // 129 -> 122 us on the 4K frame, profiles/r01).
-    auto tail = [&]() -> f3 {
-        tile_phase<2>();
-        TR_PROBE_DRAIN
-        TR_PROBE_SINCE(t_taps)
-        issue_taps();
-        TR_PROBE_WAITED(2, t_taps)
-        tile_phase<3>();
-        return finish();
     };
     TR_PROBE_SINCE(t_lights)
     lights_phase();   // the sun
@@ -1480,7 +1494,7 @@ __device__ __forceinline__ T ld_plane(const void* base, uint32_t byte_offset) {
 }
 constexpr uint32_t kWaveTileW = 16u, kWaveTileH = 4u;                       // wave tile: 16x4 pixels
 constexpr uint32_t kBlockTileW = 4u * kWaveTileW, kBlockTileH = kWaveTileH;   // block tile: four of them side by side
-constexpr uint32_t kGridRounds = 8u;   // waves in the grid per resident wave
+constexpr uint32_t kGridRounds = 4u;   // waves in the grid per resident wave (static launches)
 struct tile_regs {
     float4 pd, ns;
     float2 uv;                                        // TEXTURED only
@@ -1596,7 +1610,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             // (whole-frame launches only: the rect is the frame, its pitch the visibility buffer's)
             const unsigned long long key = ld<unsigned long long>(F->vis, gpix * 8u);
             // (the cluster table entries do not depend on the word: requested with it, ahead of the triangle's planes)
-            t.cluster_x = (uint32_t)ld<uint16_t>(F->cluster_x, cx * 2u);
+            t.cluster_x = ld<uint32_t>(F->cluster_x, cx * 4u);
             t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
             t.mat = TR_NOT_COVERED;
             t.pd = t.ns = float4{0.f, 0.f, 0.f, 0.f};
@@ -1615,13 +1629,12 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         { const f4v a = ld_plane<f4v, (kPlanesNt & 1u) != 0u>(F->pos_depth, gpix * 16u); t.pd = float4{a.x, a.y, a.z, a.w}; }
         { const f4v a = ld_plane<f4v, (kPlanesNt & 2u) != 0u>(F->nrm_scale, gpix * 16u); t.ns = float4{a.x, a.y, a.z, a.w}; }
         if constexpr (TEXTURED) { const f2v a = ld_plane<f2v, (kPlanesNt & 8u) != 0u>(F->uv, gpix * 8u); t.uv = float2{a.x, a.y}; }
-        t.cluster_x = (uint32_t)ld<uint16_t>(F->cluster_x, cx * 2u);
+        t.cluster_x = ld<uint32_t>(F->cluster_x, cx * 4u);
         t.cluster_y_term = ld<uint32_t>(F->cluster_y_term, cy * 4u);
     };
-    // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
-    auto fetch = [&](uint32_t j, tile_regs& t) {
-        claunch* F = launder(L);
-        uint32_t tile = listed ? as_constant(F->front_list)[(blockIdx.x & (kFrontLists - 1u)) * F->front_list_cap + (j >> 2)] : band_start + (j >> 2);
+    // (scalar) wave tile j of this XCD's band -> block tile j / 4 (64x4 pixels) of the rect, and the wave tile's column / row
+    auto tile_of = [&](claunch* F, uint32_t j, uint32_t& tile, uint32_t& txi, uint32_t& tyi) {
+        tile = listed ? as_constant(F->front_list)[(blockIdx.x & (kFrontLists - 1u)) * F->front_list_cap + (j >> 2)] : band_start + (j >> 2);
         if (striped) {   // local tile q of this XCD: stripe q / stripe_tiles of its own, i.e. stripe (that * 8 + xcd) of the frame
             const uint32_t q = j >> 2, st = F->fp.stripe_tiles;
             uint32_t own = __umulhi(q, F->fp.stripe_magic), off = q - own * st;
@@ -1632,8 +1645,8 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             tile = (own * 8u + xcd) * st + off;
         }
         // tile / tiles_x without the vector unit: q = mulhi(tile, floor(2^32 / d)) is the quotient or one less
-        uint32_t tyi = __umulhi(tile, F->fp.tiles_x_magic);
-        uint32_t txi = tile - tyi * F->fp.tiles_x;
+        tyi = __umulhi(tile, F->fp.tiles_x_magic);
+        txi = tile - tyi * F->fp.tiles_x;
         if (txi >= F->fp.tiles_x) {
             txi -= F->fp.tiles_x;
             ++tyi;
@@ -1648,6 +1661,12 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             tyi = (k * F->fp.strip_world + F->fp.strip_rank) * T + r;
         }
         txi = txi * 4u + (j & 3u);
+    };
+    // j = wave tile of this XCD's band: block tile j / 4 (64x4 pixels), quarter j % 4
+    auto fetch = [&](uint32_t j, tile_regs& t) {
+        claunch* F = launder(L);
+        uint32_t tile, txi, tyi;
+        tile_of(F, j, tile, txi, tyi);
         if constexpr (TEX >= kTexFull) {
             // (the lane's place in the tile is derived again per tile: two instructions instead of two registers held —
             //  or spilled — across the whole pixel)
@@ -1773,11 +1792,15 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                     }
                 }
             }
+        } else {
+            // (a tile without work has its table loads arrive here: left in flight on this one path, they make the compiler
+            //  wait for EVERYTHING outstanding — the previous tile's store with them — before the next tile's first load)
+            if constexpr (TEX == kTexNone && !VIS) asm volatile("" :: "v"(cur.cluster_x), "v"(cur.cluster_y_term));   // (the last two loads issued)
         }
         // The next tile's plane loads are issued BEFORE this tile's store: memory operations complete in order, so a
         // load behind the store could not be waited for without waiting for the store's acknowledgement as well.
         const uint32_t out_px = cur.px, out_py = cur.py;
-        j += listed ? gridDim.x / kFrontLists : (gridDim.x >> 3);
+        j += launder(L)->fp.j_step;
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         const bool write = TRANSMISSIVE ? active : inside;
         bool final_colour = true;   // (VIS) no later launch of the frame writes this pixel

@@ -3,7 +3,8 @@
 // __graft_entry__.compile_library refuses such flags for transmission_renderer_amd/libtr_shade.so).
 //   -DTR_ABLATION=1     fp.ablate (TR_ABLATE env, read per launch) switches phases off: bit0 no pyramid taps, bit1 no LUT,
 //                       bit2 no sun, bit3 no punctual lights, bit5 pure streaming skeleton, bit6 no G-buffer traffic
-//                       (synthetic inputs), bit7 no stores
+//                       (synthetic inputs), bit7 no stores, bit8 refraction taps at the pixel's own place (a streaming pattern),
+//                       bit9 every tap the same texels (no tap traffic, the same instructions)
 //   -DTR_PROBE_MASK=n   the same phases compiled out (register-pressure probes, tools/kernel_stats.py)
 //   -DTR_TIMING=1       every wave adds the cycles it waited for (0) the planes, (1) the cluster lists, (2) taps + LUT, (3)
 //                       its loop time, (4) tiles into tr_timing_counters (tr_debug_read_timing; tools/gpu_timing_cold.py);
@@ -39,11 +40,17 @@ struct tr_timer { unsigned long long wait[5]; };
     unsigned long long tiles_done = 0;                                         \
     const unsigned long long t_loop = tr_now();                                \
     const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();   /* constant 100 MHz */
+#if TR_TIMING == 3   /* only a wave's begin, end and tile count: no forced waits, the kernel's own schedule */
+#define TR_PROBE_SINCE(name)
+#define TR_PROBE_DRAIN
+#define TR_PROBE_WAITED(slot, name)
+#else
 #define TR_PROBE_SINCE(name) const unsigned long long name = tr_now();
 #define TR_PROBE_DRAIN tr_drain();
 #define TR_PROBE_WAITED(slot, name) \
     tr_drain();                     \
     timer.wait[slot] += tr_now() - name;
+#endif
 #define TR_PROBE_TILE_DONE ++tiles_done;
 #define TR_PROBE_WAVE_END                                                                                        \
     if (lane == 0) {                                                                                             \

@@ -185,11 +185,11 @@ struct tr_context {
     uint32_t h_levels_count = 0;
 
     // cluster x / y lookup tables (exact u32(frag_coord / cluster_size), shader/src/lib.rs:89)
-    uint16_t* d_cluster_x = nullptr;
+    uint32_t* d_cluster_x = nullptr;
     uint32_t* d_cluster_y_term = nullptr;
     uint32_t cl_w = 0, cl_h = 0, cl_cap_w = 0, cl_cap_h = 0, cl_ncx = 0;
     float cl_sx = 0.0f, cl_sy = 0.0f;
-    std::vector<uint16_t> stage_cluster_x;
+    std::vector<uint32_t> stage_cluster_x;
     std::vector<uint32_t> stage_cluster_y;
 
     // depth-slice thresholds of the bound LightClusterCoefficients (build_slice_thresholds)
@@ -389,7 +389,7 @@ tr_status ensure_cluster_tables(tr_context* ctx, const tr_uniforms* u, uint32_t 
         (void)hipFree(ctx->d_cluster_x);
         ctx->d_cluster_x = nullptr;
         ctx->cl_cap_w = 0;
-        TR_HIP(ctx, hipMalloc((void**)&ctx->d_cluster_x, sizeof(uint16_t) * fw));
+        TR_HIP(ctx, hipMalloc((void**)&ctx->d_cluster_x, sizeof(uint32_t) * fw));
         ctx->cl_cap_w = fw;
     }
     if (fh > ctx->cl_cap_h) {
@@ -403,10 +403,10 @@ tr_status ensure_cluster_tables(tr_context* ctx, const tr_uniforms* u, uint32_t 
     ctx->stage_cluster_y.resize(fh);
     for (uint32_t x = 0; x < fw; ++x) {
         uint32_t c = f32_as_u32(((float)x + 0.5f) / sx);
-        ctx->stage_cluster_x[x] = (uint16_t)(c > 0xFFFFu ? 0xFFFFu : c);
+        ctx->stage_cluster_x[x] = c > 0xFFFFu ? 0xFFFFu : c;
     }
     for (uint32_t y = 0; y < fh; ++y) ctx->stage_cluster_y[y] = f32_as_u32(((float)y + 0.5f) / sy) * ncx;
-    TR_HIP(ctx, hipMemcpyAsync(ctx->d_cluster_x, ctx->stage_cluster_x.data(), sizeof(uint16_t) * fw,
+    TR_HIP(ctx, hipMemcpyAsync(ctx->d_cluster_x, ctx->stage_cluster_x.data(), sizeof(uint32_t) * fw,
                                hipMemcpyHostToDevice, stream));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_cluster_y_term, ctx->stage_cluster_y.data(), sizeof(uint32_t) * fh,
                                hipMemcpyHostToDevice, stream));
@@ -640,7 +640,9 @@ void fill_launch(tr_launch& L, const tr_context* ctx, const tr_frame_params& fp,
 // One launch of shade_kernel<TRANSMISSIVE, ., TEX, .>: RGBA16F or RGBA32F target; planes, or (RGBA16F inside the frame
 // recorder) the rasteriser's visibility words.
 template <bool TRANSMISSIVE, int TEX>
-void launch_shade(const tr_launch& L, bool half, dim3 grid, dim3 block, hipStream_t stream) {
+void launch_shade(const tr_launch& L_, bool half, dim3 grid, dim3 block, hipStream_t stream) {
+    tr_launch L = L_;
+    L.fp.j_step = L.front_list ? grid.x / kFrontLists : grid.x >> 3;
     if (half && L.vis) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, TEX, true>), grid, block, 0, stream, L);
     else if (half) hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, uint2, TEX, false>), grid, block, 0, stream, L);
     else hipLaunchKernelGGL((shade_kernel<TRANSMISSIVE, float4, TEX, false>), grid, block, 0, stream, L);
