@@ -804,7 +804,7 @@ def run_single(args) -> int:
                      "algorithmic_bytes_per_launch": pixels * ALGORITHMIC_BYTES_PER_PIXEL,
                      "frac_survey_60B": headline["frac_60B"],
                      "frac_events": ev_fig["frac_52B"], "events_ms_per_step": round(events_ms, 4),
-                     "streams": 1, "launches_per_step": lps,
+                     "streams": lps, "launches_per_step": lps,
                      "note": "frac = 52 B/px x pixels / ms_per_step (the wall clock of the K timed steps, the same number `value` "
                              "comes from) / 8 TB/s.  52 B/px = what this untextured variant moves (16 + 16 + 4 B planes, 8 B opaque "
                              "colour, 8 B write; = SURVEY 8d's read-only figure); SURVEY 8d's 60 B/px also counts the 8 B/px uv "

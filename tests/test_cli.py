@@ -52,3 +52,32 @@ def test_cli_renders_a_model_in_front_of_a_backdrop(tmp_path):
     assert a.shape == b.shape == (180, 320, 4)
     changed = (a[..., :3] != b[..., :3]).any(axis=2).mean()
     assert changed > 0.1, changed            # the backdrop fills pixels the model alone leaves to the clear colour
+
+
+@pytest.mark.gpu
+def test_cli_tonemap_constants_are_explicit_inputs(tmp_path):
+    """The operator's constants are command-line inputs (the reference's come from an un-vendored crate's Default impl):
+    the defaults reproduce the frame without flags, another contrast changes it, and the presented frame equals the
+    oracle's fragment_tonemap of the HDR frame under the same constants."""
+    import ctypes as C
+    from oracle import oracle
+    from transmission_renderer_amd import _lib, wire
+    from transmission_renderer_amd.png import read_png_rgba8
+    a, b, c = (str(tmp_path / n) for n in ("a.png", "b.png", "c.png"))
+    hdr = str(tmp_path / "c.npy")
+    base = ["synthetic", "--width", "160", "--height", "96"]
+    assert cli.main(base + ["--out", a]) == 0
+    assert cli.main(base + ["--out", b, "--tonemap-contrast", "1.6", "--tonemap-shoulder", "0.977", "--tonemap-hdr-max", "8",
+                            "--tonemap-mid-in", "0.18", "--tonemap-mid-out", "0.267", "--tonemap-crosstalk", "4"]) == 0
+    assert cli.main(base + ["--out", c, "--hdr-out", hdr, "--tonemap-contrast", "1.2", "--tonemap-hdr-max", "16"]) == 0
+    fa, fb, fc = read_png_rgba8(a), read_png_rgba8(b), read_png_rgba8(c)
+    assert (fa == fb).all()
+    assert (fa[..., :3] != fc[..., :3]).any(axis=2).mean() > 0.5
+    q, tm = wire.LottesParams(), wire.TonemapParams()
+    lib = _lib.load()
+    lib.tr_lottes_defaults(C.byref(q))
+    q.contrast, q.hdr_max = 1.2, 16.0
+    q.saturation, q.cross_saturation = q.contrast, q.contrast * 16.0
+    lib.tr_bake_lottes_params(C.byref(q), C.byref(tm))
+    want = oracle.tonemap_frame(np.ascontiguousarray(np.load(hdr), dtype=np.float16), tm)[0]
+    assert np.abs(fc[..., :3].astype(np.int32) - want[..., :3].astype(np.int32)).max() <= 1

@@ -53,7 +53,7 @@ def test_bench_line_contract_and_live_traffic():
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 40 and out["dtype"] == "f32" and out["vs_baseline"] is None
     r = out["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["algorithmic_bytes_per_pixel"] == 52 and r["streams"] == 1 and r["launches_per_step"] == 2
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["algorithmic_bytes_per_pixel"] == 52 and r["streams"] == 2 and r["launches_per_step"] == 2
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
     assert abs(out["value"] - 3840 * 2160 / out["ms_per_step"] / 1e3) / out["value"] < 0.02     # value = pixels / wall time
     assert out["single_stream"]["avg_kernel_ms"] >= 0.9 * r["avg_kernel_ms"]

@@ -415,6 +415,47 @@ def test_record_frame_equals_the_stepwise_sequence(renderer, ggx_lut):
         assert (got_hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
 
 
+def test_fused_front_end_with_many_culling_blocks_over_many_frames(renderer, ggx_lut):
+    """The frame recorder's front launch hands the culling counts to the demultiplex behind its LAST culling workgroup (a
+    ticket of relaxed agent-scope atomics, no fence: csrc/tr_shade.hip frame_front_kernel).  A scene of 20 000 small
+    instances — 79 culling workgroups spread over every XCD, half of them outside the frustum — through 40 consecutive frames
+    from two alternating cameras: every frame bit for bit the stepwise frame of its camera (whose culling, demultiplex and
+    scans are launches of their own)."""
+    r = renderer
+    w, h = 320, 180
+    rng = np.random.default_rng(7)
+    S = meshes.Similarity
+    mb = meshes.ModelBuffers()
+    mb.add_primitive(meshes.plane(30.0, 30.0, cells=4), 0, [(S(np.array([0, 0.6, -6.0], np.float32)), 3)])
+    small = meshes.box(0.5, 0.5, 0.5)
+
+    def scatter(n, material):
+        return [(S(np.array([rng.uniform(-30, 30), rng.uniform(0.7, 6), rng.uniform(-30, 12)], np.float32), rng.uniform(0.02, 0.08)),
+                 material(k)) for k in range(n)]
+    mb.add_primitive(small, 0, scatter(15_000, lambda k: k % 16))
+    mb.add_primitive(small, 2, scatter(5_000, lambda k: 4))
+    geo = mb.finish()
+    assert len(geo["instances"]) > 64 * 256
+    views = (wire.default_camera()[1], wire.look_at_rh((3.5, 2.0, -6.0), (0.0, 1.2, -3.0), (0.0, 1.0, 0.0)))
+    sc = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False)
+    r.upload_materials(sc["materials"])
+    r.upload_lights(sc["lights"])
+    r.upload_geometry(geo)
+    aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+    cams = [(v, wire.view_rotation_inverse(v), wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), v)) for v in views]
+    want = [_stepwise_frame(r, sc, c, v, q, aabbs, w, h) for v, q, c in cams]
+    assert not torch.equal(want[0], want[1])
+    work = r.new_frame_buffers(w, h)
+    for k in range(40):
+        v, q, c = cams[k & 1]
+        hdr, _ = r.record_frame(sc["uniforms"], sc["push"], c, v, q, aabbs, work)
+        if k % 5 == 4 or k < 2:   # (frames in between run back to back: nothing drains the GPU between their front launches)
+            torch.cuda.synchronize()
+            assert torch.equal(hdr.view(torch.int16), want[k & 1].view(torch.int16)), k
+    torch.cuda.synchronize()
+    assert torch.equal(hdr.view(torch.int16), want[1].view(torch.int16))
+
+
 def _stepwise_frame(r, sc, culling, view, q, aabbs, w, h, dtype=torch.float16):
     from transmission_renderer_amd.renderer import OpaquePyramid
     r.assign_lights_to_clusters(view, q, aabbs)

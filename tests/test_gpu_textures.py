@@ -159,9 +159,10 @@ def _usual_gltf_set(scene):
 
 
 @pytest.mark.parametrize("w,h,nl,coverage,uv_scale", [(256, 192, 2, "full", 1.0), (250, 130, 3, "holes", 3.0)])
-def test_usual_gltf_texture_set_build_parity(renderer, ggx_lut, monkeypatch, w, h, nl, coverage, uv_scale):
-    """Both passes through the TEX = 3 build against the oracles, and against the general full-class build (TR_NO_MID_CLASS
-    makes the host launch that one): the same per-pixel arithmetic on the same values, so the frames agree to rounding."""
+def test_usual_gltf_texture_set_build_parity(renderer, ggx_lut, w, h, nl, coverage, uv_scale):
+    """Both passes through the TEX = 3 build against the oracles, and against the general full-class build (one more
+    material, referenced by no pixel, that binds an emissive texture makes the host launch that one): the same per-pixel
+    arithmetic on the same values, so the frames agree to rounding."""
     from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
     r = renderer
     scene = _usual_gltf_set(_textured_scene(w, h, nl, coverage, uv_scale))
@@ -187,9 +188,12 @@ def test_usual_gltf_texture_set_build_parity(renderer, ggx_lut, monkeypatch, w, 
         return t32.cpu().numpy(), t16.cpu().numpy(), o32.cpu().numpy()
 
     got32, got16, gop = run()
-    monkeypatch.setenv("TR_NO_MID_CLASS", "1")
+    beyond = wire.MaterialInfo.default()
+    beyond.textures = wire.Textures(*([-1] * 9))
+    beyond.textures.diffuse, beyond.textures.emissive = 0, 3
+    r.upload_materials(list(scene["materials"]) + [beyond])
     full32, full16, fop = run()
-    monkeypatch.delenv("TR_NO_MID_CLASS")
+    r.upload_materials(scene["materials"])
     ok = ~_degenerate(scene["materials"], scene["gbuffer"]["material_id"])
     assert ok.mean() >= 0.99
     for a, c in ((got32, full32), (gop, fop)):

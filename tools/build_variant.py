@@ -12,5 +12,5 @@ import __graft_entry__ as g  # noqa: E402
 name, extra = sys.argv[1], sys.argv[2:]
 os.makedirs(os.path.join(ROOT, "build_ab"), exist_ok=True)
 out = os.path.join(ROOT, "build_ab", f"libtr_{name}.so")
-g.compile_library(out, extra, force=True)
+g.compile_library(out, ["-DTR_TUNING_ENV=1"] + extra, force=True)   # (variants read the tuning environment; the product does not)
 print(out)

@@ -25,6 +25,22 @@ import time
 import numpy as np
 
 
+def lottes_from_args(r, args):
+    """tr_lottes_defaults with the --tonemap-* flags laid over it (saturation / cross-saturation follow the contrast unless
+    given, as in the operator's own parameterisation)."""
+    import ctypes as C
+    from . import wire
+    q = wire.LottesParams()
+    r._check(r.lib.tr_lottes_defaults(C.byref(q)), "tr_lottes_defaults")
+    for field in ("contrast", "shoulder", "hdr_max", "mid_in", "mid_out", "crosstalk"):
+        v = getattr(args, "tonemap_" + field)
+        if v is not None:
+            setattr(q, field, float(v))
+    q.saturation = float(args.tonemap_saturation) if args.tonemap_saturation is not None else q.contrast
+    q.cross_saturation = float(args.tonemap_cross_saturation) if args.tonemap_cross_saturation is not None else q.contrast * 16.0
+    return q
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="transmission_renderer_amd.cli", description=__doc__.split("\n\n")[0])
     ap.add_argument("gltf_sample_model_name", help="a .gltf / .glb path, 'meshes' or 'synthetic'")
@@ -40,6 +56,18 @@ def main(argv=None) -> int:
     ap.add_argument("--timings", action="store_true",
                     help="render a second, timed frame and print the GPU time of every pass under the reference's "
                          "profiling zone names (src/main.rs:1643-2227)")
+    # The reference bakes colstodian's LottesTonemapperParams::default() (src/main.rs:506-510); that crate is not vendored, so
+    # its constants cannot be read off the reference: they are explicit inputs here.  The defaults are the values of the
+    # operator's GDC 2016 presentation (tr_lottes_defaults) — ASSUMED, not pinned.
+    tm = ap.add_argument_group("tonemap operator (Lottes; defaults assumed, see --help epilog)")
+    tm.add_argument("--tonemap-contrast", type=float, default=None, help="default 1.6")
+    tm.add_argument("--tonemap-shoulder", type=float, default=None, help="default 0.977")
+    tm.add_argument("--tonemap-hdr-max", type=float, default=None, help="default 8.0")
+    tm.add_argument("--tonemap-mid-in", type=float, default=None, help="default 0.18")
+    tm.add_argument("--tonemap-mid-out", type=float, default=None, help="default 0.267")
+    tm.add_argument("--tonemap-crosstalk", type=float, default=None, help="default 4.0")
+    tm.add_argument("--tonemap-saturation", type=float, default=None, help="default: the contrast")
+    tm.add_argument("--tonemap-cross-saturation", type=float, default=None, help="default: 16 x the contrast")
     ap.add_argument("--out", default="frame.png", help="tonemapped 8-bit sRGB PNG")
     ap.add_argument("--hdr-out", default=None, help="also save the RGBA16F HDR frame as .npy")
     ap.add_argument("--device", type=int, default=0)
@@ -96,6 +124,7 @@ def main(argv=None) -> int:
     if geometry is not None:
         r.upload_geometry(geometry)
     _, view = wire.default_camera()
+    lottes = lottes_from_args(r, args)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     aabbs = r.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
@@ -107,12 +136,13 @@ def main(argv=None) -> int:
         pyr = OpaquePyramid(w, h, r.device)
         hdr = torch.zeros((h, w, 4), dtype=torch.float16, device=r.device)
         r.record(opaque, transmissive, scene["uniforms"], scene["push"], hdr, pyr)
-        ldr = r.tonemap(hdr)
+        ldr = r.tonemap(hdr, r.baked_tonemap_params(lottes))
     else:
         # one native call per frame: culling, light assignment, demultiplex, rasteriser, opaque, mips, transmissive, tonemap
         culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
         work = r.new_frame_buffers(w, h)
-        hdr, ldr = r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs, work)
+        hdr, ldr = r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs, work,
+                                  lottes=lottes)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if args.timings and geometry is not None:

@@ -56,11 +56,7 @@ __device__ __forceinline__ T ld(const void* base, uint32_t byte_offset) {
 // the same kernel keeps re-reading from L2.
 template <class T>
 __device__ __forceinline__ T ld_stream(const void* base, uint32_t byte_offset) {
-#ifdef TR_AB_PLAIN_LOADS   // experiments only
-    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset);
-#else
     return __builtin_nontemporal_load(reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset));
-#endif
 }
 template <class T>
 __device__ __forceinline__ void st(void* base, uint32_t byte_offset, T value) {

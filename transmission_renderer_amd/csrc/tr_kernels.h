@@ -78,10 +78,7 @@ __device__ __forceinline__ void tile_phase() {
 }
 constexpr uint32_t kFrontLists = 64u;      // sub-lists of the transmissive-covered tile list (tr_launch::front_list)
 constexpr uint32_t kStripeTileRows = 4u;   // VIS / textured launches: tile rows per XCD stripe (1 ... 8 measure the same)
-#ifndef TR_PARKED_VALUES
-#define TR_PARKED_VALUES 17u   // (A/B builds of tools/ raise it to measure what the LDS footprint costs in resident waves)
-#endif
-constexpr uint32_t kParkedValues = TR_PARKED_VALUES;    // full-class textured pixels: values parked in LDS, see shade_pixel_textured
+constexpr uint32_t kParkedValues = 17u;    // full-class textured pixels: values parked in LDS, see shade_pixel_textured
 
 // ---------------------------------------------------------------- digested material (240 B)
 // Index 0 of every pair belongs to the basic_brdf lobe, index 1 to the transmission_btdf lobe.
@@ -1481,12 +1478,10 @@ __device__ __forceinline__ uint32_t tonemap_pixel(uint32_t lo, uint32_t hi, cons
 // forms the quad differences with two lane swizzles (the 16x4 wave tile holds whole 2x2 quads: partner lanes are
 // lane^1 and lane^16; the host guarantees an even rect origin) before the wave splits by material, and sends
 // materials flagged as textured through shade_pixel_textured.  The sRGB decode table sits in LDS.
-#ifndef TR_PLANES_NT_MASK
-#define TR_PLANES_NT_MASK (TEXTURED ? TR_PLANES_NT_MASK_TEXTURED : TRANSMISSIVE ? 3u : 5u)   // (see fetch)
-#endif
-#ifndef TR_PLANES_NT_MASK_TEXTURED
-#define TR_PLANES_NT_MASK_TEXTURED 10u   // (textured plane launches: normal + uv planes non-temporal; all four: +3 %)
-#endif
+// Which planes a plane launch loads non-temporally (bit 0 the position plane, 1 the normal plane, 2 the ids, 3 the uv plane; see
+// fetch): textured launches the normal + uv planes (all four: +3 %), the transmissive pass both float4 planes, the opaque pass
+// position + ids.
+constexpr uint32_t planes_nt_mask(bool textured, bool transmissive) { return textured ? 10u : transmissive ? 3u : 5u; }
 template <class T, bool NT>
 __device__ __forceinline__ T ld_plane(const void* base, uint32_t byte_offset) {
     if constexpr (NT) return ld_stream<T>(base, byte_offset);
@@ -1510,9 +1505,7 @@ struct tile_regs {
 // CU, and the hint keeps the allocator from spending registers it has no use for.  Every other variant is left to
 // itself: forced up, the textured classes spill, and scratch costs more than the waves give (DESIGN.md 3.1;
 // tests/test_kernel_resources.py holds the line).
-#ifndef TR_WAVES_ATTR
 #define TR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((TEX == kTexNone && TRANSMISSIVE && VIS) ? 8 : (TEX >= kTexFull && TRANSMISSIVE) ? 6 : 1)))
-#endif
 // TEX: which material classes the uploaded materials hold (the host knows: tr_upload_materials) — ONE launch shades them all:
 //   0  no material has a texture slot: every material through the scalar record;
 //   1  untextured materials and the LITE class (lite_dmat: only a base-colour texture, dielectric);
@@ -1535,7 +1528,7 @@ constexpr uint32_t kSlotsAll = 0xFFu, kSlotsMid = 0x07u;   // bit k: slot k of s
 template <bool TRANSMISSIVE, typename OutT /* uint2 = RGBA16F, float4 = RGBA32F */, int TEX = kTexNone, bool VIS = false>
 __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch launch_by_value) {
     constexpr bool TEXTURED = TEX != kTexNone;
-    constexpr uint32_t kPlanesNt = TR_PLANES_NT_MASK;   // which planes are loaded non-temporally (see fetch)
+    constexpr uint32_t kPlanesNt = planes_nt_mask(TEXTURED, TRANSMISSIVE);
     (void)launch_by_value;  // read through the kernarg segment pointer, see tr_launch
     claunch* L = launder((claunch*)__builtin_amdgcn_kernarg_segment_ptr());
     __shared__ float lds_srgb[TEXTURED ? 256 : 1];
@@ -1602,8 +1595,7 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         // Measured with COLD inputs (bench.py: every step a different input set; 4K frame as two bands): both float4 planes
         // non-temporal 83.5 us, all three planes 83.6, position only 87.0 (rounds 2-3's choice, tuned on ONE re-read input
         // set, where a plane kept in the Infinity Cache is worth more than a clean L2: 78 vs 82 us), normal + ids 88.2,
-        // none 90.4.  The opaque pass keeps position + ids (its stores are re-read).  TR_PLANES_NT_MASK (bit 0 the position
-        // plane, 1 the normal plane, 2 the ids, 3 the uv plane) is for the A/B builds of tools/.
+        // none 90.4.  The opaque pass keeps position + ids (its stores are re-read): planes_nt_mask.
         typedef float f4v __attribute__((ext_vector_type(4)));
         typedef float f2v __attribute__((ext_vector_type(2)));
         if constexpr (VIS) {

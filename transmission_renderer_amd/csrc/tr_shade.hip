@@ -209,11 +209,10 @@ struct tr_context {
     uint64_t tables_generation = 0;
     struct stream_seen { hipStream_t stream; uint64_t generation; };
     std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
-    bool no_mid_class = false;                  // TR_NO_MID_CLASS (tests only), read once at context creation
-    uint32_t vis_grid_rounds = 4;               // see persistent_grid (TR_VIS_ROUNDS: tuning only)
-    uint32_t front_list_waves_per_cu = 48;      // the transmissive VIS launch's grid when it walks the list of covered tiles (TR_FRONT_LIST_WAVES: tuning only; 0: no list)
+    uint32_t vis_grid_rounds = 4;               // see persistent_grid (TR_VIS_ROUNDS in tools/ builds)
+    uint32_t front_list_waves_per_cu = 48;      // the transmissive VIS launch's grid when it walks the list of covered tiles (TR_FRONT_LIST_WAVES in tools/ builds; 0: no list)
     uint32_t raster_wgs_per_cu = 6;             // raster_kernel's persistent grid: 4 -> 191 / 199 us (4K mesh / glTF demo frame), 6 -> 191 / 192,
-                                                // 8 -> 194 / 195, 12 -> 191 / 196, 16 -> 198 / 199 (TR_RASTER_WGS_PER_CU: tuning only)
+                                                // 8 -> 194 / 195, 12 -> 191 / 196, 16 -> 198 / 199 (TR_RASTER_WGS_PER_CU in tools/ builds)
 };
 
 namespace {
@@ -654,7 +653,7 @@ void launch_textured(tr_context* ctx, const tr_launch& L, bool half, dim3 grid, 
     // build when none binds a slot beyond base colour, metallic-roughness and normal map (the transmission / thickness
     // slots do not exist for the opaque pass)
     if (!ctx->any_full_textured) return launch_shade<TRANSMISSIVE, kTexLite>(L, half, grid, block, stream);
-    const bool mid = (ctx->full_slots & ~(TRANSMISSIVE ? kSlotsMid : (kSlotsMid | 0x30u))) == 0u && !ctx->no_mid_class;
+    const bool mid = (ctx->full_slots & ~(TRANSMISSIVE ? kSlotsMid : (kSlotsMid | 0x30u))) == 0u;
     if (mid) launch_shade<TRANSMISSIVE, kTexAllMid>(L, half, grid, block, stream);
     else launch_shade<TRANSMISSIVE, kTexAll>(L, half, grid, block, stream);
 }
@@ -716,11 +715,12 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
             ctx->blocks_per_xcd = (uint32_t)(prop.multiProcessorCount / 8) * (uint32_t)resident * kGridRounds;
             ctx->num_cus = (uint32_t)prop.multiProcessorCount;
         }
-        if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);  // tuning only
-        ctx->no_mid_class = std::getenv("TR_NO_MID_CLASS") != nullptr;   // tests only: the full-class launch's general build
-        if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));  // tuning only
-        if (const char* e = std::getenv("TR_FRONT_LIST_WAVES")) ctx->front_list_waves_per_cu = (uint32_t)std::max(0, std::atoi(e));  // tuning only
-        if (const char* e = std::getenv("TR_RASTER_WGS_PER_CU")) ctx->raster_wgs_per_cu = (uint32_t)std::max(1, std::atoi(e));  // tuning only
+#ifdef TR_TUNING_ENV   // tools/build_variant.py builds only (build_ab/): the product reads nothing from its caller's environment
+        if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);
+        if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("TR_FRONT_LIST_WAVES")) ctx->front_list_waves_per_cu = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("TR_RASTER_WGS_PER_CU")) ctx->raster_wgs_per_cu = (uint32_t)std::max(1, std::atoi(e));
+#endif
     }
     if (hipMalloc((void**)&ctx->d_front_ticket, 4u) != hipSuccess || hipMemset(ctx->d_front_ticket, 0, 4u) != hipSuccess ||
         hipMalloc((void**)&ctx->d_levels, sizeof(tr_level_table)) != hipSuccess ||
@@ -1589,7 +1589,9 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
         L.front_list = ctx->d_front_list;
         L.front_list_count = ctx->d_front_list_count;
         L.front_list_cap = ctx->front_list_cap;
-        grid = dim3(ctx->num_cus * ctx->front_list_waves_per_cu);
+        // (a multiple of the sub-list count, at least one wave per sub-list: workgroup b walks list b % kFrontLists with stride
+        //  grid / kFrontLists — a remainder would re-walk slot 0's tiles, fewer than kFrontLists waves would never advance)
+        grid = dim3(std::max(kFrontLists, (ctx->num_cus * ctx->front_list_waves_per_cu + kFrontLists - 1u) / kFrontLists * kFrontLists));
     }
     {
         L.pyramid = (const uint2*)p->texels;
@@ -2084,9 +2086,11 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     tr_status st;
     void* draws[TR_NUM_DRAW_BUFFERS] = {ctx->d_draws[0], ctx->d_draws[1], ctx->d_draws[2], ctx->d_draws[3]};
     if (!rec) {
-        // The untimed frame fuses its launch-latency-bound front end: [culling | light assignment] in one launch,
-        // [demultiplex + both layers' draw scans] in the next (inside rasterize_impl); the instance counts are zeroed
-        // by their last reader instead of a fill.  (The timed frame launches every pass on its own, below.)
+        // The untimed frame fuses its launch-latency-bound front end into ONE launch (frame_front_kernel): culling, light
+        // assignment and the coverage clear side by side, and behind the LAST culling workgroup (a ticket counted with
+        // agent-scope atomics; what it reads are the atomics' own words) the demultiplex and both layers' draw scans; the
+        // instance counts are zeroed by their last reader instead of a fill.  tests/test_gpu_culling.py holds the hand-over
+        // against the unfused passes over many frames.  (The timed frame launches every pass on its own, below.)
         hipStream_t s_ = (hipStream_t)stream;
         TR_HIP(ctx, hipSetDevice(ctx->device));
         if (!ctx->counts_clean) TR_HIP(ctx, hipMemsetAsync(ctx->d_instance_counts, 0, sizeof(uint32_t) * ctx->num_primitives, s_));

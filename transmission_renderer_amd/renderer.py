@@ -400,14 +400,14 @@ class TransmissionRenderer:
 
     def record_frame(self, uniforms: wire.Uniforms, push: wire.PushConstants, culling: wire.CullingPushConstants,
                      view_matrix: np.ndarray, view_rotation: np.ndarray, aabbs: torch.Tensor, work: dict, tonemap=True,
-                     timed: bool = False):
+                     timed: bool = False, lottes: Optional[wire.LottesParams] = None):
         """One frame of the uploaded scene through tr_record_frame (the native recorder: culling, light assignment,
         demultiplex, rasteriser, opaque, mips, transmissive, tonemap).  `work` = new_frame_buffers(); returns
         (hdr, ldr or None) — and, with timed=True (tr_record_frame_timed, blocks), a dict {zone name: ms} under the
         reference's profiling zone names (src/main.rs:1643-2227)."""
         vm = (C.c_float * 16)(*[float(x) for x in np.asarray(view_matrix, dtype=np.float32).reshape(-1)])
         q = (C.c_float * 4)(*[float(x) for x in np.asarray(view_rotation, dtype=np.float32).reshape(-1)])
-        params = self.baked_tonemap_params() if tonemap else None
+        params = self.baked_tonemap_params(lottes) if tonemap else None   # (lottes: the operator's eight constants; None = tr_lottes_defaults)
         self._keep["clusters"] = (work["counts"], work["indices"])
         d = wire.FrameDesc()
         d.push, d.uniforms, d.culling = C.pointer(push), C.pointer(uniforms), C.pointer(culling)

@@ -197,7 +197,12 @@ def allgather_strips(comp: "Compositor", frame: torch.Tensor, strip_rows: int) -
     assert frame.is_contiguous()
     h, w = int(frame.shape[0]), int(frame.shape[1])
     if comp._comm.value:
-        fmt = {torch.float16: wire.FORMAT_RGBA16F, torch.float32: wire.FORMAT_RGBA32F, torch.uint8: wire.FORMAT_RGBA8}[frame.dtype]
+        channels = int(frame.shape[2])
+        if frame.dtype == torch.uint8 and channels == 3:
+            fmt = wire.FORMAT_RGB8          # (tonemap_rgb8's frames: three bytes per pixel, as allgather_rows)
+        else:
+            assert channels == 4, "a strip composite takes (H, W, 4) frames, or (H, W, 3) uint8 ones"
+            fmt = {torch.float16: wire.FORMAT_RGBA16F, torch.float32: wire.FORMAT_RGBA32F, torch.uint8: wire.FORMAT_RGBA8}[frame.dtype]
         st = comp.renderer.lib.tr_allgather_strips(comp.renderer._ctx, comp._comm, frame.data_ptr(), w, h, int(strip_rows), fmt,
                                                    torch.cuda.current_stream().cuda_stream)
         if st != 0:
