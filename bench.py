@@ -97,6 +97,8 @@ def parse_args(argv=None):
     ap.add_argument("--sets", type=int, default=0,
                     help="N = 1: distinct input sets (planes + pyramid + target) the timed steps rotate through; 0 = default: "
                          "as many as make more than 1.2 GB, at least 3")
+    ap.add_argument("--frame-probe", action="store_true",
+                    help="internal (the child runs under rocprofv3): 120 tr_record_frame calls of the 4K `meshes` scene, nothing else")
     ap.add_argument("--pmc-probe", action="store_true",
                     help="internal (the child runs under rocprofv3 --pmc): six whole-frame launches each of the headline "
                          "scene, the all-transmissive scene and config 3, nothing else")
@@ -382,6 +384,127 @@ def pmc_probe(args) -> int:
         torch.cuda.synchronize()
         wl.close()
     return 0
+
+
+FRAME_PROBE_FRAMES = 120
+
+
+def frame_probe(args) -> int:
+    """The child of measure_frame_kernels: the frame recorder's loop of frame_pipeline_time, one context, nothing else."""
+    import torch
+    from transmission_renderer_amd import meshes, synthetic, wire
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    w, h = args.width, args.height
+    r = TransmissionRenderer(0)
+    scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False, textured=True)
+    geometry = meshes.make_mesh_scene(extra_instances=True)
+    scene["materials"][2].alpha_clipping_cutoff = 0.75
+    scene["materials"][7].alpha_clipping_cutoff = 0.6
+    r.upload_ggx_lut()
+    r.upload_materials(scene["materials"])
+    r.upload_textures(scene["textures"])
+    r.upload_lights(scene["lights"])
+    r.upload_geometry(geometry)
+    _, view = wire.default_camera()
+    aabbs = r.write_cluster_data(scene["uniforms"], wire.inverse_perspective(w, h), (w, h))
+    culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+    work = r.new_frame_buffers(w, h)
+    q = wire.view_rotation_inverse(view)
+    for _ in range(FRAME_PROBE_FRAMES):
+        r.record_frame(scene["uniforms"], scene["push"], culling, view, q, aabbs, work)
+    torch.cuda.synchronize()
+    r.close()
+    return 0
+
+
+FRAME_KERNELS = (   # (name in the bench line, substring of the kernel's name in the trace)
+    ("front (culling | light assignment | clear, demultiplex + draw scans behind it)", "frame_front_kernel"),
+    ("set-up (vertex stage, edge functions, planes, item prefix)", "raster_setup_kernel"),
+    ("rasteriser (both layers)", "raster_kernel"),
+    ("opaque launch (visibility words; writes target, levels 0 and 1, presents)", "shade_kernel<false"),
+    ("mip chain: even levels", "mip_even_kernel"),
+    ("mip chain: first odd level", "downsample_kernel"),
+    ("mip chain: tail", "mip_tail_kernel"),
+    ("transmissive launch (visibility words, listed tiles; presents)", "shade_kernel<true"),
+)
+
+
+def measure_frame_kernels(width, height):
+    """frame_pipeline.kernels: the frame recorder's launches one by one, measured NOW by child runs of this script
+    (`--frame-probe`) under rocprofv3 — one kernel-trace pass (µs per launch, launches per frame) and three --pmc passes
+    (FETCH_SIZE; WRITE_SIZE; SQ counters), kernel trace only, as MI355X_MICROARCH.md prescribes.  Per kernel: us (mean
+    over the frames behind the first 20), launches_per_frame, hbm_bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, median
+    per launch), frac = hbm_bytes / us / 8 TB/s, issue_port_busy and waves_per_simd (see roofline.valu).  None when rocprofv3
+    is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None
+    tmp = tempfile.mkdtemp(prefix="tr_frame_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--frame-probe", "--width", str(width), "--height", str(height)]
+    env = dict(os.environ, TMPDIR="/tmp")
+
+    def rows_of(tag, extra):
+        d = os.path.join(tmp, tag)
+        r = subprocess.run([rocprof, "--kernel-trace"] + extra + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            raise RuntimeError(f"rocprofv3 {tag}: {r.stderr[-300:]}")
+        return d
+
+    try:
+        d = rows_of("trace", [])
+        per = {name: [] for name, _ in FRAME_KERNELS}
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                for name, sub in FRAME_KERNELS:
+                    if sub in row["Kernel_Name"]:
+                        per[name].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+                        break
+        out = {}
+        for name, _ in FRAME_KERNELS:
+            v = sorted(per[name])
+            if not v:
+                continue
+            lpf = max(1, round(len(v) / FRAME_PROBE_FRAMES))
+            steady = [dur for _, dur in v[20 * lpf:]] or [dur for _, dur in v]
+            out[name] = {"us": round(sum(steady) / len(steady) / 1e3 * lpf, 2), "launches_per_frame": lpf}
+        counters = {}
+        for tag, cs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+                        ("sq", ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "SQ_INSTS_VALU"])):
+            d = rows_of(tag, ["--pmc"] + cs)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    for name, sub in FRAME_KERNELS:
+                        if sub in row["Kernel_Name"]:
+                            counters.setdefault((name, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+                            break
+        med = lambda name, c: (sorted(counters[(name, c)])[len(counters[(name, c)]) // 2] if (name, c) in counters else None)
+        for name in out:
+            k = out[name]
+            fs, ws = med(name, "FETCH_SIZE"), med(name, "WRITE_SIZE")
+            if fs is not None and ws is not None:
+                k["hbm_bytes"] = int(round((2.0 * fs + ws) * 1024.0)) * k["launches_per_frame"]
+                k["frac"] = round(k["hbm_bytes"] / (k["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            busy, act, act2, wc = (med(name, c) for c in ("SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "SQ_WAVE_CYCLES"))
+            if busy:
+                per_se = busy / 32.0
+                k["issue_port_busy"] = round((act - act2) * 4.0 / 1024.0 / per_se, 3)
+                k["waves_per_simd"] = round(wc * 4.0 / 1024.0 / per_se, 2)
+                k["vector_instructions"] = int(med(name, "SQ_INSTS_VALU"))
+        out["note"] = ("rocprofv3 child passes of `bench.py --frame-probe` (120 frames of the `meshes` scene, one context): us = mean "
+                       "kernel time per frame behind the first 20 frames (kernel trace); hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE per "
+                       "frame (separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md — calibrated on wide streaming "
+                       "reads, an upper bound for the gather-heavy kernels); frac = hbm_bytes / us / 8 TB/s; issue_port_busy = "
+                       "(SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) x 4 / 1024 SIMDs / (SQ_BUSY_CYCLES / 32)")
+        return out
+    except Exception as e:   # noqa: BLE001  (reported, never fatal for the bench line)
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 class PassWorkload:
@@ -774,6 +897,9 @@ def run_single(args) -> int:
             frame_pipeline = frame_pipeline_time(fw, fh)
             frame_pipeline["at_1080p"] = {k: v for k, v in frame_pipeline_time(1920, 1080).items() if k in ("us_per_frame", "two_frames_in_flight")}
             frame_pipeline["at_8k"] = {k: v for k, v in frame_pipeline_time(7680, 4320).items() if k in ("us_per_frame", "two_frames_in_flight")}
+            if not args.no_traffic:
+                torch.cuda.synchronize()
+                frame_pipeline["kernels"] = measure_frame_kernels(fw, fh)   # child processes; the GPU is idle here
         except Exception as e:
             frame_pipeline = dict(frame_pipeline or {}, error=f"{type(e).__name__}: {e}")
 
@@ -874,6 +1000,8 @@ def run_rank(args) -> int:
         return selftest_cpu(args, world, rank)
     if args.pmc_probe:
         return pmc_probe(args)
+    if args.frame_probe:
+        return frame_probe(args)
     if world == 1 and not args.rehearse_distributed and args.streams <= 1:
         return run_single(args)
     import numpy as np
