@@ -1,10 +1,11 @@
 """The HIP passes against the reference's OWN compiled shaders (run with -m gpu on an MI355X).
 
-tests/golden/spirv_case_{a,b,c,d,e}.npz hold the outputs of compiled-shaders/normal/fragment_transmission.spv and
+tests/golden/spirv_case_{a,b,c,d,e,f}.npz hold the outputs of compiled-shaders/normal/fragment_transmission.spv and
 fragment.spv executed instruction by instruction on seeded inputs (tools/make_golden_spirv.py): a = 2 punctual lights,
 b = 4 lights + spotlights + ragged cluster lists + roughness override 0.25, c = every material-texture slot, sRGB /
 UNORM, normal mapping through OpDPdx / OpDPdy, holes; d, e = 2 000 sampled pixels each of the BENCHMARK'S OWN 3840x2160
-frames (d: the headline scene, sun + 1 light; e: BASELINE config 3, sun + 4 lights, roughness override 0.25).  The fixed
+frames (d: the headline scene, sun + 1 light; e: BASELINE config 3, sun + 4 lights, roughness override 0.25); f = 1 200
+sampled pixels (each with its 2x2 quad) of a 3840x2160 frame of textured materials.  The fixed
 function the shaders delegate to Vulkan was answered by a numpy statement of the Vulkan specification
 (oracle/spirv_ref/vk_sampling.py): no output of the C oracle is in a fixture.  Here the same inputs go through
 libtr_shade.so — for d / e the whole 4K frame is shaded — and every pixel the fixture holds is compared with the SPIR-V
@@ -95,25 +96,27 @@ def test_hip_passes_match_the_compiled_shaders(renderer, path):
 @pytest.mark.parametrize("path", GOLDEN_SAMPLED, ids=[os.path.basename(p) for p in GOLDEN_SAMPLED])
 def test_hip_passes_match_the_compiled_shaders_at_4k(renderer, path):
     """Cases d / e: the full-size launches of the benchmark's own frames against the reference binary on the sampled pixels
-    (framebuffer-size-dependent terms: lod = log2(3840) * r over the 12-level pyramid, 240x135-pixel clusters)."""
+    (framebuffer-size-dependent terms: lod = log2(3840) * r over the 12-level pyramid, 240x135-pixel clusters).  Case f: the
+    same for a 4K frame of TEXTURED materials — the launch that carries every material class (implicit LOD from the quads,
+    normal mapping, per-lane roughness -> per-lane pyramid lod)."""
     import hashlib
     from transmission_renderer_amd import synthetic
     from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
-    assert len(GOLDEN_SAMPLED) == 2, "fixtures missing"
+    assert len(GOLDEN_SAMPLED) == 3, "fixtures missing"
     r = renderer
     z = np.load(path)
     scene, w, h = sampled_scene(z)
     assert (w, h) == (3840, 2160)
     g = synthetic.make_gbuffer(w, h)
     ys, xs = z["pixels"][:, 0], z["pixels"][:, 1]
-    assert len(ys) == 2000
+    assert len(ys) == (1200 if "textures" in scene else 2000)
     for k in ("pos_depth", "nrm_scale", "uv", "material_id"):   # the frame shaded here IS the frame the fixture sampled
         assert g[k][ys, xs].tobytes() == z[k].tobytes(), k
     mip0 = synthetic.make_opaque_mip0(w, h)
     assert hashlib.sha256(mip0.tobytes()).digest() == z["opaque_mip0_sha256"].tobytes()
     r.upload_materials(scene["materials"])
     r.upload_lights(scene["lights"])
-    r.upload_textures([])
+    r.upload_textures(scene.get("textures", []))
     r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(r.device),
                          torch.from_numpy(scene["light_indices"].view(np.int32)).to(r.device))
     planes = GBufferPlanes.from_numpy(g, r.device)
@@ -132,8 +135,13 @@ def test_hip_passes_match_the_compiled_shaders_at_4k(renderer, path):
             assert np.isfinite(want).all()
             got = got_t[iy, ix].cpu().numpy()
             if dt == torch.float16:
-                want16 = want.astype(np.float16)
-                assert np.isfinite(want16.astype(np.float32)).all()
+                with np.errstate(over="ignore"):
+                    want16 = want.astype(np.float16)
+                # (a highlight beyond the half range — one pixel of case f, 4.1e5 — is +inf in an RGBA16F attachment, the
+                #  reference's and this one's alike; it is held to that and left out of the averages)
+                over = ~np.isfinite(want16.astype(np.float32)).all(axis=1)
+                assert over.sum() <= 2 and (np.isinf(got.astype(np.float32)) == np.isinf(want16.astype(np.float32)))[over].all(), key
+                got, want16, want = got[~over], want16[~over], want[~over]
                 p0 = np.sqrt(((_display(got[None]) - _display(want16[None])) ** 2).mean(axis=(0, 1)))
                 assert p0.max() <= 1e-4, (key, "display-referred", p0)
                 got, want = got.astype(np.float32), want16.astype(np.float32)
@@ -145,3 +153,4 @@ def test_hip_passes_match_the_compiled_shaders_at_4k(renderer, path):
                   f"|ref| max {np.abs(want).max():.3g}")
             assert norm.max() <= 1e-4, (key, str(dt), norm)
         del t, o
+    r.upload_textures([])

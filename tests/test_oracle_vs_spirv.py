@@ -21,7 +21,8 @@ from transmission_renderer_amd import wire
 
 _ALL = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spirv_case_*.npz")))
 GOLDEN = [p for p in _ALL if os.path.basename(p)[11] in "abc"]           # whole small frames
-GOLDEN_SAMPLED = [p for p in _ALL if os.path.basename(p)[11] in "de"]    # sampled pixels of the 4K benchmark frames
+GOLDEN_SAMPLED = [p for p in _ALL if os.path.basename(p)[11] in "def"]   # sampled pixels of 4K frames (d, e: the benchmark's;
+                                                                          # f: textured materials, each pixel with its quad)
 
 
 def _scene_from_fixture(z):
@@ -74,8 +75,13 @@ def sampled_scene(z):
     from transmission_renderer_amd import synthetic
     w, h = int(z["width"]), int(z["height"])
     ro = float(z["roughness_override"])
+    textured = "textured" in z.files and int(z["textured"]) != 0
     scene = synthetic.make_scene(w, h, num_point_lights=int(z["num_point_lights"]), roughness_override=None if ro < 0 else ro,
-                                 with_gbuffer=False)
+                                 with_gbuffer=False, textured=textured)
+    if textured:   # (the GGX LUT is the texture behind the material textures in the bindless array, as in case c)
+        scene["uniforms"].ggx_lut_texture_index = len(scene["textures"])
+        for i, (img, srgb) in enumerate(scene["textures"]):
+            assert img.tobytes() == z[f"texture_{i}"].tobytes() and bool(srgb) == bool(z["texture_srgb"][i])
     assert b"".join(bytes(m) for m in scene["materials"]) == z["materials"].tobytes()
     assert b"".join(bytes(l) for l in scene["lights"]) == z["lights"].tobytes()
     assert bytes(scene["uniforms"]) == z["uniforms"].tobytes() and bytes(scene["push"]) == z["push"].tobytes()
@@ -85,11 +91,12 @@ def sampled_scene(z):
 
 @pytest.mark.parametrize("path", GOLDEN_SAMPLED, ids=[os.path.basename(p) for p in GOLDEN_SAMPLED])
 def test_oracle_matches_reference_spirv_on_4k_samples(path, ggx_lut):
-    """Cases d / e: the oracle on the sampled pixels of the 3840x2160 benchmark frames (one 1x1 G-buffer tile per pixel,
-    placed at the pixel's frame position; the 12-level pyramid built by the oracle) == the reference binary, bit for bit."""
+    """Cases d / e / f: the oracle on the sampled pixels of the 3840x2160 frames (one G-buffer tile per pixel, placed at the
+    pixel's frame position — 1x1, or for the textured case f the pixel's 2x2 quad, whose differences are its derivatives;
+    the 12-level pyramid built by the oracle) == the reference binary, bit for bit."""
     import hashlib
     from transmission_renderer_amd import synthetic
-    assert len(GOLDEN_SAMPLED) == 2, "fixtures missing"
+    assert len(GOLDEN_SAMPLED) == 3, "fixtures missing"
     z = np.load(path)
     scene, w, h = sampled_scene(z)
     b = oracle.SceneBinding(scene, ggx_lut)
@@ -98,7 +105,8 @@ def test_oracle_matches_reference_spirv_on_4k_samples(path, ggx_lut):
     tex = oracle.new_pyramid(w, h, mip0)
     oracle.generate_mips(w, h, tex)
     n = len(z["pixels"])
-    assert n == 2000
+    quads = "quad_uv" in z.files
+    assert n == (1200 if quads else 2000)
     L = oracle.load()
     p = oracle.pyramid_struct(w, h, tex)
     # (the passes address whole-frame targets: one scratch frame, one texel of it written per call)
@@ -106,11 +114,17 @@ def test_oracle_matches_reference_spirv_on_4k_samples(path, ggx_lut):
     got_t, got_o = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
     for i, (y, x) in enumerate(z["pixels"]):
         y, x = int(y), int(x)
-        g = {"pos_depth": np.ascontiguousarray(z["pos_depth"][i].reshape(1, 1, 4)),
-             "nrm_scale": np.ascontiguousarray(z["nrm_scale"][i].reshape(1, 1, 4)),
-             "uv": np.ascontiguousarray(z["uv"][i].reshape(1, 1, 2)),
-             "material_id": np.ascontiguousarray(z["material_id"][i].reshape(1, 1)),
-             "width": 1, "height": 1, "origin_x": x, "origin_y": y}
+        if quads:
+            assert z["quad_uv"][i][y & 1, x & 1].tobytes() == z["uv"][i].tobytes()
+            g = {"pos_depth": np.ascontiguousarray(z["quad_pos_depth"][i]), "nrm_scale": np.ascontiguousarray(z["quad_nrm_scale"][i]),
+                 "uv": np.ascontiguousarray(z["quad_uv"][i]), "material_id": np.ascontiguousarray(z["quad_material_id"][i]),
+                 "width": 2, "height": 2, "origin_x": x & ~1, "origin_y": y & ~1}
+        else:
+            g = {"pos_depth": np.ascontiguousarray(z["pos_depth"][i].reshape(1, 1, 4)),
+                 "nrm_scale": np.ascontiguousarray(z["nrm_scale"][i].reshape(1, 1, 4)),
+                 "uv": np.ascontiguousarray(z["uv"][i].reshape(1, 1, 2)),
+                 "material_id": np.ascontiguousarray(z["material_id"][i].reshape(1, 1)),
+                 "width": 1, "height": 1, "origin_x": x, "origin_y": y}
         gs = oracle.gbuffer_struct(g)
         r = wire.Rect(x, y, x + 1, y + 1)
         L.o_shade_transmission(C.byref(b.struct), C.byref(gs), C.byref(p), r, oracle._ptr(t16), oracle._ptr(t32), 1)

@@ -15,6 +15,7 @@ Transcendentals go through glibc (powf/logf/expf/log2f), the library the referen
 
 cases a, b, c: every pixel of a 48x32 frame (2 lights; 4 lights + spotlights + ragged lists + roughness override;
                every texture slot with holes).
+case f:        1 200 pixels of a 3840x2160 frame of TEXTURED materials (see sampled_4k_textured_case).
 cases d, e:    2 000 random pixels of the BENCHMARK'S OWN frames at 3840x2160 — d: the headline scene (sun + 1 light),
                e: BASELINE config 3 (sun + 4 lights, roughness override 0.25) — whose framebuffer-size-dependent terms
                (lod = log2(3840) * r over a 12-level pyramid, 240x135-pixel clusters) the small frames never reach.  The
@@ -187,6 +188,52 @@ def sampled_4k_case(tag, lut, num_point_lights, roughness_override, n_pixels=200
         **scene_arrays(scene))
 
 
+def sampled_4k_textured_case(tag, lut, n_pixels=1200):
+    """case f: n pixels of a 3840x2160 frame whose materials bind texture slots (the lite class, the usual glTF set and the
+    every-slot material of synthetic.apply_textures; sun + 2 lights), two thirds of them on textured materials: the
+    full-class front end — implicit LOD from the 2x2 quad, normal mapping, per-lane roughness -> per-lane pyramid lod over
+    the 12-level pyramid — at the frame size the small case c never reaches.  The fixture holds each sampled pixel's whole
+    quad (the derivatives' inputs)."""
+    w, h = 3840, 2160
+    scene = synthetic.make_scene(w, h, num_point_lights=2, textured=True)
+    scene["uniforms"].ggx_lut_texture_index = len(scene["textures"])
+    g = scene["gbuffer"]
+    textures = [(vk.blit_chain_rgba8(img, srgb), srgb) for img, srgb in scene["textures"]]
+    mip0 = synthetic.make_opaque_mip0(w, h)
+    t0 = time.time()
+    levels = vk.blit_chain_rgba16f(mip0)
+    print(f"case {tag}: {len(levels)}-level pyramid of {w}x{h} in {time.time() - t0:.1f} s")
+    rng = np.random.default_rng(0xF)
+    mid = g["material_id"]
+    textured_ids = [i for i, m in enumerate(scene["materials"]) if any(getattr(m.textures, f) != -1 for f, _ in m.textures._fields_)]
+    is_tex = np.isin(mid, np.array(textured_ids, dtype=mid.dtype))
+    ty, tx = np.nonzero(is_tex)
+    pick = rng.integers(0, len(ty), (2 * n_pixels) // 3)
+    pix = list(zip(ty[pick].tolist(), tx[pick].tolist()))
+    rest = n_pixels - len(pix)
+    pix += list(zip(rng.integers(0, h, rest).tolist(), rng.integers(0, w, rest).tolist()))
+    t0 = time.time()
+    out_t, steps = run_module("fragment_transmission", scene, g, levels, lut, pix, textures)
+    out_o, _ = run_module("fragment", scene, g, levels, lut, pix, textures)
+    print(f"case {tag}: {len(pix)} px of {w}x{h} ({int(is_tex[[p[0] for p in pix], [p[1] for p in pix]].sum())} on textured materials), "
+          f"{steps / len(pix):.0f} SPIR-V instructions / px (transmission), {time.time() - t0:.1f} s")
+    py, px_ = np.array([p[0] for p in pix]), np.array([p[1] for p in pix])
+    qy, qx = (py & ~1)[:, None, None] + np.arange(2)[None, :, None], (px_ & ~1)[:, None, None] + np.arange(2)[None, None, :]
+    import hashlib
+    np.savez_compressed(
+        os.path.join(OUT, f"spirv_case_{tag}.npz"),
+        width=w, height=h, num_point_lights=2, roughness_override=np.float32(-1.0), textured=1,
+        pixels=np.array(pix, dtype=np.int32),
+        pos_depth=g["pos_depth"][py, px_], nrm_scale=g["nrm_scale"][py, px_], uv=g["uv"][py, px_], material_id=g["material_id"][py, px_],
+        quad_pos_depth=g["pos_depth"][qy, qx], quad_nrm_scale=g["nrm_scale"][qy, qx], quad_uv=g["uv"][qy, qx],
+        quad_material_id=g["material_id"][qy, qx],
+        opaque_mip0_sha256=np.frombuffer(hashlib.sha256(mip0.tobytes()).digest(), dtype=np.uint8),
+        texture_srgb=np.array([s_ for _, s_ in scene["textures"]], dtype=np.uint8),
+        **{f"texture_{i}": img for i, (img, _) in enumerate(scene["textures"])},
+        spirv_fragment_transmission=out_t[0], spirv_fragment_hdr=out_o[0], spirv_fragment_opaque_sampled=out_o[1],
+        **scene_arrays(scene))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     lut = read_png_rgba8(os.path.join(ROOT, "transmission_renderer_amd", "assets", "ggx_lut.png"))
@@ -238,6 +285,8 @@ def main():
         sampled_4k_case("d", lut, 1, None)
     if not only or "e" in only:
         sampled_4k_case("e", lut, 4, 0.25)
+    if not only or "f" in only:
+        sampled_4k_textured_case("f", lut)
 
 
 if __name__ == "__main__":

@@ -104,7 +104,9 @@ struct alignas(16) tr_dmat {
                            // bit2: the material has texture slots (shaded by the per-pixel material path);
                            // bit3: ... of the lite class (lite_dmat);
                            // bit4: kd is zero in every channel (transmission_factor == 1 or metallic == 1): the
-                           //       transmissive pass needs no diffuse sum; bit5: c_diff is (metallic == 1): nor the opaque
+                           //       transmissive pass needs no diffuse sum; bit5: c_diff is (metallic == 1): nor the opaque;
+                           // bit6: the btdf lobe's constants bt_a, bt_b are +-0 in every channel (alpha_t = 0: ior 1, or roughness 0):
+                           //       its sums are multiplied by zero in the resolve and need not be formed
     float ior_clamp;       // clamp(2 ior - 2, 0, 1)
     float f0_dielectric;   // ((ior - 1) / (ior + 1))^2
     float bt_a[3];         // k[1] * (1 - f0): the btdf lobe is accumulated as sum(I D'V') and sum(I D'V' p') and
@@ -987,6 +989,8 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
     // (scalar) the diffuse sum is read: always for a per-lane or lite record; for a scalar record unless its diffuse
     // constant (kd in the transmissive pass, c_diff in the opaque one) is zero in every channel
     const bool diffuse_on = !std::is_same<MatP, cdmat*>::value || TR_ABLATION || !(mat_base(m)->flags & (TRANSMISSIVE ? 16u : 32u));
+    // (scalar) the btdf lobe is evaluated: not for a scalar record whose lobe constants are zero (tr_dmat::flags bit 6)
+    const bool lobe_on = transmits && (!std::is_same<MatP, cdmat*>::value || TR_ABLATION || !(mat_base(m)->flags & 64u));
     auto issue_taps = [&]() {
     if (transmits) {
         const auto mb = mat_base(m);
@@ -1040,7 +1044,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
         // sun (lighting.rs:37-53 / 171-177)
         if (!TR_ABLATE(L2, 4u))
             eval_light<TRANSMISSIVE, !TR_ABLATION>(acc, *m2, px, {L2->fp.sun_dir[0], L2->fp.sun_dir[1], L2->fp.sun_dir[2]},
-                                     {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, transmits, diffuse_on);
+                                     {L2->fp.sun_intensity[0], L2->fp.sun_intensity[1], L2->fp.sun_intensity[2]}, lobe_on, diffuse_on);
         tile_phase<1>();
     };
     // punctual lights (lighting.rs:55-92 / 179-217): count, list and lights all through the scalar unit.  One trip of
@@ -1063,7 +1067,7 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
 #pragma clang loop unroll(disable)   // (left alone the first two trips are peeled: three copies of the light evaluation)
                 for (uint32_t i = 0; i < n; ++i) {
                     const uint32_t idx = (cl.uniform && i == 0u) ? cl.s_l0 : (cl.uniform && i == 1u) ? cl.s_l1 : list[i];
-                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[idx], pos, px, transmits, diffuse_on);
+                    eval_punctual<TRANSMISSIVE>(acc, *m2, lights[idx], pos, px, lobe_on, diffuse_on);
                 }
                 if constexpr (!TRANSMISSIVE) lights_walked = n;
             }
@@ -1094,12 +1098,14 @@ __device__ __forceinline__ f3 shade_pixel(claunch* L, MatP m, uint32_t mat_index
                    fmaf(m4->ks_df[2], acc.sp.z, m4->ks_f0[2] * acc.s.z)};            // specular: sum I nol D*V F
             if (diffuse_on) out = {fmaf(kd[0], acc.d.x, out.x), fmaf(kd[1], acc.d.y, out.y), fmaf(kd[2], acc.d.z, out.z)};
             if (transmits) {
-                out.x = fmaf(m4->kta[0], acc.ta.x, out.x);
-                out.y = fmaf(m4->kta[1], acc.ta.y, out.y);
-                out.z = fmaf(m4->kta[2], acc.ta.z, out.z);
-                out.x = fmaf(-m4->ktb[0], acc.tb.x, out.x);
-                out.y = fmaf(-m4->ktb[1], acc.tb.y, out.y);
-                out.z = fmaf(-m4->ktb[2], acc.tb.z, out.z);
+                if (lobe_on) {
+                    out.x = fmaf(m4->kta[0], acc.ta.x, out.x);
+                    out.y = fmaf(m4->kta[1], acc.ta.y, out.y);
+                    out.z = fmaf(m4->kta[2], acc.ta.z, out.z);
+                    out.x = fmaf(-m4->ktb[0], acc.tb.x, out.x);
+                    out.y = fmaf(-m4->ktb[1], acc.tb.y, out.y);
+                    out.z = fmaf(-m4->ktb[2], acc.tb.z, out.z);
+                }
                 issue_taps();
                 TR_PROBE_WAITED(2, t_taps)
                 tile_phase<3>();
@@ -1950,7 +1956,9 @@ __global__ void digest_materials_kernel(const tr_material_info* __restrict__ in,
             kd0 = kd0 && d.c_diff[k] * omtf == 0.0f;
             cd0 = cd0 && d.c_diff[k] == 0.0f;
         }
-        d.flags |= (kd0 ? 16u : 0u) | (cd0 ? 32u : 0u);
+        bool bt0 = true;   // (never for NaN / infinite factors either: 0 * x must stay what it is)
+        for (int k = 0; k < 3; ++k) bt0 = bt0 && d.bt_a[k] == 0.0f && d.bt_b[k] == 0.0f;
+        d.flags |= (kd0 ? 16u : 0u) | (cd0 ? 32u : 0u) | (bt0 ? 64u : 0u);
     }
     for (int k = 0; k < 3; ++k) {
         float coeff = -logf(mi.attenuation_colour[k]) / mi.attenuation_distance;  // :284
