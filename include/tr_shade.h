@@ -373,9 +373,11 @@ typedef struct tr_gbuffer_target {
  * depth_pre_pass_alpha_clip), `transmissive` <- buffers 2 and 3 where nearer than the opaque layer.
  * draw_counts / draws: device pointers as produced by tr_demultiplex_draws.  Materials (and textures, for alpha
  * clipping) must have been uploaded.  Fixed-function rules restated: see oracle/tr_oracle.h o_rasterize.
- * Not for stream capture: the set-up launch carries a per-call frame counter (the tag of its scan's look-back words), a
- * replayed launch would repeat it.  A capturing `stream` is refused with TR_ERR_UNSUPPORTED — also by tr_draw_scene and
- * tr_record_frame, which rasterise through this — and nothing is enqueued.
+ * Stream capture: allowed — like tr_draw_scene and tr_record_frame, which rasterise through this — once a call with the same
+ * frame size has run outside the capture (the scan's frame counter lives on the device and moves on with every replay).  What
+ * cannot be captured is refused with TR_ERR_UNSUPPORTED before anything is enqueued: (re)allocating the visibility buffers
+ * for another frame size, rebuilding a table, the timed frame recorder.  Replays of a captured frame must not interleave
+ * with other rasterising calls of the context.
  */
 tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
                        const tr_push_constants* push, const tr_gbuffer_target* opaque,

@@ -244,10 +244,10 @@ def test_screen_filling_degenerate_and_off_screen_triangles(renderer):
     assert (want_t["material_id"].view(np.int32) == -1).all()
 
 
-def test_rasterising_entries_refuse_a_capturing_stream(renderer):
-    """tr_draw_scene (and tr_rasterize / tr_record_frame through the same check) carries a per-call frame counter as a launch
-    argument: under stream capture it is refused (status 6) before anything is enqueued, and the context works on afterwards."""
-    from transmission_renderer_amd import _lib
+def test_draw_scene_replays_from_a_hip_graph(renderer):
+    """tr_draw_scene (culling, demultiplex, set-up with its look-back scan, rasteriser, resolve) captured into a HIP graph after
+    a first call outside the capture: every replay writes the layers of the direct call (the scan's frame counter is on the
+    device and moves on with every replay), and the context works on afterwards."""
     w, h = 256, 128
     view = wire.default_camera()[1]
     geo = meshes.make_mesh_scene()
@@ -256,18 +256,20 @@ def test_rasterising_entries_refuse_a_capturing_stream(renderer):
     got_o, _ = _gpu_layers(renderer, geo, sc, w, h, culling)          # (uploads; a first, uncaptured call)
     o, t = renderer.new_layer(w, h), renderer.new_layer(w, h)
     side = torch.cuda.Stream()
-    graph = torch.cuda.CUDAGraph()
-    status = None
     with torch.cuda.stream(side):
-        side.synchronize()
-        with torch.cuda.graph(graph, stream=side):
-            try:
-                renderer.draw_scene(culling, sc["push"], o, t)
-            except _lib.TrError as e:
-                status = e.status
-            torch.zeros(4, device=renderer.device).add_(1.0)           # (something to capture, so that the graph is not empty)
+        renderer.draw_scene(culling, sc["push"], o, t)                  # (once on the capturing stream, outside the capture)
     torch.cuda.synchronize()
-    assert status == 6
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        renderer.draw_scene(culling, sc["push"], o, t)
+    for k in range(3):
+        o.material_id.fill_(-7)
+        o.pos_depth.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(o.material_id.cpu().numpy().view(np.uint32), got_o["material_id"]), k
+        covered = got_o["material_id"] != wire.NOT_COVERED              # (only the id plane is defined where no fragment landed)
+        assert covered.mean() > 0.2 and np.array_equal(o.pos_depth.cpu().numpy()[covered], got_o["pos_depth"][covered]), k
     renderer.draw_scene(culling, sc["push"], o, t)
     torch.cuda.synchronize()
     assert np.array_equal(o.material_id.cpu().numpy().view(np.uint32), got_o["material_id"])
@@ -454,6 +456,61 @@ def test_fused_front_end_with_many_culling_blocks_over_many_frames(renderer, ggx
             assert torch.equal(hdr.view(torch.int16), want[k & 1].view(torch.int16)), k
     torch.cuda.synchronize()
     assert torch.equal(hdr.view(torch.int16), want[1].view(torch.int16))
+
+
+def test_record_frame_replays_from_a_hip_graph(renderer, ggx_lut):
+    """A whole frame — culling, set-up with its look-back scan, rasteriser, both shading launches, mips — captured into a HIP
+    graph once a frame has run outside the capture, and replayed: every replay is the direct frame bit for bit (the scan's
+    frame counter lives on the device and moves on with every replay; a repeated tag would make stale look-back words read as
+    current).  What cannot be captured is refused: a frame of another size would have to re-lay the visibility buffers out."""
+    r = renderer
+    w, h = 320, 180
+    geo = meshes.make_mesh_scene()
+    view = wire.default_camera()[1]
+    sc = _scene(w, h, view)
+    q = wire.view_rotation_inverse(view)
+    culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+    r.upload_materials(sc["materials"])
+    r.upload_textures(sc["textures"])
+    r.upload_lights(sc["lights"])
+    r.upload_geometry(geo)
+    aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+    work = r.new_frame_buffers(w, h)
+    frame = lambda: r.record_frame(sc["uniforms"], sc["push"], culling, view, q, aabbs, work)
+    hdr, ldr = frame()
+    torch.cuda.synchronize()
+    want_hdr, want_ldr = hdr.clone(), ldr.clone()
+    assert (want_hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        frame()                      # (once on the capturing stream: it has then seen every table)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        frame()
+    for k in range(4):
+        work["hdr"].zero_()
+        work["ldr"].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(work["hdr"].view(torch.int16), want_hdr.view(torch.int16)) and torch.equal(work["ldr"], want_ldr), k
+    # a direct frame after the replays starts from what they left behind
+    hdr, ldr = frame()
+    torch.cuda.synchronize()
+    assert torch.equal(hdr.view(torch.int16), want_hdr.view(torch.int16)) and torch.equal(ldr, want_ldr)
+    # another frame size inside a capture: refused before anything is enqueued
+    from transmission_renderer_amd._lib import TrError
+    small = r.new_frame_buffers(160, 96)
+    sc2 = _scene(160, 96, view)
+    aabbs2 = r.write_cluster_data(sc2["uniforms"], wire.inverse_perspective(160, 96), (160, 96))
+    culling2 = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(160, 96), view)
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(TrError):
+        with torch.cuda.graph(g2, stream=side):
+            r.record_frame(sc2["uniforms"], sc2["push"], culling2, view, q, aabbs2, small)
+    torch.cuda.synchronize()
+    frame()
+    torch.cuda.synchronize()
 
 
 def _stepwise_frame(r, sc, culling, view, q, aabbs, w, h, dtype=torch.float16):

@@ -316,8 +316,14 @@ struct raster_record {
     uint32_t x0, y0, x1, y1, flags;
 };
 __global__ __launch_bounds__(256) void raster_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_raster_layers rl,
-                                                     const tr_alpha_tables alpha) {
+                                                     const tr_alpha_tables alpha, uint32_t* __restrict__ scan_epoch) {
 #pragma clang fp contract(off)
+    // The frame counter the set-up launch in front of this one tagged its look-back words with (scan_lookback) moves on here,
+    // on the device: a captured frame replays with a new tag every time.  30 bits, never 0 (= never written).
+    if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x == 0u) {
+        const uint32_t e = __hip_atomic_load(scan_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(scan_epoch, e >= 0x3FFFFFFFu ? 1u : e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const uint32_t layer = blockIdx.y;
     if (!rl.enabled[layer]) return;
     const tr_tri_record* __restrict__ records = rl.records[layer];
@@ -583,7 +589,11 @@ __global__ __launch_bounds__(1024) void raster_scan_draws_kernel(const tr_two_la
 __global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_view g, const tr_raster_frame f, const tr_two_layers two,
                                                            const uint32_t* __restrict__ material_flags, uint32_t flags_stride,
                                                            unsigned long long* __restrict__ scan_status, uint32_t status_stride,
-                                                           uint32_t epoch) {
+                                                           const uint32_t* __restrict__ scan_epoch) {
+    // this frame's tag, advanced by the rasteriser launch behind this one.  (An agent-scope load, past the scalar and vector
+    // caches: replayed from a HIP graph, a plain or scalar load here returned the PREVIOUS replay's value — the look-back
+    // then read that replay's words as current)
+    const uint32_t epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(scan_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     TR_PICK_LAYER(two, blockIdx.y);
     if (W.capacity_triangles == 0u) return;
     __shared__ uint32_t lds_wave[4];

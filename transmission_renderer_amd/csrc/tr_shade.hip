@@ -83,6 +83,15 @@ __global__ __launch_bounds__(256) void frame_front_kernel(const tr_cull_params c
 }
 }  // namespace tr
 
+namespace tr {
+// Zero fill of `words` 32-bit words.  The per-frame clears go through this kernel, not hipMemsetAsync: a memset node of a
+// captured frame wrote the words it should have cleared with pointer-like garbage from its second replay on (ROCm 7.0's HIP
+// runtime under torch 2.10; tools/gpu_debug_capture2.py), a kernel node replays like any other launch.
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, uint32_t words) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) p[i] = 0u;
+}
+}  // namespace tr
+
 struct tr_context {
     int device = 0;
     int32_t last_hip_error = 0;
@@ -130,7 +139,6 @@ struct tr_context {
     uint32_t* d_item_base = nullptr;
     unsigned long long* d_scan_status = nullptr;   // per layer and set-up workgroup: the look-back words of the work-item prefix
     uint32_t scan_blocks = 0;                      // ... workgroups per layer (the words' stride)
-    uint32_t scan_epoch = 0;                       // ... and the frame counter they are tagged with (never 0)
     tr_layer_counts* d_layer_counts = nullptr;
     unsigned long long* d_vis[2] = {nullptr, nullptr};
     uint32_t* d_tile_cover[2] = {nullptr, nullptr};   // per layer: one word per 64x4 block tile (inside the d_vis allocation)
@@ -217,6 +225,14 @@ struct tr_context {
 
 namespace {
 
+inline hipError_t zero_fill(void* p, size_t bytes, hipStream_t stream) {   // (bytes: a multiple of 4, below 16 GiB)
+    const uint32_t words = (uint32_t)(bytes / 4u);
+    if (words == 0u) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((words + 255u) / 256u, 4096u);
+    hipLaunchKernelGGL(tr::zero_words_kernel, dim3(blocks), dim3(256), 0, stream, (uint32_t*)p, words);
+    return hipGetLastError();
+}
+
 #define TR_HIP(ctx, expr)                                   \
     do {                                                    \
         hipError_t e_ = (expr);                             \
@@ -240,6 +256,10 @@ uint32_t mip_levels_for_size(uint32_t w, uint32_t h) {
 // (Rebuilds are rare — new materials, another pyramid geometry, other cluster coefficients — so this is a device-wide
 // wait, not an event per launch.)
 tr_status tables_before_rebuild(tr_context* ctx, hipStream_t stream) {
+    // (a table rebuild allocates, copies from pageable host memory or synchronises: none of it can be captured.  A frame is
+    //  captured after one has run outside the capture, when every table is in place)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return TR_ERR_UNSUPPORTED;
     bool others = false;
     for (const auto& s : ctx->launch_streams) others |= s.stream != stream;
     if (others) TR_HIP(ctx, hipDeviceSynchronize());
@@ -1039,7 +1059,7 @@ tr_status tr_frustum_culling(tr_context* ctx, const void* primitives, uint32_t n
         return TR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
     TR_HIP(ctx, hipSetDevice(ctx->device));
-    TR_HIP(ctx, hipMemsetAsync(instance_counts, 0, sizeof(uint32_t) * num_primitives, stream));   // src/main.rs:1668-1674
+    TR_HIP(ctx, zero_fill(instance_counts, sizeof(uint32_t) * num_primitives, stream));   // src/main.rs:1668-1674
     if (instance_counts == ctx->d_instance_counts) ctx->counts_clean = false;   // (left holding this frame's counts)
     if (num_instances == 0) return TR_OK;
     tr_cull_params p;
@@ -1113,9 +1133,11 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_tri_planes, 2u * cap * sizeof(tr_tri_planes)));
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_item_base, 2u * (cap + 1u) * 4u));
     ctx->scan_blocks = (uint32_t)((cap + 255u) / 256u);
-    TR_HIP(ctx, hipMalloc((void**)&ctx->d_scan_status, 2u * (size_t)ctx->scan_blocks * 8u));
-    TR_HIP(ctx, hipMemsetAsync(ctx->d_scan_status, 0, 2u * (size_t)ctx->scan_blocks * 8u, stream));   // epoch 0 = never written
-    ctx->scan_epoch = 0;
+    // (behind the status words: the frame counter they are tagged with — on the device, advanced by every rasteriser launch,
+    //  so that a captured frame replays with a new tag each time; a tag of 0 = never written)
+    TR_HIP(ctx, hipMalloc((void**)&ctx->d_scan_status, (2u * (size_t)ctx->scan_blocks + 1u) * 8u));
+    TR_HIP(ctx, hipMemsetAsync(ctx->d_scan_status, 0, (2u * (size_t)ctx->scan_blocks + 1u) * 8u, stream));
+    TR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scan_status + 2u * (size_t)ctx->scan_blocks), 1, 1, stream));
     TR_HIP(ctx, hipMalloc((void**)&ctx->d_layer_counts, 2u * sizeof(tr_layer_counts)));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_position, g->position, nv * 12u, hipMemcpyHostToDevice, stream));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_normal, g->normal, nv * 12u, hipMemcpyHostToDevice, stream));
@@ -1137,9 +1159,18 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
 }  // extern "C"
 
 namespace {
+// The entries that rasterise can be captured into a HIP graph once a frame of the same size has run outside a capture:
+// what they refuse under capture is what cannot be captured — growing the visibility buffers (ensure_vis_buffers) and
+// rebuilding a table (tables_before_rebuild).
+bool stream_is_capturing(void* stream) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing((hipStream_t)stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone;
+}
+
 // The rasteriser's per-frame-size buffers: both layers' visibility words, behind them the two tile coverage maps.
-tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h) {
+tr_status ensure_vis_buffers(tr_context* ctx, uint32_t w, uint32_t h, void* stream) {
     const size_t npix = (size_t)w * h;
+    if ((npix > ctx->vis_pixels || ctx->vis_w != w || ctx->vis_h != h) && stream_is_capturing(stream)) return TR_ERR_UNSUPPORTED;
     if (npix > ctx->vis_pixels) {
         TR_HIP(ctx, hipDeviceSynchronize());
         (void)hipFree(ctx->d_vis[0]);
@@ -1195,12 +1226,6 @@ void fill_two_layers(const tr_context* ctx, const void* const draws[TR_NUM_DRAW_
     }
 }
 
-// The set-up launch's epoch is a launch argument: a graph replay would repeat it (stale look-back words would read as current).
-// The entries that rasterise refuse a capturing stream before they enqueue anything.
-bool stream_is_capturing(void* stream) {
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    return hipStreamIsCapturing((hipStream_t)stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone;
-}
 
 // fused_demux: the frame recorder's call — its first launch has demultiplexed the draws and scanned both layers' draw
 // streams behind its culling blocks (frame_front_kernel) and zeroed the coverage maps.
@@ -1220,11 +1245,10 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     if (!ctx->d_position || ctx->num_materials == 0) return TR_ERR_TABLES_MISSING;
     if (ctx->max_texture_id >= (int32_t)ctx->num_textures) return TR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
-    if (stream_is_capturing(stream_)) return TR_ERR_UNSUPPORTED;
     TR_HIP(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)w * h;
     {
-        const tr_status vs = ensure_vis_buffers(ctx, w, h);
+        const tr_status vs = ensure_vis_buffers(ctx, w, h, stream_);
         if (vs != TR_OK) return vs;
     }
     tr_geometry_view gv;
@@ -1246,10 +1270,10 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     fill_two_layers(ctx, draws, targets, two);
     // The visibility buffers are zero on entry: filled once after (re)allocation, and every resolve zeroes the words its
     // frame set (raster_resolve_body).  Per frame only the two tile coverage maps are cleared (260 KB at 4K).
-    if (!ctx->vis_clean) TR_HIP(ctx, hipMemsetAsync(ctx->d_vis[0], 0, 2u * npix * 8u, stream));
+    if (!ctx->vis_clean) TR_HIP(ctx, zero_fill(ctx->d_vis[0], 2u * npix * 8u, stream));
     ctx->vis_clean = false;   // (until this frame's resolve is enqueued)
     if (!(fused_demux && ctx->cover_cleared))   // (the frame recorder's first launch has zeroed them for its own call)
-        TR_HIP(ctx, hipMemsetAsync(ctx->d_tile_cover[0], 0, cover_clear_bytes(w, h), stream));
+        TR_HIP(ctx, zero_fill(ctx->d_tile_cover[0], cover_clear_bytes(w, h), stream));
     ctx->cover_cleared = false;
     const uint32_t max_cap = std::max(ctx->max_triangles[0], ctx->max_triangles[1]);
     // (the set-up tags every triangle with its material's class for the tile coverage words the shading launches steer by:
@@ -1262,14 +1286,11 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
         if (!fused_demux)
             hipLaunchKernelGGL(raster_scan_draws_kernel, dim3(1, 2), dim3(1024), 0, stream, two, (const uint32_t*)draw_counts,
                                ctx->num_primitives);
-        // set-up + the work-item prefix (decoupled look-back; its status words are tagged with this call's epoch)
-        if (ctx->scan_epoch >= 0x3FFFFFFFu) {   // (2^30 frames on: the tags wrap, start over from clean words)
-            TR_HIP(ctx, hipMemsetAsync(ctx->d_scan_status, 0, 2u * (size_t)ctx->scan_blocks * 8u, stream));
-            ctx->scan_epoch = 0u;
-        }
-        ctx->scan_epoch += 1u;
+        // set-up + the work-item prefix (decoupled look-back; its status words are tagged with the frame counter the device
+        // keeps behind them, which the rasteriser launch that follows advances)
+        uint32_t* const epoch_word = reinterpret_cast<uint32_t*>(ctx->d_scan_status + 2u * (size_t)ctx->scan_blocks);
         hipLaunchKernelGGL(raster_setup_kernel, dim3((max_cap + 255u) / 256u, 2), dim3(256), 0, stream, gv, fr, two, mat_flags,
-                           (uint32_t)(sizeof(tr_dmat) / 4u), ctx->d_scan_status, ctx->scan_blocks, ctx->scan_epoch);
+                           (uint32_t)(sizeof(tr_dmat) / 4u), ctx->d_scan_status, ctx->scan_blocks, (const uint32_t*)epoch_word);
         tr_raster_layers rl;
         for (uint32_t layer = 0; layer < 2u; ++layer) {
             const tr_layer_work& W = two.l[layer];
@@ -1280,7 +1301,7 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
             rl.tile_cover[layer] = ctx->d_tile_cover[layer];
             rl.enabled[layer] = ctx->max_triangles[layer] != 0u ? 1u : 0u;
         }
-        hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * ctx->raster_wgs_per_cu, 2), dim3(256), 0, stream, gv, fr, rl, at);
+        hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * ctx->raster_wgs_per_cu, 2), dim3(256), 0, stream, gv, fr, rl, at, epoch_word);
     }
     if (resolve) {
         hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u), dim3(256), 0, stream, fr, two,
@@ -1304,7 +1325,6 @@ tr_status tr_draw_scene(tr_context* ctx, const tr_culling_push_constants* cullin
                         const tr_gbuffer_target* opaque, const tr_gbuffer_target* transmissive, void* stream) {
     if (!ctx || !culling || !push) return TR_ERR_INVALID_ARGUMENT;
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
-    if (stream_is_capturing(stream)) return TR_ERR_UNSUPPORTED;
     tr_status st = tr_frustum_culling(ctx, ctx->d_primitives, ctx->num_primitives, ctx->d_instances, ctx->num_instances,
                                       culling, ctx->d_instance_counts, stream);
     if (st != TR_OK) return st;
@@ -2077,7 +2097,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
     if (w == 0 || h == 0 || w > 65535u || h > 65535u) return TR_ERR_INVALID_ARGUMENT;
     if (!ctx->d_position) return TR_ERR_TABLES_MISSING;
     if (ctx->strip_rows != 0u) return TR_ERR_UNSUPPORTED;   // (the frame recorder renders whole frames)
-    if (stream_is_capturing(stream)) return TR_ERR_UNSUPPORTED;
+    if (rec && stream_is_capturing(stream)) return TR_ERR_UNSUPPORTED;   // (the timed frame synchronises around every pass)
     ctx->cover_cleared = false;
     // RGBA16F frames are shaded straight from the rasteriser's visibility words (shade_kernel's VIS launches): no resolve,
     // the work planes of the descriptor stay untouched.  RGBA32F frames go through the planes.
@@ -2093,7 +2113,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         // against the unfused passes over many frames.  (The timed frame launches every pass on its own, below.)
         hipStream_t s_ = (hipStream_t)stream;
         TR_HIP(ctx, hipSetDevice(ctx->device));
-        if (!ctx->counts_clean) TR_HIP(ctx, hipMemsetAsync(ctx->d_instance_counts, 0, sizeof(uint32_t) * ctx->num_primitives, s_));
+        if (!ctx->counts_clean) TR_HIP(ctx, zero_fill(ctx->d_instance_counts, sizeof(uint32_t) * ctx->num_primitives, s_));
         ctx->counts_clean = false;
         tr_cull_params cp;
         cp.pc = *f->culling;
@@ -2105,7 +2125,7 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         ap.num_lights = ctx->num_lights;
         ap.num_clusters = f->num_clusters;
         const uint32_t cull_blocks = (ctx->num_instances + 255u) / 256u, assign_blocks = (f->num_clusters + 3u) / 4u;
-        st = ensure_vis_buffers(ctx, w, h);
+        st = ensure_vis_buffers(ctx, w, h, stream);
         if (st != TR_OK) return st;
         const uint32_t clear_vectors = (uint32_t)(cover_clear_bytes(w, h) / 16u), clear_blocks = (clear_vectors + 255u) / 256u;
         tr_front_demux dm;
