@@ -1717,6 +1717,8 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
     const uint32_t slot = listed ? blockIdx.x / kFrontLists : (blockIdx.x >> 3);
     uint32_t j = slot;
     tile_regs cur;
+    uint32_t clear_present = 0u;         // (scalar) the presented background pixel, once the wave has met a background tile
+    bool have_clear_present = false;
     while (j < wave_tiles) {
         tile_phase<0>();
         TR_PROBE_SINCE(t_fetch)   // (from before the fetch: a VIS tile's inputs are two dependent round trips inside it)
@@ -1799,6 +1801,34 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
         // load behind the store could not be waited for without waiting for the store's acknowledgement as well.
         const uint32_t out_px = cur.px, out_py = cur.py;
         j += launder(L)->fp.j_step;
+        if constexpr (VIS && !TRANSMISSIVE && sizeof(OutT) == 8) {
+            // A wave tile of the frame recorder's opaque launch that no opaque fragment and no transmissive one landed in — the
+            // background: half of a typical frame — holds the clear colour, texel for texel: its targets are written from
+            // constants (level 1's box of four clear texels is the clear texel), and the presented pixel — fragment_tonemap of
+            // that texel: 19 transcendental instructions — is evaluated once per WAVE, not per tile (the same function on the
+            // same bits), and kept in a scalar register.
+            if (ballot(active) == 0ull && cur.cover_front == 0u) {
+                claunch* W = launder(L);
+                const uint2 clear = uint2{0x00000000u, 0x3C000000u};   // RGBA16F (0, 0, 0, 1), src/main.rs:1592-1601
+                if (inside) {
+                    const uint32_t pix = mad24(out_py, W->fp.width, out_px);
+                    st<uint2>(W->hdr, pix * 8u, clear);
+                    if (W->mip0) st<uint2>(W->mip0, pix * 8u, clear);
+                    if (W->mip1 != nullptr && (lane_here() & 17u) == 0u)
+                        st<uint2>(W->mip1, mad24(out_py >> 1, W->fp.width >> 1, out_px >> 1) * 8u, clear);
+                    if (W->present != nullptr) {
+                        if (!have_clear_present) {
+                            const tr_tonemap_params pp = {W->present_params.a, W->present_params.b, W->present_params.c, W->present_params.d,
+                                                          W->present_params.crosstalk, W->present_params.saturation, W->present_params.cross_saturation};
+                            clear_present = (uint32_t)__builtin_amdgcn_readfirstlane((int)tonemap_pixel(clear.x, clear.y, pp, W->present_e1, W->present_bgra));
+                        }
+                        st<uint32_t>(W->present, pix * 4u, clear_present);
+                    }
+                }
+                have_clear_present = have_clear_present || launder(L)->present != nullptr;
+                continue;
+            }
+        }
         // transmissive pass: uncovered pixels keep the attachment (LOAD); opaque pass: clear colour
         const bool write = TRANSMISSIVE ? active : inside;
         bool final_colour = true;   // (VIS) no later launch of the frame writes this pixel
