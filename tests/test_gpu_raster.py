@@ -601,6 +601,44 @@ def test_record_frame_from_visibility_words_untextured(ggx_lut):
         assert (hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
 
 
+@pytest.mark.parametrize("w,h", [(320, 180), (483, 273), (514, 290), (1920, 1080), (1024, 1024), (3840, 2160)])
+def test_record_frame_leaves_the_whole_opaque_pyramid(ggx_lut, w, h):
+    """The pyramid a recorded frame leaves behind — level 1 written by the opaque launch itself from its wave tiles' quads when
+    both frame sizes are even, the chain's launches from level 2 on; from level 1 on for odd sizes — is, level by level and bit
+    for bit, tr_generate_mips on the same level 0; over three consecutive frames, levels 1.. overwritten with NaN in between
+    (nothing survives from the frame before)."""
+    from transmission_renderer_amd.renderer import OpaquePyramid, TransmissionRenderer
+    r = TransmissionRenderer(0)
+    try:
+        r.upload_ggx_lut(ggx_lut)
+        geo = meshes.make_mesh_scene(extra_instances=True)
+        view = wire.default_camera()[1]
+        sc = _scene(w, h, view)
+        q = wire.view_rotation_inverse(view)
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+        r.upload_materials(sc["materials"])
+        r.upload_textures(sc["textures"])
+        r.upload_lights(sc["lights"])
+        r.upload_geometry(geo)
+        aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+        work = r.new_frame_buffers(w, h)
+        ref = OpaquePyramid(w, h, r.device)
+        for frame in range(3):
+            work["pyramid"].texels[w * h:].fill_(float("nan"))
+            r.record_frame(sc["uniforms"], sc["push"], culling, view, q, aabbs, work)
+            torch.cuda.synchronize()
+            got = work["pyramid"]
+            ref.level(0).copy_(got.level(0))
+            r.generate_mips(ref)
+            torch.cuda.synchronize()
+            for l in range(got.levels):
+                assert torch.equal(got.level(l).view(torch.int16), ref.level(l).view(torch.int16)), (frame, l)
+            assert torch.isfinite(got.level(got.levels - 1).float()).all()
+    finally:
+        r.close()
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("w,h", [(3840, 2160), (7680, 4320)])
 def test_record_frame_equals_the_stepwise_sequence_at_4k_and_8k(ggx_lut, tmp_path, w, h):
     """BASELINE configs 4 / 5's frame sizes through the frame recorder (culling -> rasteriser -> visibility-word shading ->
