@@ -785,11 +785,15 @@ def full_pipeline_8k(r, comp, world, rank, dev, dist, scene4k, K, args):
     hdr = torch.zeros((padded, fw, 4), dtype=torch.float16, device=dev)
     exchange = args.exchange if world > 1 else "allgather"
 
-    def frame():
-        sharded.record_sharded(r, g, g, uniforms, push, hdr, pyr, comp, exchange=exchange)
+    def frame(confirm="late"):
+        # (the halo's excess word is judged a frame late: no drain between a frame's passes and its composite; the frames in
+        #  front of the timed ones settle the halo with the word read at once, the timed ones must all be confirmed exact)
+        sharded.record_sharded(r, g, g, uniforms, push, hdr, pyr, comp, exchange=exchange, confirm=confirm)
 
     for _ in range(3):
-        frame()
+        frame("now")
+    comp.halo_shrink_after = 0          # (no probe frame inside the timed region)
+    inexact_before = int(getattr(comp, "halo_inexact_frames", 0))
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -799,10 +803,14 @@ def full_pipeline_8k(r, comp, world, rank, dev, dist, scene4k, K, args):
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
+    if hasattr(comp, "confirm_halo"):
+        comp.confirm_halo()             # (the last frame's verdict)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item()) / K * 1e3
     out = {"ms_per_frame": round(ms, 4), "Mpixels_per_s": round(fw * fh / ms / 1e3, 1), "frames": K,
+           "exchange_confirmed": "a frame late (no drain in front of the composite)",
+           "exchange_inexact_frames": int(getattr(comp, "halo_inexact_frames", 0)) - inexact_before,
            "workload": f"opaque -> exchange -> mip chain -> transmissive -> composite, frame {fw}x{fh} in {world} row bands of {rows} rows, "
                        f"synthetic TGB-v1 layer as both layers, sun + {args.lights} punctual light(s)",
            "exchange": exchange, "exchange_fallbacks": int(getattr(comp, "halo_fallbacks", 0)),

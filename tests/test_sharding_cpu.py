@@ -183,6 +183,11 @@ class _OracleRenderer:
     def tap_window_excess(self):
         return self.excess
 
+    device = "cpu"
+
+    def tap_window_excess_word(self):
+        return torch.tensor([self.excess], dtype=torch.int64)
+
     def _window_excess(self, g, push, pyramid, rect):
         """What the kernel's tap_window_excess reports, restated in numpy (float64): 1 + the level-0 rows by which the
         bilinear rows of a tap of level 0 / 1 lie outside the window."""
@@ -371,6 +376,94 @@ def test_record_sharded_halo_exchange_over_gloo_matches_single_rank(tmp_path, gg
             assert fallbacks == 1 and halo_now > halo
         else:
             assert calls.split() == ["opaque", "mips_band", "mips_from", "transmission"] and fallbacks == 0 and halo_now == halo
+
+
+def _worker_late(rank, world, port, w, h, out_dir, halo, thickness_scale):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        from transmission_renderer_amd.png import read_png_rgba8
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        lut = read_png_rgba8(os.path.join(root, "transmission_renderer_amd", "assets", "ggx_lut.png"))
+        scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False)
+        for m in scene["materials"]:
+            m.thickness_factor *= thickness_scale
+        binding = oracle.SceneBinding(scene, lut)
+        rows, y0, y1 = sharded.band_rows(h, world, rank)
+        band = synthetic.make_gbuffer(w, h, rows=(y0, y1))
+        comp = sharded.Compositor(world, rank)
+        comp.halo_rows = halo
+        log = []
+        for frame in range(2):
+            hdr = torch.zeros((rows * world, w, 4), dtype=torch.float16)
+            pyr = _OraclePyramid(w, h, rows * world)
+            fake = _OracleRenderer(binding, scene["materials"])
+            sharded.record_sharded(fake, band, band, scene["uniforms"], scene["push"], hdr, pyr, comp, exchange="halo", confirm="late")
+            log.append(f"{' '.join(c[0] for c in fake.calls)}|{comp.halo_fallbacks} {comp.halo_inexact_frames} {comp.halo_rows}")
+        last_ok = comp.confirm_halo()
+        np.save(os.path.join(out_dir, f"frame_{rank}.npy"), hdr[:h].numpy())
+        with open(os.path.join(out_dir, f"late_{rank}.txt"), "w") as f:
+            f.write("\n".join(log) + f"\n{int(last_ok)} {comp.halo_fallbacks} {comp.halo_inexact_frames}\n")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_record_sharded_halo_confirmed_a_frame_late_over_gloo(tmp_path, ggx_lut):
+    """record_sharded(exchange="halo", confirm="late"): the excess word is all-reduced behind the passes and read when the
+    next frame starts — no drain between a frame's passes and its composite.  Frame 1 (a 4-row halo under volumes that
+    throw taps across the frame) is composited as it is and found inexact when frame 2 starts, which then exchanges more
+    rows (here: everything, the gather) and is the single-rank frame bit for bit on every rank."""
+    from oracle import oracle
+    w, h, world, halo = 64, 48, 2, 4
+    mp.spawn(_worker_late, args=(world, _free_port(), w, h, str(tmp_path), halo, 1.0), nprocs=world, join=True)
+    frames = [np.load(tmp_path / f"frame_{r}.npy") for r in range(world)]
+    scene = synthetic.make_scene(w, h, num_point_lights=2)
+    binding = oracle.SceneBinding(scene, ggx_lut)
+    hdr16, _, mip0 = oracle.shade_opaque(binding, scene["gbuffer"])
+    tex = oracle.new_pyramid(w, h, mip0)
+    oracle.generate_mips(w, h, tex)
+    oracle.shade_transmission(binding, scene["gbuffer"], tex, hdr_f16=hdr16)
+    for r in range(world):
+        np.testing.assert_array_equal(frames[r].view(np.uint16), hdr16.view(np.uint16))
+        first, second, end = open(tmp_path / f"late_{r}.txt").read().splitlines()
+        calls, state = first.split("|")
+        assert calls.split() == ["opaque", "mips_band", "mips_from", "transmission"]      # nothing redone, nothing read
+        assert [int(x) for x in state.split()] == [0, 0, halo]
+        calls, state = second.split("|")
+        fallbacks, inexact, halo_now = (int(x) for x in state.split())
+        assert fallbacks == 1 and inexact == 1 and halo_now > halo
+        assert [int(x) for x in end.split()] == [1, 1, 1]
+
+
+def test_halo_policy_grows_at_once_and_shrinks_by_probing():
+    """Compositor's halo book-keeping without any rank: a tap that leaves the halo widens it at once; after
+    halo_shrink_after clean frames one frame checks its taps against three quarters of the halo — the exchange shrinks when
+    they fit, stays when they do not, and a probe frame whose taps left the whole halo is a fallback like any other."""
+    comp = sharded.Compositor.__new__(sharded.Compositor)
+    comp.halo_rows, comp.halo_shrink_after = 64, 3
+    assert comp.halo_window_margin(64) == 64
+    assert comp.halo_verdict(0, 64, 64) and comp.halo_clean_frames == 1
+    assert not comp.halo_verdict(11, 64, 64)                       # the worst tap missed the window by 10 rows
+    assert comp.halo_fallbacks == 1 and comp.halo_rows == int((64 + 11) * 1.25) + 4 and comp.halo_clean_frames == 0
+    halo = 96
+    comp.halo_rows = halo
+    for _ in range(3):
+        assert comp.halo_window_margin(halo) == halo and comp.halo_verdict(0, halo, halo)
+    assert comp.halo_window_margin(halo) == 72                     # the probe: three quarters, a multiple of 4
+    assert comp.halo_verdict(9, halo, 72) and comp.halo_rows == halo and comp.halo_clean_frames == 0   # 8 rows beyond 72: inside 96, no shrink
+    for _ in range(3):
+        assert comp.halo_verdict(0, halo, halo)
+    assert comp.halo_verdict(0, halo, comp.halo_window_margin(halo)) and comp.halo_rows == 72            # they fit: the halo shrinks
+    for _ in range(3):
+        assert comp.halo_verdict(0, 72, 72)
+    assert comp.halo_window_margin(72) == 52
+    assert not comp.halo_verdict(40, 72, 52) and comp.halo_fallbacks == 2 and comp.halo_rows == int((52 + 40) * 1.25) + 4   # 39 rows beyond 52 > 72
+    comp.halo_shrink_after = 0
+    comp.halo_clean_frames = 100
+    assert comp.halo_window_margin(64) == 64                       # (0: never probes)
 
 
 def test_halo_rows_between():

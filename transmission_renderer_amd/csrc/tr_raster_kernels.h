@@ -163,7 +163,9 @@ __device__ __forceinline__ uint32_t raster_setup_body(const tr_geometry_view g, 
                                                            const uint32_t* __restrict__ material_flags /* tr_dmat::flags or null */,
                                                            uint32_t flags_stride /* in words */, uint32_t t) {
 #pragma clang fp contract(off)
-    const uint32_t d = upper_index(tri_base, counts->num_draws, t);
+    // (8-ary: the draw of a triangle is the first of the set-up's eight or so dependent round trips, and the launch is nothing but
+    //  that chain — 960 triangles at 4K; tri_base[num_draws] is the total, above every t)
+    const uint32_t d = upper_index_wide(tri_base, counts->num_draws, t);
     const bool second = d >= counts->num_draws_first;
     const tr_draw_command c = second ? draws_b[d - counts->num_draws_first] : draws_a[d];
     const uint32_t local = t - tri_base[d], ntri = c.index_count / 3u;
@@ -593,7 +595,8 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_vie
     // this frame's tag, advanced by the rasteriser launch behind this one.  (An agent-scope load, past the scalar and vector
     // caches: replayed from a HIP graph, a plain or scalar load here returned the PREVIOUS replay's value — the look-back
     // then read that replay's words as current)
-    const uint32_t epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(scan_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    // (requested here, read where the look-back starts: made scalar at once, it is a memory round trip in front of everything else)
+    const uint32_t epoch_word = __hip_atomic_load(scan_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     TR_PICK_LAYER(two, blockIdx.y);
     if (W.capacity_triangles == 0u) return;
     __shared__ uint32_t lds_wave[4];
@@ -627,6 +630,7 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const tr_geometry_vie
         total += lds_wave[k];
     }
     if (wave == 0u) {
+        const uint32_t epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch_word);
         const uint32_t ex = scan_lookback(scan_status + (size_t)blockIdx.y * status_stride, blockIdx.x, total, epoch, lane);
         if (lane == 0u) lds_prefix = ex;
     }

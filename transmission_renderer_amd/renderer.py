@@ -347,6 +347,13 @@ class TransmissionRenderer:
         missed it (synchronises)."""
         return int(self._keep["tap_excess"].item()) if "tap_excess" in self._keep else 0
 
+    def tap_window_excess_word(self) -> torch.Tensor:
+        """The same word as a device tensor (int64, a copy enqueued on the current stream): nothing synchronises — for a
+        caller that judges the frame later (sharded.record_sharded(confirm="late"))."""
+        if "tap_excess" not in self._keep:
+            return torch.zeros(1, dtype=torch.int64, device=self.device)
+        return self._keep["tap_excess"].to(torch.int64)
+
     def shade_transmission(self, g: GBufferPlanes, uniforms: wire.Uniforms, push: wire.PushConstants,
                            pyramid: OpaquePyramid, hdr: torch.Tensor, rect=None):
         """"opaque transmissive objects": `fragment_transmission` (shader/src/lib.rs:37-162) over hdr (LOAD)."""

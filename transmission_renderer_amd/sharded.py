@@ -119,8 +119,52 @@ class Compositor:
 
     # ---- the halo exchange of the sharded full pipeline
     halo_rows = 0          # level-0 rows exchanged on either side of a band (0: not chosen yet -> the first frame gathers)
-    halo_fallbacks = 0     # frames that had to be redone with the full gather
+    halo_fallbacks = 0     # frames that had to be redone with the full gather (confirm="late": that were found inexact a frame later)
     halo_margin = 1.25     # growth factor over the largest excursion seen
+    halo_shrink_after = 32     # clean frames in a row before a frame PROBES a smaller halo (0: the halo never shrinks)
+    halo_shrink_factor = 0.75  # the probe: taps checked against this fraction of the halo while the whole halo is still exchanged
+    halo_clean_frames = 0
+    halo_inexact_frames = 0    # confirm="late" only: composited frames whose taps turned out to have left the halo
+    _halo_pending = None       # confirm="late": (device word, collective, halo, window margin) of the frame not yet judged
+
+    def halo_window_margin(self, halo: int) -> int:
+        """The rows around its band a rank's taps are checked against this frame: the halo, or — once in a while, after
+        halo_shrink_after clean frames — a smaller one, to find out whether the exchange can shrink again."""
+        if self.halo_shrink_after and self.halo_clean_frames >= self.halo_shrink_after:
+            probe = max(4, int(halo * self.halo_shrink_factor) // 4 * 4)
+            if probe < halo:
+                return probe
+        return halo
+
+    def halo_verdict(self, excess: int, halo: int, margin: int) -> bool:
+        """Book-keeping behind a frame's (all-rank) excess word — 0, or 1 + the rows by which the worst tap missed the window
+        of `margin` rows.  True: the frame's taps stayed inside the `halo` rows that were exchanged."""
+        if excess > 0 and excess - 1 > halo - margin:            # a tap left what was exchanged
+            self.halo_fallbacks += 1
+            self.halo_clean_frames = 0
+            self.halo_rows = int((margin + excess) * self.halo_margin) + 4
+            return False
+        if margin < halo:                                        # a probe frame
+            self.halo_clean_frames = 0
+            if excess == 0:
+                self.halo_rows = margin                          # (every tap fitted the smaller window)
+            return True
+        self.halo_clean_frames += 1
+        return True
+
+    def confirm_halo(self) -> bool:
+        """confirm="late": reads the previous frame's excess word — its collective was enqueued behind that frame's passes,
+        in front of its composite — and judges it.  True: that frame was exact (or there is none to judge)."""
+        if self._halo_pending is None:
+            return True
+        word, work, halo, margin = self._halo_pending
+        self._halo_pending = None
+        if work is not None:
+            work.wait()
+        ok = self.halo_verdict(int(word.item()), halo, margin)
+        if not ok:
+            self.halo_inexact_frames += 1
+        return ok
 
     def exchange_halo(self, level_rows: torch.Tensor, rows_per_rank: int, halo: int) -> None:
         """level_rows: (total_rows, W, C) contiguous, a whole pyramid level of which this rank has written its band; on
@@ -241,7 +285,7 @@ def record_sharded_strips(renderer, opaque, transmissive, uniforms, push, hdr, p
 
 
 def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid, compositor: Compositor,
-                   composite: bool = True, exchange: str = "allgather") -> None:
+                   composite: bool = True, exchange: str = "allgather", confirm: str = "now") -> None:
     """The hot-path slice of `record()` (src/main.rs:1969-2124) for one rank of a row-band sharded frame.
 
     `opaque` / `transmissive` are this rank's G-buffer tiles (origin_y = its first row); `hdr` holds
@@ -250,6 +294,13 @@ def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid,
     exchange = "allgather": all of level 0 to every rank, the chain replicated (round 3);
     exchange = "halo": border rows of levels 0 / 1 + all of level 2 (see the module docstring); needs frame sizes that are
     multiples of 4 (else it gathers) and falls back to the gather for a frame whose taps left the halo.
+    confirm = "now": the frame's excess word is read (a device drain and a small all-reduce) before the composite, and a
+    frame whose taps left the halo is redone — every frame returned is exact.  confirm = "late" (a renderer that hands out
+    the word on the device: tap_window_excess_word): the word's all-reduce is enqueued, the composite follows at once, and
+    the verdict is read when the NEXT frame starts (compositor.confirm_halo(); nothing waits): a frame whose taps left the
+    halo has then been composited as it was — compositor.halo_inexact_frames counts them — and the following frames
+    exchange more rows.  Either way a halo that has been wide enough for compositor.halo_shrink_after frames is probed:
+    one frame checks its taps against three quarters of it, and the exchange shrinks if they fit.
     """
     world, rank = compositor.world, compositor.rank
     fw, fh = int(push.framebuffer_size[0]), int(push.framebuffer_size[1])
@@ -258,33 +309,44 @@ def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid,
     mine = rect[3] > rect[1]     # (a band can be empty when the height is far from a multiple of world * 4)
     if mine:
         renderer.shade_opaque(opaque, uniforms, push, hdr, pyramid, rect)
+    compositor.confirm_halo()      # (confirm="late": the previous frame's verdict; it may widen the halo used below)
     halo = compositor.halo_rows
     use_halo = (world > 1 and exchange == "halo" and fw % 4 == 0 and fh % 4 == 0 and pyramid.levels >= 4
                 and 0 < halo and halo + rows < fh)     # (a halo that reaches every row is the gather)
     if use_halo:
         halo = min(-(-halo // 4) * 4, fh)
+        margin = compositor.halo_window_margin(halo)   # (the same on every rank: the counters move with all-rank verdicts)
+        late = confirm == "late" and hasattr(renderer, "tap_window_excess_word")
         renderer.generate_mips_band(pyramid, rect[1], rect[3])                       # levels 1, 2 of the band
         compositor.exchange_halo(pyramid.level(0), rows, halo)
         compositor.exchange_halo(pyramid.level(1), rows // 2, halo // 2)
         compositor.allgather_bands(pyramid.level(2), rows // 4)
         renderer.generate_mips_from(pyramid, 3)
+        excess, word = 0, None
         if mine:
-            renderer.set_tap_window(max(rect[1] - halo, 0), min(rect[3] + halo, fh))
+            renderer.set_tap_window(max(rect[1] - margin, 0), min(rect[3] + margin, fh))
             try:
                 renderer.shade_transmission(transmissive, uniforms, push, pyramid, hdr, rect)
             finally:
-                excess = renderer.tap_window_excess()
+                if late:
+                    word = renderer.tap_window_excess_word()     # (a device tensor: nothing is read here)
+                else:
+                    excess = renderer.tap_window_excess()
                 renderer.set_tap_window(0, 0)
-        else:
-            excess = 0
+        if late:
+            if word is None:
+                word = torch.zeros(1, dtype=torch.int64, device=renderer.device)
+            work = dist.all_reduce(word, op=dist.ReduceOp.MAX, group=compositor.group, async_op=True) if world > 1 else None
+            compositor._halo_pending = (word, work, halo, margin)
+            if composite:
+                compositor.allgather_rows(hdr)
+            return
         excess = compositor.max_over_ranks(excess)
-        if excess == 0:
+        if compositor.halo_verdict(excess, halo, margin):
             if composite:
                 compositor.allgather_rows(hdr)
             return
         # a tap left the halo: this frame is redone with the full gather, the next ones exchange what was needed
-        compositor.halo_fallbacks += 1
-        compositor.halo_rows = int((halo + excess) * compositor.halo_margin) + 4
     elif world > 1 and exchange == "halo" and halo == 0:
         compositor.halo_rows = max(rows // 4, 4)         # (first frame: gather, then start from a quarter band)
     if world > 1:
