@@ -1883,7 +1883,9 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
                 if constexpr (TRANSMISSIVE) {   // the last writer of the frame: streamed out past L2 (the opaque pass's
                     typedef uint32_t u2v __attribute__((ext_vector_type(2)));   // targets are re-read at once: cached)
                     __builtin_nontemporal_store(u2v{o.x, o.y}, reinterpret_cast<u2v*>(static_cast<char*>(W->hdr) + pix * 8u));
-                } else {
+                } else if (final_colour) {
+                    // (a pixel under a surviving transmissive fragment is written again by the frame's transmissive launch,
+                    //  which does not read the target there: only level 0 of the pyramid needs its opaque colour)
                     st<uint2>(W->hdr, pix * 8u, o);
                 }
                 if constexpr (VIS) {

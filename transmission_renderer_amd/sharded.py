@@ -316,7 +316,9 @@ def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid,
     if use_halo:
         halo = min(-(-halo // 4) * 4, fh)
         margin = compositor.halo_window_margin(halo)   # (the same on every rank: the counters move with all-rank verdicts)
-        late = confirm == "late" and hasattr(renderer, "tap_window_excess_word")
+        # (late: the word stays on the device — a host-side backend could only reduce it after reading it)
+        late = (confirm == "late" and hasattr(renderer, "tap_window_excess_word")
+                and (world == 1 or str(renderer.device) == "cpu" or dist.get_backend(compositor.group) != "gloo"))
         renderer.generate_mips_band(pyramid, rect[1], rect[3])                       # levels 1, 2 of the band
         compositor.exchange_halo(pyramid.level(0), rows, halo)
         compositor.exchange_halo(pyramid.level(1), rows // 2, halo // 2)
