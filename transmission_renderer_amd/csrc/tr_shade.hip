@@ -217,7 +217,7 @@ struct tr_context {
     uint64_t tables_generation = 0;
     struct stream_seen { hipStream_t stream; uint64_t generation; };
     std::vector<stream_seen> launch_streams;   // streams that launched since the last build, and the build they waited for
-    uint32_t vis_grid_rounds = 4;               // see persistent_grid (TR_VIS_ROUNDS in tools/ builds)
+    uint32_t vis_grid_rounds = 6;               // see persistent_grid (TR_VIS_ROUNDS in tools/ builds)
     uint32_t front_list_waves_per_cu = 48;      // the transmissive VIS launch's grid when it walks the list of covered tiles (TR_FRONT_LIST_WAVES in tools/ builds; 0: no list)
     uint32_t raster_wgs_per_cu = 6;             // raster_kernel's persistent grid: 4 -> 191 / 199 us (4K mesh / glTF demo frame), 6 -> 191 / 192,
                                                 // 8 -> 194 / 195, 12 -> 191 / 196, 16 -> 198 / 199 (TR_RASTER_WGS_PER_CU in tools/ builds)
@@ -560,7 +560,9 @@ tr_status fill_frame_params(const tr_context* ctx, const tr_gbuffer* g, const tr
 // (TR_BLOCKS_PER_XCD sweep, all shading launches of the frame): 1 -> 243.8 us, 2 -> 227.0, 4 -> 227.0, 7 -> 228.9,
 // 8 -> 232.1, 16 -> 247.0: a wave's start (kernarg loads, the sRGB table into LDS) is paid per wave, and a frame's covered
 // tiles are spread evenly over the stripes anyway.  (End of round 4, frame at 172 us: 2 and 3 -> 172.2, 4 -> 170.6, 5 -> 172.2;
-// glTF demo 176.0 / 173.9 / 173.6: 4.)  The synthetic G-buffer's plane launches keep 8 (§3.1 of DESIGN.md).
+// glTF demo 176.0 / 173.9 / 173.6: 4.  Round 5, background tiles written from constants, so that a wave's tiles differ tenfold
+// in cost: 2 / 3 / 4 / 5 / 6 / 7 / 8 / 12 / 16 -> 168.4 / 168.1 / 166.2 / 168.2 / 165.3 / 167.2 / 166.5 / 170.1 / 171.3 us, glTF demo 168.8 at 4,
+// 165.6 at 6, 8K 641 / 632: 6.)  The synthetic G-buffer's plane launches keep their own count (kGridRounds, §3.1 of DESIGN.md).
 uint32_t persistent_grid(const tr_context* ctx, uint32_t ntiles, bool vis = false) {
     const uint32_t per_xcd = (ntiles + 7u) / 8u;
     uint32_t bpx = vis ? ctx->blocks_per_xcd / kGridRounds * ctx->vis_grid_rounds : ctx->blocks_per_xcd;
