@@ -77,7 +77,9 @@ __device__ __forceinline__ void tile_phase() {
     __builtin_amdgcn_s_setprio(P);
 }
 constexpr uint32_t kFrontLists = 64u;      // sub-lists of the transmissive-covered tile list (tr_launch::front_list)
-constexpr uint32_t kStripeTileRows = 4u;   // VIS / textured launches: tile rows per XCD stripe (1 ... 8 measure the same)
+constexpr uint32_t kStripeTileRows = 1u;   // VIS / textured launches: tile rows per XCD stripe (round 4: 1 ... 8 measured the same; with background
+                                           // tiles written from constants 1 / 2 / 4 / 8 / 16 -> 4K mesh frame 163.3 / 163.6 / 164.8 / 167.5 / 172.8 us;
+                                           // fractions of a row are no better, and 15 tiles — every XCD the same columns — 173)
 constexpr uint32_t kParkedValues = 17u;    // full-class textured pixels: values parked in LDS, see shade_pixel_textured
 
 // ---------------------------------------------------------------- digested material (240 B)
