@@ -1303,7 +1303,10 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
             rl.tile_cover[layer] = ctx->d_tile_cover[layer];
             rl.enabled[layer] = ctx->max_triangles[layer] != 0u ? 1u : 0u;
         }
-        hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * ctx->raster_wgs_per_cu, 2), dim3(256), 0, stream, gv, fr, rl, at, epoch_word);
+        // (a wave prepares its items — search, record, block tests — whether it has one or twenty: a small frame's fewer items
+        //  go to fewer waves.  1080p mesh frame, 3 / 4 / 5 / 6 workgroups per CU: 86.3 / 85.5 / 88.3 / 88.7 us; 720p and 1440p flat)
+        const uint32_t raster_wgs = npix < 3000000u ? std::min(ctx->raster_wgs_per_cu, 4u) : ctx->raster_wgs_per_cu;
+        hipLaunchKernelGGL(raster_kernel, dim3(ctx->num_cus * raster_wgs, 2), dim3(256), 0, stream, gv, fr, rl, at, epoch_word);
     }
     if (resolve) {
         hipLaunchKernelGGL(raster_resolve_kernel, dim3((w + 63u) / 64u, (h + 3u) / 4u), dim3(256), 0, stream, fr, two,
