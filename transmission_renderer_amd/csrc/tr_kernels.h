@@ -1799,8 +1799,9 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             //  wait for EVERYTHING outstanding — the previous tile's store with them — before the next tile's first load)
             if constexpr (TEX == kTexNone && !VIS) asm volatile("" :: "v"(cur.cluster_x), "v"(cur.cluster_y_term));   // (the last two loads issued)
         }
-        // The next tile's plane loads are issued BEFORE this tile's store: memory operations complete in order, so a
-        // load behind the store could not be waited for without waiting for the store's acknowledgement as well.
+        // (There is no prefetch of the next tile in front of this tile's store — rounds 2, 4 and 5 built it three ways, planes
+        //  in registers, planes and visibility words in LDS: never faster, docs/TRIED_r05.md.  The next tile's first wait is
+        //  therefore also a wait for this store's acknowledgement: vector memory completes in order.)
         const uint32_t out_px = cur.px, out_py = cur.py;
         j += launder(L)->fp.j_step;
         if constexpr (VIS && !TRANSMISSIVE && sizeof(OutT) == 8) {
