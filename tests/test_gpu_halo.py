@@ -118,11 +118,18 @@ def test_tap_window_reports_the_excursion(renderer):
     _, y0, y1 = sharded.band_rows(h, 3, 1)
     r.set_tap_window(y0 - 16, y1 + 16)
     r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr, (0, y0, w, y1))
+    word = r.tap_window_excess_word()            # (the same word, left on the device: record_sharded(confirm="late") reduces it there)
     excess = r.tap_window_excess()
     assert 4 < excess < h, excess
+    assert word.dtype == torch.int64 and word.is_cuda and int(word.item()) == excess
     r.set_tap_window(0, h)
     r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, hdr, (0, y0, w, y1))
     assert r.tap_window_excess() == 0
+    # the compositor's verdict on the first launch's word: a fallback, the halo grows to what was needed + 25 %; the probe of a
+    # halo that has been wide enough: three quarters of it
+    comp = sharded.Compositor.__new__(sharded.Compositor)
+    comp.halo_rows = 16
+    assert not comp.halo_verdict(excess, 16, 16) and comp.halo_rows == int((16 + excess) * 1.25) + 4 and comp.halo_fallbacks == 1
     r.set_tap_window(0, 0)
 
 
