@@ -35,7 +35,10 @@ __device__ __forceinline__ bool tri_edges(const Rec& rec, float pxc, float pyc, 
     for (int i = 0; i < 3; ++i) {
         fv[i] = (rec.A[i] * pxc + rec.B[i] * pyc) + rec.C[i];
         const bool tie = rec.A[i] > 0.0f || (rec.A[i] == 0.0f && rec.B[i] > 0.0f);
-        inside &= fv[i] > 0.0f || (fv[i] == 0.0f && tie);
+        // (bitwise, not short-circuit: two compares and two mask operations per edge; the short-circuit form is compiled to a
+        //  compare under a saved exec mask per edge — six instructions, three of them exec writes)
+        const bool positive = fv[i] > 0.0f, on_edge = fv[i] == 0.0f;
+        inside = inside & (positive | (on_edge & tie));
     }
     return inside;
 }
