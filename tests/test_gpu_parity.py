@@ -86,7 +86,7 @@ def _display(frame16):
     return oracle.tonemap_frame(np.ascontiguousarray(frame16, dtype=np.float16), _TONEMAP)[1].astype(np.float64)
 
 
-def _check_against_oracles(got32, got16, o32, o64, o16_64, what, o16_32=None, t3_outliers=0):
+def _check_against_oracles(got32, got16, o32, o64, o16_64, what, o16_32=None, t3_documented=()):
     assert np.isfinite(got32).all(), what
     # P0: the presented frame against the pinned fp32 oracle's: plain RMSE, all pixels
     if o16_32 is None:
@@ -132,11 +132,13 @@ def _check_against_oracles(got32, got16, o32, o64, o16_64, what, o16_32=None, t3
     assert np.sqrt((e32[good][..., :3] ** 2).mean(axis=0)).max() <= 1e-4, (what, "T3")
     bad = ~good
     if bad.any():
-        gpu_off = np.abs(e64).max(axis=2)[bad]
-        # (t3_outliers: pixels allowed past this per-pixel clause — each still inside T1's 5e-3 bound above; 0 everywhere
-        #  but one scene, where the kernel is 1.8e-4 from fp64 on ONE highlight pixel of 49 152 and the fp32 oracle 6.5e-5)
-        assert int((gpu_off > noise[bad] + 1e-4).sum()) <= t3_outliers, (what, "T3 ill-conditioned pixels",
-                                                                       int((gpu_off > noise[bad] + 1e-4).sum()), float(gpu_off.max()))
+        gpu_off = np.abs(e64).max(axis=2)
+        # (t3_documented: pixels, by (row, column), that are past this per-pixel clause and documented where the caller says —
+        #  each still inside T1's 5e-3 bound above.  Empty everywhere but one scene: tests/test_gpu_textures.py,
+        #  test_the_documented_highlight_pixel.  A pixel past the clause that is not listed fails; a listed one that is not past it too.)
+        past = {(int(y), int(x)) for y, x in zip(*np.nonzero(bad & (gpu_off > noise + 1e-4)))}
+        assert past == set(t3_documented), (what, "T3 ill-conditioned pixels past the clause", sorted(past), "documented", sorted(t3_documented),
+                                            float(gpu_off[bad].max()))
 
 
 def _p1_against_pinned(got, o32, o64, what, covered=None, max_ill_fraction=5e-4):

@@ -149,6 +149,30 @@ def test_textured_opaque_pass_parity(renderer, ggx_lut, w, h, coverage, uv_scale
     _check_against_oracles(got32, got16, o32, o64, o16_64, f"textured opaque {w}x{h}")
 
 
+# The one pixel of the suite that is past T3's per-pixel clause ("on a pixel where the reference's own fp32 formulas are
+# ill-conditioned the kernel is no further from their fp64 evaluation than the fp32 oracle is, + 1e-4"): a specular highlight of
+# material 9 of the 256x192 usual-glTF-set scene — a dielectric (f0 a splat: the three channels are off by the same amount) whose
+# roughness, 0.797 x the metallic-roughness texture's sample, and normal, from the normal map through the cotangent frame of the
+# quad's view-vector differences, are both per-lane values.  Measured (tools/gpu_debug_t3.py; a Newton step on every
+# normalisation of that path leaves it where it is): kernel 1.84e-4 from fp64, fp32 oracle 6.5e-5 — of the scene's 497
+# ill-conditioned pixels the kernel is the closer one on 90 % (median ratio of the two distances 0.02), on this one 2.8 x further.
+_DOCUMENTED_HIGHLIGHT = {(256, 192): ((163, 165),)}
+
+
+def _the_documented_highlight_pixel(scene, got32, o32, o64):
+    (y, x), = _DOCUMENTED_HIGHLIGHT[(256, 192)]
+    assert int(scene["gbuffer"]["material_id"][y, x]) == 9
+    m = scene["materials"][9]
+    assert m.metallic_factor == 0.0 and m.textures.metallic_roughness != -1 and m.textures.normal_map != -1
+    norm = lambda a: np.abs((a[y, x, :3].astype(np.float64) - o64[y, x, :3]) / np.maximum(np.abs(o64[y, x, :3]), 1.0))   # noqa: E731
+    gpu, ref = norm(got32), norm(o32)
+    print(f"[parity] documented highlight pixel ({y}, {x}): kernel {got32[y, x, :3]} oracle32 {o32[y, x, :3]} oracle64 {o64[y, x, :3]}; "
+          f"normalised distance from fp64: kernel {gpu.max():.3e}, oracle32 {ref.max():.3e}")
+    assert 1.0e-4 < gpu.max() < 2.5e-4 and ref.max() < 1.0e-4          # what is documented: past the clause, a factor below T1's bound
+    d = got32[y, x, :3].astype(np.float64) - o64[y, x, :3]
+    assert np.ptp(d) < 2e-6 * np.abs(o64[y, x, :3]).max()               # the same amount in every channel: an achromatic specular term
+
+
 def _usual_gltf_set(scene):
     """Every textured material keeps its base-colour, metallic-roughness and normal-map slots only: the material set
     the full-class launch has a build of its own for (shade_kernel's TEX = 3: the other five factors stay scalar)."""
@@ -204,7 +228,10 @@ def test_usual_gltf_texture_set_build_parity(renderer, ggx_lut, w, h, nl, covera
                                             hdr_f32=base.astype(np.float64), nthreads=8, fp64=True)
     m32, mo32, mo64 = _masked(ok, got32, o32, o64)
     m16, mo16_64 = _masked(ok, got16, o16_64)
-    _check_against_oracles(m32, m16, mo32, mo64, mo16_64, f"usual glTF set, transmission {w}x{h}", t3_outliers=1)
+    _check_against_oracles(m32, m16, mo32, mo64, mo16_64, f"usual glTF set, transmission {w}x{h}",
+                           t3_documented=_DOCUMENTED_HIGHLIGHT.get((w, h), ()))
+    if (w, h) in _DOCUMENTED_HIGHLIGHT:
+        _the_documented_highlight_pixel(scene, got32, o32, o64)
     _, p32, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8)
     _, p64, _ = oracle.shade_opaque(b, scene["gbuffer"], nthreads=8, fp64=True)
     mop, mp32, mp64 = _masked(ok, gop, p32, p64)

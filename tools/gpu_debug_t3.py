@@ -1,54 +1,61 @@
-"""T3 of tests/test_gpu_parity.py on the usual-glTF-set scene, per library build: python tools/gpu_debug_t3.py lib.so ..."""
-import sys, os, subprocess, json
+#!/usr/bin/env python3
+"""Where is the one pixel tests/test_gpu_textures.py documents as past T3's per-pixel clause (_DOCUMENTED_HIGHLIGHT)?  Runs the 'usual glTF
+set' transmission scene of that test, lists every pixel whose distance from the fp64 oracle exceeds the fp32 oracle's own by
+more than 1e-4 (normalised), with its material, the values of the three evaluations and the per-light terms."""
+import os
+import sys
+
+import numpy as np
+import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CHILD = r'''
-import sys, os
-sys.path.insert(0, os.environ["TR_ROOT"])
-import numpy as np, torch, ctypes as C
-from transmission_renderer_amd import _lib
-_lib.LIB_PATH = os.environ["TR_AB_LIB"]
-class _Tolerant(C.CDLL):
-    def __getattr__(self, name):
-        try:
-            return super().__getattr__(name)
-        except AttributeError:
-            if name.startswith("tr_"):
-                return type("missing", (), {})()
-            raise
-C.CDLL = _Tolerant
-from transmission_renderer_amd import synthetic, wire
-from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer, load_ggx_lut
-from oracle import oracle
-w, h, nl = 256, 192, 2
-scene = synthetic.make_scene(w, h, num_point_lights=nl, coverage="full", textured=True)
-for m in scene["materials"]:
-    t = m.textures
-    t.emissive = t.transmission = t.thickness = t.specular = t.specular_colour = -1
-lut = load_ggx_lut()
-r = TransmissionRenderer(0); dev = r.device
-r.upload_materials(scene["materials"]); r.upload_lights(scene["lights"]); r.upload_ggx_lut(lut)
-r.upload_textures(scene["textures"])
-r.set_cluster_tables(torch.from_numpy(scene["cluster_counts"].view(np.int32)).to(dev), torch.from_numpy(scene["light_indices"].view(np.int32)).to(dev))
-g = GBufferPlanes.from_numpy(scene["gbuffer"], dev)
-b = oracle.SceneBinding(scene, lut)
-tex = oracle.new_pyramid(w, h, synthetic.make_opaque_mip0(w, h)); oracle.generate_mips(w, h, tex)
-pyr = OpaquePyramid(w, h, dev); pyr.texels.copy_(torch.from_numpy(tex).to(dev))
-base = np.full((h, w, 4), 0.125, dtype=np.float32)
-t32 = torch.from_numpy(base).to(dev)
-r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32); torch.cuda.synchronize()
-_, o32 = oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=base.astype(np.float16), hdr_f32=base.copy(), nthreads=8)
-_, o64 = oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=base.astype(np.float16), hdr_f32=base.astype(np.float64), nthreads=8, fp64=True)
-got = t32.cpu().numpy().astype(np.float64)
-ne = lambda a, c: (a - c) / np.maximum(np.abs(c), 1.0)
-noise = np.abs(ne(o32.astype(np.float64), o64)).max(axis=2)
-off = np.abs(ne(got, o64)).max(axis=2)
-bad = noise > 1e-5
-viol = bad & (off > noise + 1e-4)
-print(os.path.basename(os.environ["TR_AB_LIB"]), "ill", int(bad.sum()), "violations", int(viol.sum()), "max gpu off", off.max(), "rmse", np.sqrt((ne(got, o64) ** 2).mean()))
-for (y, x) in np.argwhere(viol)[:6]:
-    print("   ", y, x, "mat", scene["gbuffer"]["material_id"][y, x], "gpu", got[y, x, :3], "o32", o32[y, x, :3], "o64", o64[y, x, :3], "noise", noise[y, x], "off", off[y, x])
-'''
-for lib in sys.argv[1:]:
-    env = dict(os.environ, TR_ROOT=ROOT, TR_AB_LIB=os.path.abspath(lib))
-    out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
-    print(out.stdout[-3000:], out.stderr[-1500:] if out.returncode else "")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle  # noqa: E402
+from transmission_renderer_amd import synthetic, wire  # noqa: E402
+from transmission_renderer_amd.png import read_png_rgba8  # noqa: E402
+from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer  # noqa: E402
+import test_gpu_textures as T  # noqa: E402
+import test_gpu_parity as P  # noqa: E402
+
+lut = read_png_rgba8(os.path.join(ROOT, "transmission_renderer_amd", "assets", "ggx_lut.png"))
+r = TransmissionRenderer(0)
+r.upload_ggx_lut(lut)
+for (w, h, nl, coverage, uv_scale) in [(256, 192, 2, "full", 1.0), (250, 130, 3, "holes", 3.0)]:
+    scene = T._usual_gltf_set(T._textured_scene(w, h, nl, coverage, uv_scale))
+    T._upload_scene(r, scene)
+    r.upload_textures(scene["textures"])
+    g = GBufferPlanes.from_numpy(scene["gbuffer"], r.device)
+    b = oracle.SceneBinding(scene, lut)
+    tex = oracle.new_pyramid(w, h, synthetic.make_opaque_mip0(w, h))
+    oracle.generate_mips(w, h, tex)
+    pyr = OpaquePyramid(w, h, r.device)
+    pyr.texels.copy_(torch.from_numpy(tex).to(r.device))
+    base = np.full((h, w, 4), 0.125, dtype=np.float32)
+    t32 = torch.from_numpy(base).to(r.device)
+    r.shade_transmission(g, scene["uniforms"], scene["push"], pyr, t32)
+    torch.cuda.synchronize()
+    got32 = t32.cpu().numpy()
+    _, o32 = oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=base.astype(np.float16), hdr_f32=base.copy(), nthreads=8)
+    _, o64 = oracle.shade_transmission(b, scene["gbuffer"], tex, hdr_f16=base.astype(np.float16), hdr_f32=base.astype(np.float64), nthreads=8, fp64=True)
+    ok = ~T._degenerate(scene["materials"], scene["gbuffer"]["material_id"])
+    got32, o32, o64 = T._masked(ok, got32, o32, o64)
+    noise = np.abs(P._norm_err(o32, o64)).max(axis=2)
+    e64 = np.abs(P._norm_err(got32, o64)).max(axis=2)
+    bad = (noise > 1e-5) & (e64 > noise + 1e-4)
+    print(f"{w}x{h}: {int(bad.sum())} pixel(s) past T3's clause; ill-conditioned (noise > 1e-5): {int((noise > 1e-5).sum())}")
+    gb = scene["gbuffer"]
+    for (y, x) in zip(*np.nonzero(bad)):
+        mid = int(gb["material_id"][y, x])
+        m = scene["materials"][mid]
+        print(f"  pixel ({y},{x}) material {mid}: roughness_factor {m.roughness_factor:.4f} metallic {m.metallic_factor:.3f} ior {m.index_of_refraction:.3f} "
+              f"transmission {m.transmission_factor:.2f} textures: diffuse {m.textures.diffuse} mr {m.textures.metallic_roughness} normal {m.textures.normal_map}")
+        print(f"    gpu    {got32[y, x, :3]}\n    oracle32 {o32[y, x, :3]}\n    oracle64 {o64[y, x, :3]}")
+        print(f"    |gpu - o64| / max(|o64|,1) = {e64[y, x]:.3e}; |o32 - o64| = {noise[y, x]:.3e}; pos {gb['pos_depth'][y, x]} nrm {gb['nrm_scale'][y, x]} uv {gb['uv'][y, x]}")
+    # the distribution over the ill-conditioned set: how far the kernel and the fp32 oracle are from fp64
+    ill = noise > 1e-5
+    if ill.any():
+        ratio = e64[ill] / np.maximum(noise[ill], 1e-12)
+        print(f"  over the {int(ill.sum())} ill-conditioned pixels: gpu/oracle32 distance ratio median {np.median(ratio):.2f} p90 {np.percentile(ratio, 90):.2f} max {ratio.max():.2f}; "
+              f"gpu closer than oracle32 on {float((ratio < 1).mean()):.2f} of them")
+r.close()
