@@ -601,6 +601,71 @@ def test_record_frame_from_visibility_words_untextured(ggx_lut):
         assert (hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
 
 
+@pytest.mark.parametrize("case", ["everything culled", "no transmissive draw", "no opaque draw", "one sliver"])
+def test_record_frame_of_degenerate_scenes(ggx_lut, case):
+    """Frames whose layers are (nearly) empty — the camera looks away from every instance (each pixel is the clear colour: the
+    opaque launch's background path writes the target, pyramid levels 0 and 1 and the presented frame from constants), a
+    scene without a transmissive draw (the list of covered tiles stays empty), one without an opaque draw (the transmissive
+    launch shades over the clear colour), one long sliver triangle — through tr_record_frame twice, bit for bit the stepwise
+    sequence, the whole pyramid bit for bit tr_generate_mips on the frame's level 0."""
+    from transmission_renderer_amd.renderer import OpaquePyramid, TransmissionRenderer
+    S = meshes.Similarity
+    w, h = 514, 290
+    view = wire.default_camera()[1]
+    mb = meshes.ModelBuffers()
+    at = lambda x, y, z, s=1.0: S(np.array([x, y, z], np.float32), s)   # noqa: E731
+    if case == "everything culled":
+        mb.add_primitive(meshes.uv_sphere(1.0, 12, 6), 0, [(at(0.0, 3.0, 30.0), 1), (at(-60.0, 1.0, -3.0), 6)])
+        mb.add_primitive(meshes.box(0.5, 0.5, 0.5), 2, [(at(0.0, 80.0, -3.0), 4)])
+    elif case == "no transmissive draw":
+        mb.add_primitive(meshes.plane(8.0, 8.0, cells=4, uv_repeat=4.0), 0, [(at(0, 0.6, -3.0), 3)])
+        mb.add_primitive(meshes.uv_sphere(1.0, 16, 8), 0, [(at(-0.9, 1.6, -2.6, 0.55), 1), (at(1.1, 1.4, -3.4, 0.7), 6)])
+    elif case == "no opaque draw":
+        mb.add_primitive(meshes.uv_sphere(1.0, 16, 8), 2, [(at(0.15, 1.7, -1.9, 0.6), 4), (at(-1.6, 1.2, -3.9, 0.45), 10)])
+        mb.add_primitive(meshes.box(0.7, 0.4, 0.08), 2, [(at(1.3, 1.0, -2.2), 14)])
+    else:
+        # (about two pixels tall at its thick end and eight world units long; both windings: one of the two faces the camera)
+        sliver = meshes.Mesh(position=np.array([[-4.0, 1.0, -3.0], [4.0, 1.0, -3.0], [4.0, 1.03, -3.0]], np.float32),
+                             normal=np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (3, 1)),
+                             uv=np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0]], np.float32), index=np.array([0, 1, 2, 0, 2, 1], np.uint32))
+        mb.add_primitive(sliver, 0, [(at(0.0, 0.5, 0.0), 5)])
+        mb.add_primitive(sliver, 2, [(at(0.0, 0.0, 0.3), 4)])
+    geo = mb.finish()
+    r = TransmissionRenderer(0)
+    try:
+        r.upload_ggx_lut(ggx_lut)
+        sc = _scene(w, h, view)
+        q = wire.view_rotation_inverse(view)
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
+        r.upload_materials(sc["materials"])
+        r.upload_textures(sc["textures"])
+        r.upload_lights(sc["lights"])
+        r.upload_geometry(geo)
+        aabbs = r.write_cluster_data(sc["uniforms"], wire.inverse_perspective(w, h), (w, h))
+        work = r.new_frame_buffers(w, h)
+        for _ in range(2):
+            work["pyramid"].texels[w * h:].fill_(float("nan"))
+            hdr, ldr = r.record_frame(sc["uniforms"], sc["push"], culling, view, q, aabbs, work)
+            torch.cuda.synchronize()
+        want = _stepwise_frame(r, sc, culling, view, q, aabbs, w, h)
+        assert torch.equal(hdr.view(torch.int16), want.view(torch.int16)), case
+        assert torch.equal(ldr, r.tonemap(want)), case
+        covered = (hdr[..., :3].float().sum(dim=2) > 0).float().mean().item()
+        if case == "everything culled":
+            assert covered == 0.0 and torch.equal(hdr[..., 3].view(torch.int16), torch.full((h, w), 0x3C00, dtype=torch.int16, device=hdr.device))
+        else:
+            assert covered > (0.0005 if case == "one sliver" else 0.02), (case, covered)
+        ref = OpaquePyramid(w, h, r.device)
+        ref.level(0).copy_(work["pyramid"].level(0))
+        r.generate_mips(ref)
+        torch.cuda.synchronize()
+        for l in range(ref.levels):
+            assert torch.equal(work["pyramid"].level(l).view(torch.int16), ref.level(l).view(torch.int16)), (case, l)
+    finally:
+        r.close()
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("w,h", [(320, 180), (483, 273), (514, 290), (1920, 1080), (1024, 1024), (3840, 2160)])
 def test_record_frame_leaves_the_whole_opaque_pyramid(ggx_lut, w, h):
     """The pyramid a recorded frame leaves behind — level 1 written by the opaque launch itself from its wave tiles' quads when
