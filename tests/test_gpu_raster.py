@@ -601,16 +601,18 @@ def test_record_frame_from_visibility_words_untextured(ggx_lut):
         assert (hdr[..., :3].float().sum(dim=2) > 0).float().mean().item() > 0.2
 
 
-@pytest.mark.parametrize("case", ["everything culled", "no transmissive draw", "no opaque draw", "one sliver"])
-def test_record_frame_of_degenerate_scenes(ggx_lut, case):
+@pytest.mark.parametrize("case,w,h", [("everything culled", 514, 290), ("no transmissive draw", 514, 290), ("no opaque draw", 514, 290),
+                                      ("one sliver", 514, 290), ("everything culled", 3442, 1442), ("one sliver", 3442, 1442)])
+def test_record_frame_of_degenerate_scenes(ggx_lut, case, w, h):
     """Frames whose layers are (nearly) empty — the camera looks away from every instance (each pixel is the clear colour: the
     opaque launch's background path writes the target, pyramid levels 0 and 1 and the presented frame from constants), a
     scene without a transmissive draw (the list of covered tiles stays empty), one without an opaque draw (the transmissive
     launch shades over the clear colour), one long sliver triangle — through tr_record_frame twice, bit for bit the stepwise
-    sequence, the whole pyramid bit for bit tr_generate_mips on the frame's level 0."""
+    sequence, the whole pyramid bit for bit tr_generate_mips on the frame's level 0.  3442x1442: a frame large enough for a wave to
+    meet several background tiles (above ~3 Mpixels) whose width is no multiple of 16 and whose height no multiple of 4 — the lanes
+    that were outside the rect on a wave's first background tile must present the clear texel, not 0, on its later ones."""
     from transmission_renderer_amd.renderer import OpaquePyramid, TransmissionRenderer
     S = meshes.Similarity
-    w, h = 514, 290
     view = wire.default_camera()[1]
     mb = meshes.ModelBuffers()
     at = lambda x, y, z, s=1.0: S(np.array([x, y, z], np.float32), s)   # noqa: E731

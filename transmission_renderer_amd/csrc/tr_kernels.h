@@ -1813,22 +1813,23 @@ __global__ __launch_bounds__(64) TR_WAVES_ATTR void shade_kernel(const tr_launch
             if (ballot(active) == 0ull && cur.cover_front == 0u) {
                 claunch* W = launder(L);
                 const uint2 clear = uint2{0x00000000u, 0x3C000000u};   // RGBA16F (0, 0, 0, 1), src/main.rs:1592-1601
+                // (the presented clear texel is evaluated by the WHOLE wave, ahead of the divergent `inside`: evaluated under it,
+                //  the lanes outside the rect on the wave's first background tile kept 0 and presented 0 on every later tile —
+                //  frames whose width is no multiple of 16 or whose height no multiple of 4, from about 3 Mpixels up)
+                if (W->present != nullptr && !have_clear_present) {
+                    const tr_tonemap_params pp = {W->present_params.a, W->present_params.b, W->present_params.c, W->present_params.d,
+                                                  W->present_params.crosstalk, W->present_params.saturation, W->present_params.cross_saturation};
+                    clear_present = (uint32_t)__builtin_amdgcn_readfirstlane((int)tonemap_pixel(clear.x, clear.y, pp, W->present_e1, W->present_bgra));
+                    have_clear_present = true;
+                }
                 if (inside) {
                     const uint32_t pix = mad24(out_py, W->fp.width, out_px);
                     st<uint2>(W->hdr, pix * 8u, clear);
                     if (W->mip0) st<uint2>(W->mip0, pix * 8u, clear);
                     if (W->mip1 != nullptr && (lane_here() & 17u) == 0u)
                         st<uint2>(W->mip1, mad24(out_py >> 1, W->fp.width >> 1, out_px >> 1) * 8u, clear);
-                    if (W->present != nullptr) {
-                        if (!have_clear_present) {
-                            const tr_tonemap_params pp = {W->present_params.a, W->present_params.b, W->present_params.c, W->present_params.d,
-                                                          W->present_params.crosstalk, W->present_params.saturation, W->present_params.cross_saturation};
-                            clear_present = (uint32_t)__builtin_amdgcn_readfirstlane((int)tonemap_pixel(clear.x, clear.y, pp, W->present_e1, W->present_bgra));
-                        }
-                        st<uint32_t>(W->present, pix * 4u, clear_present);
-                    }
+                    if (W->present != nullptr) st<uint32_t>(W->present, pix * 4u, clear_present);
                 }
-                have_clear_present = have_clear_present || launder(L)->present != nullptr;
                 continue;
             }
         }

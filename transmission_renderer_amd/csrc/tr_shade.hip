@@ -11,6 +11,7 @@
 #define TR_PROBE_GRID(bpx)
 #endif
 #include "tr_kernels.h"
+#include "tr_lc_kernels.h"
 #include "tr_cluster_kernels.h"
 #include "tr_geometry_kernels.h"
 #include "tr_raster_kernels.h"
@@ -96,6 +97,7 @@ struct tr_context {
     int device = 0;
     int32_t last_hip_error = 0;
     uint32_t blocks_per_xcd = 1024;  // (CUs / 8) * resident blocks per CU * kGridRounds, set at context creation
+    uint32_t lc_wgs_per_cu = 0;      // > 0: the untextured transmissive plane pass runs as loader / consumer workgroups (tr_lc_kernels.h)
 
     // materials
     tr_material_info* d_materials_raw = nullptr;
@@ -739,6 +741,9 @@ tr_status tr_context_create(int32_t device_ordinal, tr_context** out_ctx) {
         }
 #ifdef TR_TUNING_ENV   // tools/build_variant.py builds only (build_ab/): the product reads nothing from its caller's environment
         if (const char* e = std::getenv("TR_BLOCKS_PER_XCD")) ctx->blocks_per_xcd = (uint32_t)std::atoi(e);
+#ifndef TR_LC_DISABLE   // (an A/B's base build ignores the switch its siblings read)
+        if (const char* e = std::getenv("TR_LC")) ctx->lc_wgs_per_cu = (uint32_t)std::max(0, std::atoi(e));
+#endif
         if (const char* e = std::getenv("TR_VIS_ROUNDS")) ctx->vis_grid_rounds = (uint32_t)std::max(1, std::atoi(e));
         if (const char* e = std::getenv("TR_FRONT_LIST_WAVES")) ctx->front_list_waves_per_cu = (uint32_t)std::max(0, std::atoi(e));
         if (const char* e = std::getenv("TR_RASTER_WGS_PER_CU")) ctx->raster_wgs_per_cu = (uint32_t)std::max(1, std::atoi(e));
@@ -1624,6 +1629,12 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
         const bool half = format == TR_FORMAT_RGBA16F;
         if (ctx->any_textured) {
             launch_textured<true>(ctx, L, half, grid, block, stream);
+        } else if (ctx->lc_wgs_per_cu != 0u && !L.vis && !L.tile_cover) {
+            // loader / consumer workgroups (tr_lc_kernels.h): G persistent workgroups per XCD
+            L.fp.j_step = std::max(1u, ctx->num_cus / 8u * ctx->lc_wgs_per_cu);
+            const dim3 lc_grid(8u * L.fp.j_step), lc_block(kLcWaves * 64u);
+            if (half) hipLaunchKernelGGL(shade_lc_kernel<uint2>, lc_grid, lc_block, 0, stream, L);
+            else hipLaunchKernelGGL(shade_lc_kernel<float4>, lc_grid, lc_block, 0, stream, L);
         } else {
             launch_shade<true, kTexNone>(L, half, grid, block, stream);
         }
