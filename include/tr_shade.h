@@ -287,6 +287,13 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
 
 /* lights[] storage buffer (set 2 binding 0; src/main.rs:450-496). Host pointer. */
 tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_t count, void* stream);
+/* Rewrites lights [first, first + count) of the uploaded array in place — what the reference does per frame to its two
+ * rotating spotlights through a mapped buffer (`light_buffers.lights.write_mapped`, src/main.rs:1244-1256).  Host pointer,
+ * read before the call returns; the records travel inside kernel arguments (TR_UPDATE_MAX_BYTES per launch), so the call
+ * allocates nothing, copies nothing from pageable memory and waits for nothing: it is ordered on `stream` like a launch.
+ * The range must lie inside the last tr_upload_lights. */
+#define TR_UPDATE_MAX_BYTES 3072u
+tr_status tr_update_lights(tr_context* ctx, uint32_t first, uint32_t count, const tr_light* lights_host, void* stream);
 
 /* cluster_light_counts / light_indices (set 2 bindings 1,2; src/main.rs:485-496):
  * device pointers, `num_clusters_total` u32 counts and num_clusters_total*128 u32
@@ -355,6 +362,11 @@ typedef struct tr_geometry_desc {
     uint32_t num_instances;
 } tr_geometry_desc;
 tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* geometry_host, void* stream);
+/* Rewrites instances [first, first + count) of the uploaded geometry in place — the reference's per-frame
+ * `model_buffers.instances.write_mapped` of the rotating model (src/main.rs:1258-1261, 1316-1322).  Every record keeps its
+ * primitive_id (TR_ERR_INVALID_ARGUMENT otherwise: the draw streams and the rasteriser's work buffers were sized from the
+ * per-primitive instance ranges); nothing is re-allocated or re-sized.  Same transport and ordering as tr_update_lights. */
+tr_status tr_update_instances(tr_context* ctx, uint32_t first, uint32_t count, const tr_instance* instances_host, void* stream);
 
 /* One writable TGB-v1 layer covering the whole frame (push->framebuffer_size): device pointers.  Where a pixel has no
  * fragment only material_id (= TR_NOT_COVERED) is written; the other planes keep whatever they held. */
@@ -421,6 +433,15 @@ tr_status tr_assign_lights_to_clusters(tr_context* ctx, const float view_matrix[
 tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* gbuffer, const tr_uniforms* uniforms,
                           const tr_push_constants* push, void* hdr_out, tr_format format,
                           void* opaque_mip0_out, tr_rect rect, void* stream);
+/* The same pass writing INTO THE PYRAMID: level 0 as above and — when the target is RGBA16F, both frame sizes are even and
+ * the rect lies on even pixels — level 1 as well, from the 2x2 quads of the values the pass stores (a LINEAR blit of an
+ * even-sized level is the box of its rounded texels: bit for bit what tr_generate_mips would write), so that the chain
+ * never reads level 0 back (66 of its 88 MB at 4K).  *next_level_out = the level to continue from:
+ * tr_generate_mips_from(ctx, pyramid, *next_level_out, stream) completes the pyramid (2, or 1 when level 1 was not written).
+ * `pyramid` must have the frame's size (push->framebuffer_size). */
+tr_status tr_shade_opaque_pyramid(tr_context* ctx, const tr_gbuffer* gbuffer, const tr_uniforms* uniforms,
+                                  const tr_push_constants* push, void* hdr_out, tr_format format,
+                                  const tr_pyramid* pyramid, tr_rect rect, uint32_t* next_level_out, void* stream);
 
 /* "opaque framebuffer mipchain": generate_mips (src/main.rs:2046-2064): levels 1.. from level 0,
  * each level a LINEAR blit of the previous one, fp32 accumulate, RTNE store to RGBA16F. */
@@ -600,6 +621,9 @@ tr_status tr_comm_from_nccl(void* nccl_comm, uint32_t nranks, uint32_t rank, tr_
 tr_status tr_comm_destroy(tr_comm* comm);
 /* ncclResult_t of the last failing RCCL call on this communicator (0 if none; -1: RCCL could not be loaded). */
 int32_t   tr_comm_last_error(const tr_comm* comm);
+/* What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): a host that wants to be sure its
+ * composite runs over RCCL — and over how many ranks — asks here instead of trusting its own book-keeping. */
+tr_status tr_comm_query(tr_comm* comm, uint32_t* nranks_out, uint32_t* rank_out);
 /* The composite (and the mid-frame level-0 exchange): `frame_dev` holds nranks * rows_per_rank rows of `width`
  * pixels of `format`; this rank has written band `rank` (rows rank * rows_per_rank ...); on return (stream order)
  * every band is everywhere.  In place: ncclAllGather(sendbuff = recvbuff + rank * band_bytes).  Asynchronous on

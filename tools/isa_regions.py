@@ -60,19 +60,21 @@ def regions_of(path):
                  ("pyramid+lut", r"^struct tap_pair"), ("digest", r"^__device__ __forceinline__ void lut_rows"),
                  ("cluster_lookup", r"^constexpr uint32_t kNoCluster"), ("pixel:frame", r"^__device__ __forceinline__ f3 shade_pixel\("),
                  ("pixel:taps", r"auto issue_taps = "), ("pixel:sun", r"auto lights_phase = "), ("pixel:punctual", r"auto punctual = "),
-                 ("pixel:finish", r"auto finish = "), ("pixel:tail", r"auto tail = "), ("textured_front_end", r"^struct quad_derivs"),
-                 ("lite_front_end", r"f3 shade_pixel_lite\("), ("kernel:prologue", r"^#ifndef TR_PLANES_NT_MASK$"),
+                 ("pixel:tail", r"auto tail = "), ("textured_front_end", r"^struct quad_derivs"),
+                 ("lite_front_end", r"f3 shade_pixel_lite\("), ("kernel:prologue", r"^constexpr uint32_t planes_nt_mask"),
                  ("kernel:fetch", r"auto fetch = "), ("kernel:vis_fetch", r"if constexpr \(VIS\) \{$"), ("kernel:plane_fetch", r"t.mat = ld_plane<uint32_t"),
                  ("kernel:loop", r"const uint32_t wave_tiles = "), ("kernel:quad_derivs", r"quad_derivs qd;"),
                  ("kernel:material_loop", r"^            while \(todo\) \{"), ("kernel:store", r"const uint32_t out_px = cur.px"),
-                 ("kernel:vis_zero", r"the last reader of a visibility word leaves it zeroed"),
+                 ("kernel:vis_zero", r"the reader of a visibility word leaves it zeroed"),
                  ("kernel:mip1", r"Level 1 of the opaque pyramid straight from"), ("kernel:write", r"if \(write && "),
-                 ("other_kernels", r"^struct tr_classify_params")]
+                 ("other_kernels", r"^__global__ __launch_bounds__\(256\) void depth_slice_kernel")]
         for nm, pat in marks:
             for i, l in enumerate(src):
                 if re.search(pat, l):
                     table.append((i + 1, nm))
                     break
+            else:   # (a marker that is not found would silently charge its instructions to the region in front of it)
+                raise SystemExit(f"tools/isa_regions.py: source anchor of region {nm!r} not found in {name}: {pat!r}")
         table.sort()
     return table
 

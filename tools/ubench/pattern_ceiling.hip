@@ -1,0 +1,246 @@
+// pattern_ceiling.hip — what MI355X can move in the ACCESS PATTERN of the 4K transmissive plane pass when nothing else competes:
+// per 16x4 wave tile two non-temporal dwordx4 plane rows and a dword id row (36 B/px streamed once), T scattered 16-byte "taps"
+// per pixel into an 88 MB RGBA16F pyramid at a bounded displacement from the pixel (the refraction scatter: level 0 / 1 texel
+// pairs, two rows each), one 16-byte LUT-line load from a 4 MB table, an 8-byte non-temporal store per pixel; one-wave
+// workgroups on the pass's own tile numbering (XCD bands, wave slot w takes tiles w, w + W, ...), W waves per SIMD chosen
+// by an LDS allocation.  No shading arithmetic: a tile's loads are issued together, waited for once, folded with a few adds
+// into the stored value (so that nothing is eliminated) — the least instruction stream that makes the requests.
+//
+// Reported per configuration: us per frame, TB/s on the 52 B/px the pass is priced on, the mean time a tile's loads are
+// outstanding (s_memtime around the wait, converted with the measured tick rate), and Little's law read the other way:
+//   bytes in flight per CU = (read bytes per frame / 256 CUs) / (frame time) x latency
+// — the number the memory side sustains per CU for THIS pattern.  The last rows repeat the 8-wave measurement with a block
+// of N dependent fma per pixel between the wait and the store (the arithmetic a real pass must overlap with the stream).
+//
+// Build + run:  hipcc --offload-arch=gfx950 -O3 tools/ubench/pattern_ceiling.hip -o /tmp/pattern_ceiling && /tmp/pattern_ceiling
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+
+struct params {
+    const f4v* pos; const f4v* nrm; const uint32_t* ids; const u4v* pyr; const f4v* lut; u2v* out;
+    uint32_t width, height, tiles_x, ntiles, j_step, taps, fma, scatter;   // scatter: largest tap displacement in pixels
+    uint32_t tap_mode;     // 0: texel-aligned 16-byte pairs (the pass); 1: the same pairs forced to 16-byte alignment; 2: 8-byte loads, one texel each
+    uint32_t tile_begin;   // first block tile of this launch's row band (two bands on two streams: bench.py's step)
+    unsigned long long* wait_ticks; unsigned long long* waits;
+};
+
+template <int LDS_BYTES>
+__global__ __launch_bounds__(64) void pattern_kernel(const params p) {
+    __shared__ unsigned char occupy[LDS_BYTES];      // limits the waves a CU holds
+    if (p.width == 0xFFFFFFFFu) occupy[threadIdx.x] = 1;
+    const uint32_t lane = threadIdx.x, lx = lane & 15u, ly = lane >> 4;
+    const uint32_t xcd = blockIdx.x & 7u, per = p.ntiles >> 3, rem = p.ntiles & 7u;
+    const uint32_t band_start = xcd * per + (xcd < rem ? xcd : rem), band_len = per + (xcd < rem ? 1u : 0u);
+    unsigned long long waited = 0, n = 0;
+    for (uint32_t j = blockIdx.x >> 3; j < band_len * 4u; j += p.j_step) {
+        const uint32_t tile = p.tile_begin + band_start + (j >> 2), tyi = tile / p.tiles_x, txi = (tile - tyi * p.tiles_x) * 4u + (j & 3u);
+        const uint32_t px = min(txi * 16u + lx, p.width - 1u), py = min(tyi * 4u + ly, p.height - 1u);
+        const uint32_t pix = py * p.width + px;
+        const f4v a = __builtin_nontemporal_load(p.pos + pix);
+        const f4v b = __builtin_nontemporal_load(p.nrm + pix);
+        const uint32_t id = p.ids[pix];
+        // the taps: displaced from the pixel by a field that varies smoothly over the screen (neighbouring pixels refract
+        // alike: adjacent lanes fetch adjacent texels, as in the pass; `scatter` is the field's amplitude in pixels) and jumps
+        // at "material" borders every 96 pixels; pairs of rows like the sampler's (row, row + 1) of two levels
+        uint32_t h = pix * 2654435761u;
+        const float fx = (float)px, fy = (float)py, amp = (float)p.scatter * (0.4f + 0.6f * (float)(((px / 96u) * 7u + (py / 96u) * 3u) % 5u) * 0.25f);
+        const int sdx = (int)(amp * __sinf(fx * 0.013f + fy * 0.007f)), sdy = (int)(amp * __cosf(fx * 0.009f - fy * 0.011f));
+        u4v t[8];
+        const uint32_t taps = p.taps;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (k < taps) {
+                const int dx = sdx, dy = sdy;
+                const uint32_t level = k >> 1;    // taps 0,1: level 0 rows y, y + 1; taps 2,3: level 1
+                const uint32_t lw = p.width >> level, lh = p.height >> level, base = level ? p.width * p.height : 0u;
+                const uint32_t tx = (uint32_t)min(max((int)(px >> level) + (dx >> level), 0), (int)lw - 2);
+                const uint32_t tyy = (uint32_t)min(max((int)(py >> level) + (dy >> level) + (int)(k & 1u), 0), (int)lh - 1);
+                const char* at = reinterpret_cast<const char*>(p.pyr) + ((size_t)base + (size_t)tyy * lw + (p.tap_mode == 1u ? (tx & ~1u) : tx)) * 8u;
+                if (p.tap_mode == 2u) {
+                    const u2v lo = *reinterpret_cast<const u2v*>(at), hi = *reinterpret_cast<const u2v*>(at + 8);
+                    t[k] = u4v{lo.x, lo.y, hi.x, hi.y};
+                } else {
+                    typedef u4v u4v_a8 __attribute__((aligned(8)));
+                    t[k] = *reinterpret_cast<const u4v_a8*>(at);
+                }
+            } else {
+                t[k] = u4v{0, 0, 0, 0};
+            }
+        }
+        // the LUT line: 258 entries of 16 bytes per material, indexed by n.v — smooth over the screen like the taps
+        const f4v line = taps ? p.lut[(id & 15u) * 260u + ((uint32_t)(128.0f + 120.0f * __sinf(fx * 0.011f - fy * 0.005f)) & 255u)] : f4v{0.f, 0.f, 0.f, 0.f};
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        waited += __builtin_amdgcn_s_memtime() - t0;
+        ++n;
+        float x = a.x + b.x + line.x, y = a.y + b.y + line.y, z = a.z + b.z + a.w + b.w + line.z + line.w;
+        uint32_t fold = id;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) fold += t[k].x ^ t[k].y ^ t[k].z ^ t[k].w;
+        for (uint32_t k = 0; k < p.fma; ++k) {   // dependent chains, three per pixel
+            x = __builtin_fmaf(x, 1.0001f, y);
+            y = __builtin_fmaf(y, 0.9999f, z);
+            z = __builtin_fmaf(z, 1.0002f, x);
+        }
+        __builtin_nontemporal_store(u2v{__float_as_uint(x + y) ^ fold, __float_as_uint(z)}, p.out + (size_t)(tyi * 4u + ly) * p.width + txi * 16u + lx);
+    }
+    if (lane == 0) {
+        atomicAdd(p.wait_ticks + (blockIdx.x & 255u), waited);
+        atomicAdd(p.waits + (blockIdx.x & 255u), n);
+    }
+}
+
+template <int LDS_BYTES>
+static void run(const char* name, params p, int waves_per_simd, int sets, void** pos, void** nrm, void** ids, void** pyr, void** out, double ticks_per_us,
+                int bands = 1) {
+    static hipStream_t streams[2] = {nullptr, nullptr};
+    if (!streams[1]) {   // (two streams of their own: the legacy default stream would serialise with the other one)
+        CHECK(hipStreamCreateWithFlags(&streams[0], hipStreamNonBlocking));
+        CHECK(hipStreamCreateWithFlags(&streams[1], hipStreamNonBlocking));
+    }
+    const uint32_t all_tiles = p.ntiles;
+    // resident waves: 256 CUs x 4 SIMDs x waves; the grid is four rounds of them, like the pass's
+    const uint32_t resident = 256u * 4u * (uint32_t)waves_per_simd;
+    const uint32_t grid = resident * 4u;
+    p.j_step = grid >> 3;
+    CHECK(hipMemset(p.wait_ticks, 0, 256 * 8));
+    CHECK(hipMemset(p.waits, 0, 256 * 8));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const int warm = 1500, K = 200;    // (the clocks ramp over the first ~10 ms of load: ~0.15 s of launches before the timed ones)
+    for (int k = 0; k < warm + K; ++k) {
+        if (k == warm) {
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemset(p.wait_ticks, 0, 256 * 8));
+            CHECK(hipMemset(p.waits, 0, 256 * 8));
+            CHECK(hipEventRecord(e0, streams[0]));
+        }
+        const int s = k % sets;      // cold inputs: every launch another set (> 1.2 GB rotates through the 256 MiB cache)
+        p.pos = (const f4v*)pos[s]; p.nrm = (const f4v*)nrm[s]; p.ids = (const uint32_t*)ids[s]; p.pyr = (const u4v*)pyr[s]; p.out = (u2v*)out[s];
+        for (int b = 0; b < bands; ++b) {   // (no join between frames: band b of frame k + 1 follows band b of frame k on its stream)
+            params q = p;
+            const uint32_t rows = all_tiles / p.tiles_x, r0 = rows * b / bands, r1 = rows * (b + 1) / bands;
+            q.tile_begin = r0 * p.tiles_x;
+            q.ntiles = (r1 - r0) * p.tiles_x;
+            q.j_step = (grid / bands) >> 3;      // (each band a grid of its own share of the wave slots' rounds)
+            hipLaunchKernelGGL(pattern_kernel<LDS_BYTES>, dim3(grid / bands), dim3(64), 0, streams[b], q);
+        }
+    }
+    if (bands > 1) {
+        hipEvent_t j;
+        CHECK(hipEventCreate(&j));
+        CHECK(hipEventRecord(j, streams[1]));
+        CHECK(hipStreamWaitEvent(streams[0], j, 0));
+    }
+    CHECK(hipEventRecord(e1, streams[0]));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / K;
+    std::vector<unsigned long long> wt(256), wn(256);
+    CHECK(hipMemcpy(wt.data(), p.wait_ticks, 256 * 8, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(wn.data(), p.waits, 256 * 8, hipMemcpyDeviceToHost));
+    double ticks = 0, cnt = 0;
+    for (int i = 0; i < 256; ++i) { ticks += (double)wt[i]; cnt += (double)wn[i]; }
+    const double px = (double)p.width * p.height;
+    const double read_bytes = px * (36.0 + 8.0 * (p.taps ? 1.0 : 0.0));     // planes + one level-0-equivalent texel per pixel (the pass's figure)
+    const double all_bytes = read_bytes + px * 8.0;
+    const double lat_us = ticks / cnt / ticks_per_us;
+    const double in_flight_per_cu = read_bytes / 256.0 / us * lat_us;
+    printf("%-34s %7.1f us  %5.2f TB/s on %.0f B/px  wait %6.0f ticks = %5.2f us  reads in flight per CU %6.1f KB\n", name, us,
+           all_bytes / us / 1e6, all_bytes / px, ticks / cnt, lat_us, in_flight_per_cu / 1024.0);
+}
+
+__global__ void tick_kernel(unsigned long long* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float x = threadIdx.x;
+    for (int i = 0; i < 2000000; ++i) x = __builtin_fmaf(x, 1.0000001f, 1e-9f);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; out[2] = (unsigned long long)x; }
+}
+
+int main() {
+    const uint32_t W = 3840, H = 2160;
+    const size_t px = (size_t)W * H;
+    const int sets = 4;
+    void *pos[sets], *nrm[sets], *ids[sets], *pyr[sets], *out[sets];
+    const size_t pyr_bytes = px * 8 * 4 / 3 + 4096;
+    for (int s = 0; s < sets; ++s) {
+        CHECK(hipMalloc(&pos[s], px * 16)); CHECK(hipMalloc(&nrm[s], px * 16)); CHECK(hipMalloc(&ids[s], px * 4));
+        CHECK(hipMalloc(&pyr[s], pyr_bytes)); CHECK(hipMalloc(&out[s], px * 8));
+        CHECK(hipMemset(pos[s], 0x11, px * 16)); CHECK(hipMemset(nrm[s], 0x22, px * 16)); CHECK(hipMemset(ids[s], 0x03, px * 4));
+        CHECK(hipMemset(pyr[s], 0x3c, pyr_bytes));
+    }
+    params p{};
+    void* lut;
+    CHECK(hipMalloc(&lut, 16 * 16384 * 16));
+    CHECK(hipMemset(lut, 0, 16 * 16384 * 16));
+    p.lut = (const f4v*)lut;
+    CHECK(hipMalloc(&p.wait_ticks, 256 * 8));
+    CHECK(hipMalloc(&p.waits, 256 * 8));
+    p.width = W; p.height = H; p.tiles_x = (W + 63) / 64; p.ntiles = p.tiles_x * ((H + 3) / 4);
+    // s_memtime ticks per microsecond (against the constant 100 MHz clock)
+    unsigned long long* d; unsigned long long h[3];
+    CHECK(hipMalloc(&d, 24));
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, 0, d);
+    CHECK(hipMemcpy(h, d, 24, hipMemcpyDeviceToHost));
+    const double ticks_per_us = (double)h[0] / ((double)h[1] / 100.0);
+    printf("s_memtime: %.1f ticks per us\n", ticks_per_us);
+
+    p.scatter = 48; p.fma = 0;
+    printf("-- planes + store only (the streaming skeleton)\n");
+    p.taps = 0;
+    run<160 * 1024 / 4>("1 wave per SIMD", p, 1, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<160 * 1024 / 8>("2 waves per SIMD", p, 2, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<160 * 1024 / 16>("4 waves per SIMD", p, 4, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024>("8 waves per SIMD", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    printf("-- the pass's pattern: planes + 4 scattered 16-byte taps + LUT line + store\n");
+    p.taps = 4;
+    run<160 * 1024 / 4>("1 wave per SIMD", p, 1, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<160 * 1024 / 8>("2 waves per SIMD", p, 2, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<160 * 1024 / 16>("4 waves per SIMD", p, 4, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024>("8 waves per SIMD", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    for (uint32_t sc : {0u, 8u, 200u}) {
+        p.scatter = sc;
+        char nm[64];
+        snprintf(nm, sizeof nm, "8 waves, tap scatter +-%u px", sc);
+        run<1024>(nm, p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    }
+    p.scatter = 48;
+    printf("-- what in a tap costs: 8 waves per SIMD, one launch per frame\n");
+    p.tap_mode = 1;
+    run<1024>("pairs forced to 16-byte alignment", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    p.tap_mode = 2;
+    run<1024>("two 8-byte loads per pair", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    p.tap_mode = 0;
+    p.taps = 2;
+    run<1024>("level 0 taps only (2 of 4)", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    p.taps = 4;
+    printf("-- every frame as two row bands on two streams (bench.py's step), 8 waves per SIMD\n");
+    p.taps = 0;
+    run<1024>("planes + store only, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+    p.taps = 4;
+    run<1024>("the pass's pattern, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+    p.scatter = 0;
+    run<1024>("... tap scatter +-0 px, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+    p.scatter = 48;
+    printf("-- the same at 8 waves per SIMD with dependent fma per pixel behind the wait (3 chains x N)\n");
+    for (uint32_t f : {16u, 32u, 64u, 96u, 128u}) {
+        p.fma = f;
+        char nm[64];
+        snprintf(nm, sizeof nm, "8 waves, %u fma per pixel", 3 * f);
+        run<1024>(nm, p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    }
+    return 0;
+}

@@ -27,6 +27,7 @@ SYMBOLS = (
     "tr_band_rows", "tr_comm_unique_id", "tr_comm_create", "tr_comm_from_nccl", "tr_comm_destroy", "tr_comm_last_error",
     "tr_allgather_frame", "tr_set_strips", "tr_strip_of_rank", "tr_allgather_strips",
     "tr_generate_mips_from", "tr_generate_mips_band", "tr_set_tap_window", "tr_exchange_halo", "tr_halo_rows", "tr_tonemap_rgb8",
+    "tr_update_lights", "tr_update_instances", "tr_shade_opaque_pyramid", "tr_comm_query",
 )
 
 _lib = None
@@ -159,6 +160,15 @@ def load() -> C.CDLL:
     lib.tr_halo_rows.argtypes = [u32, u32, u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
     lib.tr_tonemap_rgb8.restype = i32
     lib.tr_tonemap_rgb8.argtypes = [vp, vp, u32, u32, C.POINTER(wire.TonemapParams), vp, i32, vp]
+    lib.tr_update_lights.restype = i32
+    lib.tr_update_lights.argtypes = [vp, u32, u32, C.POINTER(wire.Light), vp]
+    lib.tr_update_instances.restype = i32
+    lib.tr_update_instances.argtypes = [vp, u32, u32, vp, vp]
+    lib.tr_shade_opaque_pyramid.restype = i32
+    lib.tr_shade_opaque_pyramid.argtypes = [vp, C.POINTER(wire.GBuffer), C.POINTER(wire.Uniforms), C.POINTER(wire.PushConstants), vp, i32,
+                                            C.POINTER(wire.Pyramid), wire.Rect, C.POINTER(u32), vp]
+    lib.tr_comm_query.restype = i32
+    lib.tr_comm_query.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     lib.tr_ibl_volume_refraction.restype = i32
     lib.tr_ibl_volume_refraction.argtypes = [vp, vp, u32, C.POINTER(wire.Pyramid), vp, vp]
     lib.tr_ibl_volume_refraction_requests.restype = i32

@@ -40,7 +40,9 @@ __device__ __forceinline__ uint32_t wave_lane() {
 // this point, so their live ranges start here.
 template <class T>
 __device__ __forceinline__ T* launder(T* p) {
+#ifndef TR_NO_LAUNDER   // (tools/build_variant.py experiment: what the allocator does when every launch constant may be hoisted)
     asm volatile("" : "+s"(p));
+#endif
     return p;
 }
 

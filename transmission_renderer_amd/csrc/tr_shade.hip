@@ -129,6 +129,7 @@ struct tr_context {
     tr_primitive_info* d_primitives = nullptr;
     tr_instance* d_instances = nullptr;
     uint32_t num_vertices = 0, num_indices = 0, num_primitives = 0, num_instances = 0;
+    std::vector<uint32_t> h_instance_primitive;   // primitive_id of every uploaded instance (tr_update_instances keeps it)
     uint32_t max_triangles[2] = {0, 0};       // per layer, if every instance is visible
     size_t work_capacity = 0, work_draws = 0; // elements per layer in the rasteriser's work buffers
     uint32_t* d_instance_counts = nullptr;
@@ -878,6 +879,48 @@ tr_status tr_upload_materials(tr_context* ctx, const tr_material_info* materials
     return tables_rebuilt(ctx, stream);
 }
 
+}  // extern "C"
+
+// The digest of one light (tr_upload_lights / tr_update_lights): what the shading kernels and the cluster assignment read.
+static void digest_light(const tr_light& s, tr_dlight& d, tr_alight& a) {
+    std::memset(&d, 0, sizeof(d));
+    std::memset(&a, 0, sizeof(a));
+    for (int k = 0; k < 3; ++k) {
+        d.pos[k] = s.position_and_spotlight_epsilon[k];
+        d.colour[k] = s.colour_emission_and_falloff_distance_sq[k];
+        d.spot_dir[k] = s.spotlight_direction_and_outer_angle[k];
+        a.pos[k] = s.position_and_spotlight_epsilon[k];
+        a.spot_dir[k] = s.spotlight_direction_and_outer_angle[k];
+    }
+    const float outer = s.spotlight_direction_and_outer_angle[3];
+    d.is_spot = outer != 0.0f ? 1u : 0u;  // Light::is_a_spotlight, shared-structs/src/lib.rs:125-127
+    d.cos_outer = std::cos(outer);
+    d.inv_spot_epsilon = 1.0f / s.position_and_spotlight_epsilon[3];
+    a.falloff_distance_sq = s.colour_emission_and_falloff_distance_sq[3];
+    a.is_spot = d.is_spot;
+    a.cos_angle = std::cos(outer);   // ClusterAabb::cull_spotlight, shared-structs/src/lib.rs:312
+    a.sin_angle = std::sin(outer);
+}
+
+// Per-frame rewrites of a few records (the reference writes them into mapped buffers: two spotlights, src/main.rs:1244-1256;
+// one instance's rotation, :1258-1261, 1316-1322): the records travel INSIDE the launch's kernel arguments, so the call
+// neither allocates, nor copies from pageable host memory, nor waits — and is ordered on `stream` like any launch.
+namespace tr {
+struct alignas(16) tr_update_payload {   // (the records digested into it are 16-byte aligned types)
+    uint32_t words[TR_UPDATE_MAX_BYTES / 4u];
+};
+__global__ __launch_bounds__(64) void update_records_kernel(uint32_t* __restrict__ dst_a, uint32_t words_a,
+                                                            uint32_t* __restrict__ dst_b, uint32_t words_b, const tr_update_payload p) {
+    // (payload: words_a words for dst_a, then words_b words for dst_b)
+    for (uint32_t i = threadIdx.x; i < words_a + words_b; i += 64u) {
+        if (i < words_a) dst_a[i] = p.words[i];
+        else dst_b[i - words_a] = p.words[i];
+    }
+}
+}  // namespace tr
+
+extern "C" {
+
 tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_t count, void* stream_) {
     if (!ctx || (!lights_host && count)) return TR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
@@ -926,6 +969,27 @@ tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_
                                hipMemcpyHostToDevice, stream));
     ctx->num_lights = count;
     return tables_rebuilt(ctx, stream);
+}
+
+tr_status tr_update_lights(tr_context* ctx, uint32_t first, uint32_t count, const tr_light* lights_host, void* stream_) {
+    if (!ctx || (!lights_host && count)) return TR_ERR_INVALID_ARGUMENT;
+    if ((uint64_t)first + count > ctx->num_lights) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0u) return TR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    constexpr uint32_t per_launch = TR_UPDATE_MAX_BYTES / (uint32_t)(sizeof(tr_dlight) + sizeof(tr_alight));
+    for (uint32_t done = 0; done < count; done += per_launch) {
+        const uint32_t n = std::min(per_launch, count - done);
+        tr::tr_update_payload pay;
+        tr_dlight* d = reinterpret_cast<tr_dlight*>(pay.words);
+        tr_alight* a = reinterpret_cast<tr_alight*>(pay.words + n * (sizeof(tr_dlight) / 4u));
+        for (uint32_t i = 0; i < n; ++i) digest_light(lights_host[done + i], d[i], a[i]);
+        hipLaunchKernelGGL(tr::update_records_kernel, dim3(1), dim3(64), 0, stream,
+                           reinterpret_cast<uint32_t*>(ctx->d_lights + first + done), n * (uint32_t)(sizeof(tr_dlight) / 4u),
+                           reinterpret_cast<uint32_t*>(ctx->d_alights + first + done), n * (uint32_t)(sizeof(tr_alight) / 4u), pay);
+    }
+    TR_HIP(ctx, hipGetLastError());
+    return TR_OK;
 }
 
 tr_status tr_set_cluster_tables(tr_context* ctx, const void* counts_dev, const void* indices_dev,
@@ -1160,6 +1224,31 @@ tr_status tr_upload_geometry(tr_context* ctx, const tr_geometry_desc* g, void* s
     ctx->max_triangles[0] = (uint32_t)max_tris[0];
     ctx->max_triangles[1] = (uint32_t)max_tris[1];
     ctx->counts_clean = false;
+    ctx->h_instance_primitive.resize(nn);
+    for (size_t i = 0; i < nn; ++i) ctx->h_instance_primitive[i] = g->instances[i].primitive_id;
+    return TR_OK;
+}
+
+tr_status tr_update_instances(tr_context* ctx, uint32_t first, uint32_t count, const tr_instance* instances_host, void* stream_) {
+    if (!ctx || (!instances_host && count)) return TR_ERR_INVALID_ARGUMENT;
+    if ((uint64_t)first + count > ctx->num_instances) return TR_ERR_INVALID_ARGUMENT;
+    // (an instance keeps its primitive: the per-primitive instance ranges, the draw streams and the rasteriser's work buffers
+    //  were sized from them at tr_upload_geometry — what changes per frame is the transform, src/main.rs:1258-1261)
+    for (uint32_t i = 0; i < count; ++i)
+        if (instances_host[i].primitive_id != ctx->h_instance_primitive[first + i]) return TR_ERR_INVALID_ARGUMENT;
+    if (count == 0u) return TR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    TR_HIP(ctx, hipSetDevice(ctx->device));
+    constexpr uint32_t per_launch = TR_UPDATE_MAX_BYTES / (uint32_t)sizeof(tr_instance);
+    for (uint32_t done = 0; done < count; done += per_launch) {
+        const uint32_t n = std::min(per_launch, count - done);
+        tr::tr_update_payload pay;
+        std::memcpy(pay.words, instances_host + done, (size_t)n * sizeof(tr_instance));
+        hipLaunchKernelGGL(tr::update_records_kernel, dim3(1), dim3(64), 0, stream,
+                           reinterpret_cast<uint32_t*>(ctx->d_instances + first + done), n * (uint32_t)(sizeof(tr_instance) / 4u),
+                           (uint32_t*)nullptr, 0u, pay);
+    }
+    TR_HIP(ctx, hipGetLastError());
     return TR_OK;
 }
 
@@ -1424,8 +1513,13 @@ tr_status tr_get_depth_slice(tr_context* ctx, const tr_light_cluster_coefficient
     return TR_OK;
 }
 
-tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u, const tr_push_constants* pc,
-                          void* hdr_out, tr_format format, void* opaque_mip0_out, tr_rect rect, void* stream_) {
+}   // extern "C"
+namespace {
+// tr_shade_opaque / tr_shade_opaque_pyramid.  `mip1_out`: level 1 of the opaque pyramid, written by the launch from the 2x2
+// quads of the values it stores (tr_kernels.h: the pass's wave tiles hold whole quads) — the caller has checked that the
+// frame sizes are even and the rect lies on even pixels; NULL: level 0 only.
+tr_status shade_opaque_impl(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u, const tr_push_constants* pc,
+                            void* hdr_out, tr_format format, void* opaque_mip0_out, void* mip1_out, tr_rect rect, void* stream_) {
     if (!ctx || !g || !u || !pc || !hdr_out || !g->pos_depth || !g->nrm_scale || !g->material_id)
         return TR_ERR_INVALID_ARGUMENT;
     if (format != TR_FORMAT_RGBA16F && format != TR_FORMAT_RGBA32F) return TR_ERR_INVALID_ARGUMENT;
@@ -1454,6 +1548,7 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
         L.hdr = hdr_out;
         L.mip0 = (uint2*)opaque_mip0_out;
         L.mip1 = (L.vis && L.mip0 && format == TR_FORMAT_RGBA16F) ? (uint2*)ctx->mip1_hint : nullptr;   // (the frame recorder)
+        if (!L.vis && L.mip0 && format == TR_FORMAT_RGBA16F && mip1_out) L.mip1 = (uint2*)mip1_out;     // (tr_shade_opaque_pyramid)
         if (L.vis && L.cover_front && ctx->front_list_hint) {   // ... whose opaque launch lists the tiles with transmissive fragments
             L.front_list_build = ctx->d_front_list;
             L.front_list_build_count = ctx->d_front_list_count;
@@ -1468,6 +1563,27 @@ tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniform
     }
     TR_HIP(ctx, hipGetLastError());
     return TR_OK;
+}
+}  // namespace
+extern "C" {
+
+tr_status tr_shade_opaque(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u, const tr_push_constants* pc,
+                          void* hdr_out, tr_format format, void* opaque_mip0_out, tr_rect rect, void* stream) {
+    return shade_opaque_impl(ctx, g, u, pc, hdr_out, format, opaque_mip0_out, nullptr, rect, stream);
+}
+
+tr_status tr_shade_opaque_pyramid(tr_context* ctx, const tr_gbuffer* g, const tr_uniforms* u, const tr_push_constants* pc,
+                                  void* hdr_out, tr_format format, const tr_pyramid* p, tr_rect rect,
+                                  uint32_t* next_level_out, void* stream) {
+    if (!p || !p->texels || !next_level_out || !pc || p->levels == 0 || p->levels > TR_MAX_MIP_LEVELS) return TR_ERR_INVALID_ARGUMENT;
+    if (p->width != pc->framebuffer_size[0] || p->height != pc->framebuffer_size[1]) return TR_ERR_INVALID_ARGUMENT;
+    uint2* const base = (uint2*)p->texels;
+    // level 1 from the pass's own quads: an exact 2x2 box needs even frame sizes, and whole quads a rect on even pixels —
+    // otherwise the chain starts at level 1 as after tr_shade_opaque
+    const bool quads = p->levels >= 2u && format == TR_FORMAT_RGBA16F && !(p->width & 1u) && !(p->height & 1u) &&
+                       !((rect.x0 | rect.y0 | rect.x1 | rect.y1) & 1u);
+    *next_level_out = quads ? 2u : 1u;
+    return shade_opaque_impl(ctx, g, u, pc, hdr_out, format, base + p->level_offset[0], quads ? base + p->level_offset[1] : nullptr, rect, stream);
 }
 
 }   // extern "C"
@@ -1793,6 +1909,8 @@ struct rccl_api {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // (optional: tr_comm_query)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
 };
 // Loaded once.  By soname first: a process that already mapped an RCCL (a framework's bundled copy has the same
@@ -1814,6 +1932,8 @@ const rccl_api& rccl() {
         a.Recv = (decltype(a.Recv))dlsym(a.handle, "ncclRecv");
         a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
         a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
+        a.CommCount = (decltype(a.CommCount))dlsym(a.handle, "ncclCommCount");
+        a.CommUserRank = (decltype(a.CommUserRank))dlsym(a.handle, "ncclCommUserRank");
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.Broadcast && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
         return a;
     }();
@@ -1896,6 +2016,21 @@ tr_status tr_comm_destroy(tr_comm* comm) {
 }
 
 int32_t tr_comm_last_error(const tr_comm* comm) { return comm ? comm->last_error : (rccl().ok ? 0 : -1); }
+
+tr_status tr_comm_query(tr_comm* comm, uint32_t* nranks_out, uint32_t* rank_out) {
+    if (!comm || !nranks_out || !rank_out) return TR_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok || !rccl().CommCount || !rccl().CommUserRank || !comm->comm) return TR_ERR_COMM;
+    int n = 0, r = 0;
+    ncclResult_t e = rccl().CommCount(comm->comm, &n);
+    if (e == ncclSuccess) e = rccl().CommUserRank(comm->comm, &r);
+    if (e != ncclSuccess) {
+        comm->last_error = (int32_t)e;
+        return TR_ERR_COMM;
+    }
+    *nranks_out = (uint32_t)n;
+    *rank_out = (uint32_t)r;
+    return TR_OK;
+}
 
 tr_status tr_allgather_frame(tr_context* ctx, tr_comm* comm, void* frame, uint32_t width, uint32_t rows_per_rank,
                              tr_format format, void* stream_) {

@@ -143,6 +143,18 @@ class TransmissionRenderer:
         arr = wire.as_ctypes_array(list(lights), wire.Light) if lights else None
         self._check(self.lib.tr_upload_lights(self._ctx, arr, len(lights), self._stream()), "tr_upload_lights")
 
+    def update_lights(self, first: int, lights: Sequence[wire.Light]):
+        """Rewrites lights [first, first + len(lights)) in place (tr_update_lights): the reference's per-frame write of its
+        rotating spotlights (src/main.rs:1244-1256).  No allocation, no wait."""
+        arr = wire.as_ctypes_array(list(lights), wire.Light)
+        self._check(self.lib.tr_update_lights(self._ctx, int(first), len(lights), arr, self._stream()), "tr_update_lights")
+
+    def update_instances(self, first: int, instances: np.ndarray):
+        """Rewrites instances [first, first + len(instances)) of the uploaded geometry in place (tr_update_instances): the
+        reference's per-frame write of the rotating model's instances (src/main.rs:1258-1261, 1316-1322)."""
+        a = np.ascontiguousarray(instances, dtype=wire.INSTANCE_DTYPE)
+        self._check(self.lib.tr_update_instances(self._ctx, int(first), len(a), a.ctypes.data, self._stream()), "tr_update_instances")
+
     def set_cluster_tables(self, counts: torch.Tensor, indices: torch.Tensor):
         assert counts.is_cuda and indices.is_cuda and counts.dtype == torch.int32 and indices.dtype == torch.int32
         assert indices.numel() == counts.numel() * wire.MAX_LIGHTS_PER_CLUSTER
@@ -317,6 +329,18 @@ class TransmissionRenderer:
                                              self._fmt(hdr), mip0, self._rect(g, rect), self._stream()),
                     "tr_shade_opaque")
 
+    def shade_opaque_pyramid(self, g: GBufferPlanes, uniforms: wire.Uniforms, push: wire.PushConstants, hdr: torch.Tensor,
+                             pyramid: OpaquePyramid, rect=None) -> int:
+        """"main opaque" writing into the pyramid (tr_shade_opaque_pyramid): level 0 and — RGBA16F target, even frame sizes,
+        rect on even pixels — level 1 from the pass's own quads.  Returns the level generate_mips_from continues from."""
+        gs = g.as_struct()
+        self._check_target(hdr, push)
+        nxt = C.c_uint32()
+        self._check(self.lib.tr_shade_opaque_pyramid(self._ctx, C.byref(gs), C.byref(uniforms), C.byref(push), hdr.data_ptr(),
+                                                     self._fmt(hdr), C.byref(pyramid.desc), self._rect(g, rect), C.byref(nxt),
+                                                     self._stream()), "tr_shade_opaque_pyramid")
+        return int(nxt.value)
+
     def generate_mips(self, pyramid: OpaquePyramid):
         """"opaque framebuffer mipchain" (src/main.rs:2046-2064)."""
         self._check(self.lib.tr_generate_mips(self._ctx, C.byref(pyramid.desc), self._stream()), "tr_generate_mips")
@@ -450,6 +474,12 @@ class TransmissionRenderer:
     def record(self, opaque: GBufferPlanes, transmissive: GBufferPlanes, uniforms: wire.Uniforms,
                push: wire.PushConstants, hdr: torch.Tensor, pyramid: OpaquePyramid, rect=None):
         """The hot-path slice of `record()` in the reference's order (src/main.rs:1969-2124)."""
-        self.shade_opaque(opaque, uniforms, push, hdr, pyramid, rect)
-        self.generate_mips(pyramid)
+        whole = rect is None and opaque.origin_x == 0 and opaque.origin_y == 0 and opaque.width == int(push.framebuffer_size[0]) \
+            and opaque.height == int(push.framebuffer_size[1])
+        if whole and pyramid.desc.height == int(push.framebuffer_size[1]):
+            # the opaque launch writes level 1 from its own quads where it can: the chain never reads level 0 back
+            self.generate_mips_from(pyramid, self.shade_opaque_pyramid(opaque, uniforms, push, hdr, pyramid))
+        else:
+            self.shade_opaque(opaque, uniforms, push, hdr, pyramid, rect)
+            self.generate_mips(pyramid)
         self.shade_transmission(transmissive, uniforms, push, pyramid, hdr, rect)
