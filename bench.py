@@ -108,6 +108,9 @@ def parse_args(argv=None):
                          "under `rocprofv3 --pmc ...`); the committed profiles/pmc_traffic.json is used for the traffic instead")
     ap.add_argument("--no-single-gpu-reference", action="store_true")
     ap.add_argument("--no-full-pipeline", action="store_true", help="N > 1: skip the 8K full-pipeline frame (full_pipeline_8k)")
+    ap.add_argument("--full-pipeline-size", default="7680x4320",
+                    help="N > 1: frame size of the sharded full pipeline (full_pipeline_8k; BASELINE config 5 is 7680x4320 — a "
+                         "smaller one for the one-device rehearsal)")
     ap.add_argument("--exchange", choices=("halo", "allgather"), default="halo",
                     help="N > 1, full pipeline: how the opaque colour crosses the band borders between the passes — halo: rows "
                          "of levels 0 and 1 with the two neighbours + an all-gather of level 2 (1/16 of the bytes); allgather: "
@@ -120,6 +123,14 @@ def parse_args(argv=None):
                     help="N = 1 only: run the N > 1 code path on one GPU (process group of one rank, the library's RCCL "
                          "communicator, comm stream, composite in the timed step) — every line of the multi-GPU path that "
                          "one GPU can execute")
+    ap.add_argument("--one-device", action="store_true",
+                    help="N > 1 rehearsal on ONE GPU: every rank drives cuda:0, the process group is gloo and the exchanges of "
+                         "device tensors are staged through host memory (RCCL refuses two ranks on one device).  Exercises "
+                         "run_rank with WORLD_SIZE > 1 on device buffers — band origins, halo windows, the late verdict — not "
+                         "the links: its numbers are not performance figures")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="N > 1: exit non-zero unless the composite ran over the library's own RCCL communicator "
+                         "(tr_allgather_frame) — a silent fallback to torch.distributed would not be measuring it")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="no GPU: the ranks rendezvous over gloo, cut the frame into bands and composite a host frame "
                          "(covers the launcher and the band arithmetic; tests/test_bench_launch.py)")
@@ -775,7 +786,7 @@ def full_pipeline_8k(r, comp, world, rank, dev, dist, scene4k, K, args):
     import torch
     from transmission_renderer_amd import sharded, synthetic
     from transmission_renderer_amd.renderer import OpaquePyramid
-    fw, fh = 7680, 4320
+    fw, fh = (int(v) for v in args.full_pipeline_size.lower().split("x"))
     scene = synthetic.make_scene(fw, fh, num_point_lights=args.lights, with_gbuffer=False)     # (same materials and lights: uploaded)
     uniforms, push = scene["uniforms"], scene["push"]
     rows, y0, y1 = sharded.band_rows(fh, world, rank)
@@ -805,7 +816,7 @@ def full_pipeline_8k(r, comp, world, rank, dev, dist, scene4k, K, args):
     elapsed = time.perf_counter() - t0
     if hasattr(comp, "confirm_halo"):
         comp.confirm_halo()             # (the last frame's verdict)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.one_device else dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item()) / K * 1e3
     out = {"ms_per_frame": round(ms, 4), "Mpixels_per_s": round(fw * fh / ms / 1e3, 1), "frames": K,
@@ -1022,8 +1033,13 @@ def run_rank(args) -> int:
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.one_device:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from transmission_renderer_amd import sharded, synthetic
     from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid, TransmissionRenderer, load_ggx_lut
@@ -1078,6 +1094,14 @@ def run_rank(args) -> int:
     ldr_frames = [torch.zeros((padded, fw, ldr_channels), dtype=torch.uint8, device=dev) for _ in frames] if present_ldr else None
     tonemap_params = r.baked_tonemap_params() if present_ldr else None
     comp = sharded.Compositor(world, rank, renderer=r, single_rank_comm=args.rehearse_distributed) if distributed else None
+    if distributed and args.require_rccl and not comp.backend.startswith("tr_allgather_frame"):
+        print(f"bench.py --require-rccl: the composite would run over {comp.backend!r}, not over tr_allgather_frame (RCCL)",
+              file=sys.stderr, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        r.close()
+        return 3
+    cdev = "cpu" if args.one_device else dev     # where the run's small book-keeping collectives live (gloo reduces host memory)
     torch.cuda.synchronize()
 
     compute = torch.cuda.current_stream()
@@ -1172,7 +1196,7 @@ def run_rank(args) -> int:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     region_ms = max(ev0[0].elapsed_time(e) for e in ev1) / K
@@ -1216,26 +1240,26 @@ def run_rank(args) -> int:
     composite_ms = None
     per_rank_kernel_ms = [kernel_ms]
     if distributed:
-        mine = torch.tensor([kernel_ms, float((y1 - y0) * fw)], dtype=torch.float64, device=dev)
+        mine = torch.tensor([kernel_ms, float((y1 - y0) * fw)], dtype=torch.float64, device=cdev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_kernel_ms = [float(e[0].item()) for e in every]
         per_rank_pixels = [float(e[1].item()) for e in every]
         kernel_ms_max = max(per_rank_kernel_ms)
         if kernel_in_flight_ms is not None:
-            t = torch.tensor([kernel_in_flight_ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([kernel_in_flight_ms], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             kernel_in_flight_ms = float(t.item())
         dist.barrier()
         composite_ms = timed_launches(max(10, K // 4), lambda: comp.allgather_rows(frames[0]))
-        t = torch.tensor([composite_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([composite_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         composite_ms = float(t.item())
         # the same composite of the frame as it is presented: bands tonemapped to RGBA8 first (half the bytes per link)
         ldr = torch.zeros((padded, fw, ldr_channels), dtype=torch.uint8, device=dev)
         dist.barrier()
         composite_ldr_ms = timed_launches(max(10, K // 4), lambda: comp.allgather_rows(ldr))
-        t = torch.tensor([composite_ldr_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([composite_ldr_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         composite_ldr_ms = float(t.item())
     # per-launch events for the frame-time percentiles of the metric
@@ -1407,6 +1431,12 @@ def run_rank(args) -> int:
                                     "frac_survey_60B": round(pixels_rank * SURVEY_BYTES_PER_PIXEL / ss / 1e9 / HBM_PEAK_GBS, 4),
                                     "note": "the same K launches on one stream, each behind the previous one"}
         if distributed:
+            out["composite_backend"] = comp.backend
+            out["rccl_ranks"] = comp.rccl_ranks          # ncclCommCount of the library's communicator; null: it is not in use
+            out["composite_fell_back"] = bool(comp.fell_back)
+            if args.one_device:
+                out["one_device_rehearsal"] = ("every rank on cuda:0, gloo process group, exchanges staged through host memory: the "
+                                               "N > 1 code path on device buffers, NOT a measurement of the links")
             out["kernel_only"] = {"ms_per_step": round(kernel_ms_max, 4),
                                   "Mpixels_per_s": round(pixels_step / kernel_ms_max / 1e3, 1),
                                   "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],

@@ -25,8 +25,9 @@ def test_distributed_bench_path_on_one_gpu(fmt):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["scaling"] == "strong" and out["value"] > 0
-    assert out["config"]["composite"].startswith("overlap: tr_allgather_frame (RCCL), of the "
+    assert out["config"]["composite"].startswith("overlap: tr_allgather_frame (RCCL), 1 ranks by ncclCommCount, of the "
                                                  + ("frame as presented" if fmt == "rgb8" else "RGBA16F HDR target"))
+    assert out["composite_backend"].startswith("tr_allgather_frame (RCCL)") and out["rccl_ranks"] == 1 and out["composite_fell_back"] is False
     assert out["kernel_only"]["per_rank_kernel_ms"][0] > 0 and 0 < out["kernel_only"]["per_rank_roofline_frac"][0] < 1
     assert out["composite_allgather_ms"] > 0 and out["composite_rgb8_allgather_ms" if fmt == "rgb8" else "composite_rgba8_allgather_ms"] > 0
     fp = out["full_pipeline_8k"]            # BASELINE config 5's frame through the sharded full pipeline (one rank here)

@@ -87,8 +87,19 @@ class Compositor:
         self.renderer = renderer
         self._comm = C.c_void_p()
         self.backend = "none" if world == 1 else "torch.distributed:" + dist.get_backend(group)
-        if (world > 1 or single_rank_comm) and renderer is not None and prefer_library:
+        # a GPU frame exchanged through a host-side backend (gloo: the one-GPU rehearsal of the N > 1 path, both ranks on one
+        # device, which RCCL refuses) is staged through host memory by the fallbacks below
+        self.host_staged = world > 1 and renderer is not None and str(getattr(renderer, "device", "cpu")) != "cpu" \
+            and dist.get_backend(group) == "gloo"
+        self.fell_back = False          # the library's RCCL communicator was wanted and could not be made
+        self.rccl_ranks = None          # what RCCL itself reports for the library's communicator (tr_comm_query)
+        if (world > 1 or single_rank_comm) and renderer is not None and prefer_library and not self.host_staged:
             self._try_library_comm()
+            if not self._comm.value:
+                self.fell_back = True
+                self.backend += " (FALLBACK: the library's RCCL communicator could not be created)"
+        if self.host_staged:
+            self.backend += " (device tensors staged through host memory)"
 
     def _try_library_comm(self):
         """The library's RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes."""
@@ -109,6 +120,10 @@ class Compositor:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)       # every rank or none
         if int(flag.item()) == 1:
             self.backend = "tr_allgather_frame (RCCL)"
+            n, r = C.c_uint32(), C.c_uint32()
+            if lib.tr_comm_query(self._comm, C.byref(n), C.byref(r)) == 0:
+                self.rccl_ranks = int(n.value)
+                self.backend += f", {n.value} ranks by ncclCommCount"
         else:
             self.close()
 
@@ -179,19 +194,25 @@ class Compositor:
             if st != 0:
                 raise _lib.TrError(st, "tr_exchange_halo", self.renderer.lib.tr_comm_last_error(self._comm))
             return
-        ops, keep = [], []
+        ops, keep, landed = [], [], []
         for peer in range(self.world):
             if peer == self.rank:
                 continue
             a, b = halo_rows_between(total, rows_per_rank, self.world, self.rank, peer, halo)     # mine, for the peer
             if b > a:
-                keep.append(level_rows[a:b].clone())
+                keep.append(level_rows[a:b].cpu() if self.host_staged else level_rows[a:b].clone())
                 ops.append(dist.P2POp(dist.isend, keep[-1], peer, group=self.group))
             a, b = halo_rows_between(total, rows_per_rank, self.world, peer, self.rank, halo)     # the peer's, for me
             if b > a:
-                ops.append(dist.P2POp(dist.irecv, level_rows[a:b], peer, group=self.group))
+                if self.host_staged:
+                    landed.append((a, b, torch.empty(level_rows[a:b].shape, dtype=level_rows.dtype)))
+                    ops.append(dist.P2POp(dist.irecv, landed[-1][2], peer, group=self.group))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, level_rows[a:b], peer, group=self.group))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
+        for a, b, host in landed:
+            level_rows[a:b].copy_(host)
 
     def allgather_bands(self, level_rows: torch.Tensor, rows_per_rank: int) -> None:
         """In-place all-gather of a level whose bands are clipped to it (no padding rows behind it)."""
@@ -225,7 +246,13 @@ class Compositor:
         flat = frame.view(-1)
         n = flat.numel() // self.world
         mine = flat[self.rank * n:(self.rank + 1) * n]
-        if dist.get_backend(self.group) == "gloo":   # gloo has no in-place variant on views of the output
+        if self.host_staged:
+            outs = [torch.empty(n, dtype=flat.dtype) for _ in range(self.world)]
+            dist.all_gather(outs, mine.cpu(), group=self.group)
+            for i, o in enumerate(outs):
+                if i != self.rank:
+                    flat[i * n:(i + 1) * n].copy_(o)
+        elif dist.get_backend(self.group) == "gloo":   # gloo has no in-place variant on views of the output
             outs = [flat[i * n:(i + 1) * n] for i in range(self.world)]
             dist.all_gather(outs, mine.clone(), group=self.group)
         else:
@@ -252,12 +279,20 @@ def allgather_strips(comp: "Compositor", frame: torch.Tensor, strip_rows: int) -
         if st != 0:
             raise _lib.TrError(st, "tr_allgather_strips", comp.renderer.lib.tr_comm_last_error(comp._comm))
         return
-    works = []
+    works, landed = [], []
     for s, y in enumerate(range(0, h, strip_rows)):
-        works.append(dist.broadcast(frame[y:min(y + strip_rows, h)], src=dist.get_global_rank(comp.group, s % comp.world)
+        rows = frame[y:min(y + strip_rows, h)]
+        buf = rows
+        if comp.host_staged:                      # (see Compositor: a host-side backend under device tensors)
+            buf = rows.cpu()
+            if s % comp.world != comp.rank:
+                landed.append((rows, buf))
+        works.append(dist.broadcast(buf, src=dist.get_global_rank(comp.group, s % comp.world)
                                     if comp.group is not None else s % comp.world, group=comp.group, async_op=True))
     for wk in works:
         wk.wait()
+    for rows, buf in landed:
+        rows.copy_(buf)
 
 
 def record_sharded_strips(renderer, opaque, transmissive, uniforms, push, hdr, pyramid, compositor: "Compositor",
@@ -318,7 +353,7 @@ def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid,
         margin = compositor.halo_window_margin(halo)   # (the same on every rank: the counters move with all-rank verdicts)
         # (late: the word stays on the device — a host-side backend could only reduce it after reading it)
         late = (confirm == "late" and hasattr(renderer, "tap_window_excess_word")
-                and (world == 1 or str(renderer.device) == "cpu" or dist.get_backend(compositor.group) != "gloo"))
+                and (world == 1 or str(renderer.device) == "cpu" or dist.get_backend(compositor.group) != "gloo" or compositor.host_staged))
         renderer.generate_mips_band(pyramid, rect[1], rect[3])                       # levels 1, 2 of the band
         compositor.exchange_halo(pyramid.level(0), rows, halo)
         compositor.exchange_halo(pyramid.level(1), rows // 2, halo // 2)
@@ -338,6 +373,8 @@ def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid,
         if late:
             if word is None:
                 word = torch.zeros(1, dtype=torch.int64, device=renderer.device)
+            if compositor.host_staged:
+                word = word.cpu()          # (the rehearsal's host-side backend reduces host memory: this read waits for the passes)
             work = dist.all_reduce(word, op=dist.ReduceOp.MAX, group=compositor.group, async_op=True) if world > 1 else None
             compositor._halo_pending = (word, work, halo, margin)
             if composite:
