@@ -42,6 +42,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import signal
 import json
 import os
 import socket
@@ -99,6 +100,7 @@ def parse_args(argv=None):
                          "as many as make more than 1.2 GB, at least 3")
     ap.add_argument("--frame-probe", action="store_true",
                     help="internal (the child runs under rocprofv3): 120 tr_record_frame calls of the 4K `meshes` scene, nothing else")
+    ap.add_argument("--room", action="store_true", help="--frame-probe: the overdraw scene (meshes.make_mesh_scene(room=True))")
     ap.add_argument("--pmc-probe", action="store_true",
                     help="internal (the child runs under rocprofv3 --pmc): six whole-frame launches each of the headline "
                          "scene, the all-transmissive scene and config 3, nothing else")
@@ -331,6 +333,22 @@ PROBE_PHASES = ("headline", "all_transmissive", "config3")
 PROBE_LAUNCHES = 6
 
 
+def run_profiled(cmd, env, timeout):
+    """A rocprofv3 child in its own session; on a timeout the WHOLE group is killed (killing only rocprofv3 left the profiled
+    Python process running on the GPU beside whatever was timed next).  (returncode, stderr); returncode None: timed out."""
+    p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)     # (the group this call started, by its id)
+        except ProcessLookupError:
+            pass
+        p.communicate()
+        return None, "timed out"
+    return p.returncode, err
+
+
 def measure_pmc(args):
     """Counters of the transmissive kernel, measured NOW: three child runs of this script (`--pmc-probe`: PROBE_LAUNCHES
     whole-frame launches each of the headline scene, the all-transmissive scene and config 3, one stream) under
@@ -355,8 +373,8 @@ def measure_pmc(args):
                    sys.executable, os.path.abspath(__file__), "--pmc-probe", "--width", str(args.width), "--height", str(args.height),
                    "--lights", str(args.lights)]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
-            if r.returncode != 0:
+            code, _ = run_profiled(cmd, env, 120)
+            if code != 0:
                 return None
             rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -408,7 +426,7 @@ def frame_probe(args) -> int:
     w, h = args.width, args.height
     r = TransmissionRenderer(0)
     scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False, textured=True)
-    geometry = meshes.make_mesh_scene(extra_instances=True)
+    geometry = meshes.make_mesh_scene(extra_instances=True, room=args.room)
     scene["materials"][2].alpha_clipping_cutoff = 0.75
     scene["materials"][7].alpha_clipping_cutoff = 0.6
     r.upload_ggx_lut()
@@ -440,7 +458,7 @@ FRAME_KERNELS = (   # (name in the bench line, substring of the kernel's name in
 )
 
 
-def measure_frame_kernels(width, height):
+def measure_frame_kernels(width, height, room=False, counters=True):
     """frame_pipeline.kernels: the frame recorder's launches one by one, measured NOW by child runs of this script
     (`--frame-probe`) under rocprofv3 — one kernel-trace pass (µs per launch, launches per frame) and three --pmc passes
     (FETCH_SIZE; WRITE_SIZE; SQ counters), kernel trace only, as MI355X_MICROARCH.md prescribes.  Per kernel: us (mean
@@ -455,15 +473,14 @@ def measure_frame_kernels(width, height):
     if rocprof is None or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
         return None
     tmp = tempfile.mkdtemp(prefix="tr_frame_", dir="/tmp")
-    child = [sys.executable, os.path.abspath(__file__), "--frame-probe", "--width", str(width), "--height", str(height)]
+    child = [sys.executable, os.path.abspath(__file__), "--frame-probe", "--width", str(width), "--height", str(height)] + (["--room"] if room else [])
     env = dict(os.environ, TMPDIR="/tmp")
 
     def rows_of(tag, extra):
         d = os.path.join(tmp, tag)
-        r = subprocess.run([rocprof, "--kernel-trace"] + extra + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
-                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
-        if r.returncode != 0:
-            raise RuntimeError(f"rocprofv3 {tag}: {r.stderr[-300:]}")
+        code, err = run_profiled([rocprof, "--kernel-trace"] + extra + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child, env, 240)
+        if code != 0:
+            raise RuntimeError(f"rocprofv3 {tag}: {err[-300:]}")
         return d
 
     try:
@@ -483,6 +500,8 @@ def measure_frame_kernels(width, height):
             lpf = max(1, round(len(v) / FRAME_PROBE_FRAMES))
             steady = [dur for _, dur in v[20 * lpf:]] or [dur for _, dur in v]
             out[name] = {"us": round(sum(steady) / len(steady) / 1e3 * lpf, 2), "launches_per_frame": lpf}
+        if not counters:
+            return out
         counters = {}
         for tag, cs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
                         ("sq", ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "SQ_INSTS_VALU"])):
@@ -683,7 +702,38 @@ def measure_config(name, device_index, width, height, K, W, lights=1, roughness=
         torch.cuda.empty_cache()
 
 
-def frame_pipeline_time(width, height):
+def fragments_per_pixel(room, width=960, height=540):
+    """Depth complexity of the mesh scene as the rasteriser meets it: every instance drawn ALONE through tr_draw_scene, its
+    covered pixels counted (front-facing, un-clipped fragments), summed and divided by the frame's pixels."""
+    import numpy as np
+    import torch
+    from transmission_renderer_amd import meshes, synthetic, wire
+    from transmission_renderer_amd.renderer import TransmissionRenderer
+    r = TransmissionRenderer(0)
+    try:
+        scene = synthetic.make_scene(width, height, num_point_lights=1, with_gbuffer=False, textured=True)
+        scene["materials"][2].alpha_clipping_cutoff = 0.75
+        scene["materials"][7].alpha_clipping_cutoff = 0.6
+        r.upload_ggx_lut()
+        r.upload_materials(scene["materials"])
+        r.upload_textures(scene["textures"])
+        _, view = wire.default_camera()
+        culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(width, height), view)
+        o, t = r.new_layer(width, height), r.new_layer(width, height)
+        fragments = 0
+        for mesh, draw_buffer, instances in meshes.mesh_scene_parts(True, room):
+            for inst in instances:
+                mb = meshes.ModelBuffers()
+                mb.add_primitive(mesh, draw_buffer, [inst])
+                r.upload_geometry(mb.finish())
+                r.draw_scene(culling, scene["push"], o, t)
+                fragments += int((o.material_id != -1).sum().item()) + int((t.material_id != -1).sum().item())
+        return fragments / float(width * height)
+    finally:
+        r.close()
+
+
+def frame_pipeline_time(width, height, room=False):
     """us per frame of tr_record_frame on the procedural `meshes` scene (own contexts; see run_rank): every frame behind
     the previous one, and with two frames in flight — two contexts (each its own work buffers and targets) on two HIP
     streams, frame k recorded into context k mod 2, like a renderer with a swapchain: a frame is a dependent chain of
@@ -696,7 +746,7 @@ def frame_pipeline_time(width, height):
     def make_context():
         r = TransmissionRenderer(0)
         scene = synthetic.make_scene(width, height, num_point_lights=2, with_gbuffer=False, textured=True)
-        geometry = meshes.make_mesh_scene(extra_instances=True)
+        geometry = meshes.make_mesh_scene(extra_instances=True, room=room)
         scene["materials"][2].alpha_clipping_cutoff = 0.75
         scene["materials"][7].alpha_clipping_cutoff = 0.6
         r.upload_ggx_lut()
@@ -820,7 +870,7 @@ def full_pipeline_8k(r, comp, world, rank, dev, dist, scene4k, K, args):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item()) / K * 1e3
     out = {"ms_per_frame": round(ms, 4), "Mpixels_per_s": round(fw * fh / ms / 1e3, 1), "frames": K,
-           "exchange_confirmed": "a frame late (no drain in front of the composite)",
+           "exchange_confirmed": "two frames late, from pinned host memory behind an event (no drain in front of the composite, no host wait in the frame loop)",
            "exchange_inexact_frames": int(getattr(comp, "halo_inexact_frames", 0)) - inexact_before,
            "workload": f"opaque -> exchange -> mip chain -> transmissive -> composite, frame {fw}x{fh} in {world} row bands of {rows} rows, "
                        f"synthetic TGB-v1 layer as both layers, sun + {args.lights} punctual light(s)",
@@ -873,7 +923,7 @@ def run_single(args) -> int:
     launch_log += [("same_input", K * len(wl.parts)), ("single_stream", K)]
     # p50 frame ms of the metric: the step's own pattern, timed in batches of 10 steps (an event pair per step would put a
     # barrier packet between the steps it measures)
-    batch = 10
+    batch = 10     # (>= 50 timed steps whatever --steps says: SURVEY 8d)
     per_step = np.array([wl.timed(batch)[0] for _ in range(max(5, min(20, K // 2)))], dtype=np.float64)
     launch_log.append(("percentiles", len(per_step) * batch * len(wl.parts)))
     # ... and of single whole-frame launches, an event pair around each
@@ -916,9 +966,20 @@ def run_single(args) -> int:
             frame_pipeline = frame_pipeline_time(fw, fh)
             frame_pipeline["at_1080p"] = {k: v for k, v in frame_pipeline_time(1920, 1080).items() if k in ("us_per_frame", "two_frames_in_flight")}
             frame_pipeline["at_8k"] = {k: v for k, v in frame_pipeline_time(7680, 4320).items() if k in ("us_per_frame", "two_frames_in_flight")}
+            # the same frame where the rasteriser is NOT in its best case: the objects inside a closed room with partitions
+            # behind them (the reference renders its model inside Sponza, src/main.rs:342-351; its depth pre-pass exists for
+            # exactly this, readme.md:74) — every pixel covered, later draws nearer
+            over = frame_pipeline_time(fw, fh, room=True)
+            frame_pipeline["overdraw"] = {"us_per_frame": over["us_per_frame"], "two_frames_in_flight": over["two_frames_in_flight"],
+                                          "at_1080p_us_per_frame": frame_pipeline_time(1920, 1080, room=True)["us_per_frame"],
+                                          "fragments_per_pixel": round(fragments_per_pixel(True), 2),
+                                          "fragments_per_pixel_of_the_plain_scene": round(fragments_per_pixel(False), 2),
+                                          "scene": "the `meshes` scene inside a closed room (mesh_scene_parts(room=True)): back wall, "
+                                                   "ceiling, side walls and three partitions drawn far to near behind the objects"}
             if not args.no_traffic:
                 torch.cuda.synchronize()
                 frame_pipeline["kernels"] = measure_frame_kernels(fw, fh)   # child processes; the GPU is idle here
+                frame_pipeline["overdraw"]["kernels"] = measure_frame_kernels(fw, fh, room=True, counters=False)   # (one kernel-trace pass)
         except Exception as e:
             frame_pipeline = dict(frame_pipeline or {}, error=f"{type(e).__name__}: {e}")
 

@@ -389,7 +389,12 @@ typedef struct tr_gbuffer_target {
  * frame size has run outside the capture (the scan's frame counter lives on the device and moves on with every replay).  What
  * cannot be captured is refused with TR_ERR_UNSUPPORTED before anything is enqueued: (re)allocating the visibility buffers
  * for another frame size, rebuilding a table, the timed frame recorder.  Replays of a captured frame must not interleave
- * with other rasterising calls of the context.
+ * with other rasterising calls of the context.  What a replay relies on, precisely: whether a call enqueues the clear of its
+ * work buffers is decided from the context's state when the call is RECORDED.  A captured tr_record_frame / tr_draw_scene
+ * always zeroes the instance counts it culls into (so a replay may follow a direct tr_frustum_culling on the context's own
+ * counts); the visibility words (133 MB at 4K) are only zeroed when the context says they are dirty at capture time, so a
+ * graph must be captured behind a complete frame and never replayed after a direct call that leaves them set — a
+ * tr_rasterize / tr_draw_scene into RGBA16F frames whose shading passes were not run.  Re-capture after such a call.
  */
 tr_status tr_rasterize(tr_context* ctx, const void* draw_counts, const void* const draws[TR_NUM_DRAW_BUFFERS],
                        const tr_push_constants* push, const tr_gbuffer_target* opaque,

@@ -23,6 +23,15 @@ def test_cli_refuses_bad_scene_arguments(tmp_path, capsys):
     assert "backdrop" in capsys.readouterr().err
 
 
+def test_cli_resolves_bare_names_like_the_reference(tmp_path, capsys):
+    """path_for_gltf_model (src/model_loading.rs:381-390): <dir>/2.0/<Name>/glTF/<Name>.gltf; --external-model takes a path as it is."""
+    assert cli.main(["Nothing", "--sample-models-dir", str(tmp_path)]) == 2
+    assert os.path.join(str(tmp_path), "2.0", "Nothing", "glTF", "Nothing.gltf") in capsys.readouterr().err
+    assert cli.main([str(tmp_path / "model.bin"), "--external-model"]) == 2      # a path by declaration: "no such file"
+    assert "no such file" in capsys.readouterr().err
+    assert cli.main(["meshes", "--frames", "0"]) == 2
+
+
 def test_backdrop_scene_is_loaded_first_and_model_appended(tmp_path):
     """What --backdrop does on the host: the reference's two load_gltf calls into one set of model buffers."""
     import make_demo_gltf
@@ -81,3 +90,31 @@ def test_cli_tonemap_constants_are_explicit_inputs(tmp_path):
     lib.tr_bake_lottes_params(C.byref(q), C.byref(tm))
     want = oracle.tonemap_frame(np.ascontiguousarray(np.load(hdr), dtype=np.float16), tm)[0]
     assert np.abs(fc[..., :3].astype(np.int32) - want[..., :3].astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_cli_frame_loop_rotates_the_model_and_the_spotlights(tmp_path):
+    """--rotate-model / --spotlights with --frames N: the reference's per-frame rewrites (src/main.rs:1243-1261, 1316-1322) through
+    tr_update_instances / tr_update_lights — the last frame differs from the first, a loop without the flags does not; and a
+    model behind --external-model (a path without a glTF suffix) loads like the same file with one."""
+    import shutil
+    import make_demo_gltf
+    from transmission_renderer_amd.png import read_png_rgba8
+    out = [str(tmp_path / f"{k}.png") for k in range(6)]
+    common = ["--width", "320", "--height", "180", "--spotlights"]
+    assert cli.main(["meshes", *common, "--out", out[0]]) == 0
+    assert cli.main(["meshes", *common, "--frames", "40", "--out", out[1]]) == 0
+    assert (read_png_rgba8(out[0]) != read_png_rgba8(out[1])).any(), "the spotlights did not turn"          # (0.4 rad after 40 frames)
+    model = str(tmp_path / "demo.glb")
+    make_demo_gltf.main(model)
+    renamed = str(tmp_path / "model.bin")
+    shutil.copy(model, renamed)
+    view = ["--width", "320", "--height", "180", "--scale", "0.15"]
+    assert cli.main([model, *view, "--out", out[2]]) == 0
+    assert cli.main([renamed, "--external-model", *view, "--out", out[3]]) == 0
+    assert (read_png_rgba8(out[2]) == read_png_rgba8(out[3])).all()
+    # the LAST instance of the model buffers gets Quat::from_rotation_y(-0.0025 k) as its rotation (src/main.rs:920-921, 1258-1261)
+    assert cli.main([model, *view, "--frames", "40", "--out", out[4]]) == 0
+    assert cli.main([model, *view, "--frames", "40", "--rotate-model", "--out", out[5]]) == 0
+    assert (read_png_rgba8(out[2]) == read_png_rgba8(out[4])).all()             # a loop without the flags repeats the frame
+    assert (read_png_rgba8(out[4]) != read_png_rgba8(out[5])).any(), "the model did not rotate"

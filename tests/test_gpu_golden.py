@@ -46,6 +46,15 @@ def _rmse_rows(e):
     return np.sqrt((e[:, :3] ** 2).mean(axis=0))
 
 
+def _plain_rmse_low(got, want):
+    """north_star's literal bound where it is meaningful: the PLAIN per-channel RMSE over the pixels whose reference value is
+    at most 1 in every channel (there the normalisation by max(|ref|, 1) divides by 1); (rmse, pixels)."""
+    low = (np.abs(want[:, :3]) <= 1.0).all(axis=1)
+    if not low.any():
+        return 0.0, 0
+    return float(_rmse_rows(got[low].astype(np.float64) - want[low].astype(np.float64)).max()), int(low.sum())
+
+
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 def test_hip_passes_match_the_compiled_shaders(renderer, path):
     from transmission_renderer_amd.renderer import GBufferPlanes, OpaquePyramid
@@ -86,9 +95,11 @@ def test_hip_passes_match_the_compiled_shaders(renderer, path):
                 assert (got[:, 3] == 1.0).all()
                 norm = _rmse_rows(_norm_err(got, want))
                 raw = _rmse_rows(got.astype(np.float64) - want.astype(np.float64))
+                low, n_low = _plain_rmse_low(got, want)
                 print(f"[golden] {os.path.basename(path)} {key} {dt}: normalised RMSE {norm.max():.2e}, raw {raw.max():.2e}, "
-                      f"|ref| max {np.abs(want).max():.3g}")
+                      f"|ref| max {np.abs(want).max():.3g}; plain RMSE where |ref| <= 1: {low:.2e} ({n_low} of {len(want)} pixels)")
                 assert norm.max() <= 1e-4, (key, str(dt), norm)
+                assert low <= 1e-4, (key, str(dt), "plain RMSE where |ref| <= 1", low)
     finally:
         r.upload_textures([])
 
@@ -149,8 +160,10 @@ def test_hip_passes_match_the_compiled_shaders_at_4k(renderer, path):
             assert (got[:, 3] == 1.0).all()
             norm = _rmse_rows(_norm_err(got, want))
             raw = _rmse_rows(got.astype(np.float64) - want.astype(np.float64))
+            low, n_low = _plain_rmse_low(got, want)
             print(f"[golden 4K] {os.path.basename(path)} {key} {dt}: normalised RMSE {norm.max():.2e}, raw {raw.max():.2e}, "
-                  f"|ref| max {np.abs(want).max():.3g}")
+                  f"|ref| max {np.abs(want).max():.3g}; plain RMSE where |ref| <= 1: {low:.2e} ({n_low} of {len(want)} pixels)")
             assert norm.max() <= 1e-4, (key, str(dt), norm)
+            assert low <= 1e-4, (key, str(dt), "plain RMSE where |ref| <= 1", low)
         del t, o
     r.upload_textures([])

@@ -107,8 +107,14 @@ def _check_against_oracles(got32, got16, o32, o64, o16_64, what, o16_32=None, t3
     p1_all = _rmse(e32_all).max()
     p1 = np.sqrt((e32_all[~ill][:, :3] ** 2).mean(axis=0)).max()
     noise = _rmse(n32).max()      # the reference's own fp32 rounding noise on this input
+    # north_star's literal wording — plain per-channel RMSE <= 1e-4 — where it is meaningful: over the pixels whose reference
+    # value is at most 1 in every channel (the normalisation divides by 1 there), the ill-conditioned set excluded as above
+    low = (np.abs(o32[..., :3]) <= 1.0).all(axis=2) & ~ill
+    plain_low = float(np.sqrt(((got32[low][:, :3].astype(np.float64) - o32[low][:, :3].astype(np.float64)) ** 2).mean(axis=0)).max()) if low.any() else 0.0
     print(f"[parity] {what}: P0 {p0.max():.2e}  P1 rmse(gpu, oracle32) {p1:.2e} outside {int(ill.sum())} ill-conditioned "
-          f"pixels of {ill.size} ({p1_all:.2e} over all)  rmse(oracle32, oracle64) {noise:.2e}")
+          f"pixels of {ill.size} ({p1_all:.2e} over all)  rmse(oracle32, oracle64) {noise:.2e}  "
+          f"plain RMSE where |ref| <= 1: {plain_low:.2e} ({int(low.sum())} pixels)")
+    assert plain_low <= 1e-4, (what, "plain RMSE where |ref| <= 1", plain_low)
     assert p1 <= 1e-4, (what, "P1 RMSE vs oracle32", p1, "ill-conditioned pixels excluded:", int(ill.sum()))
     # ... and over ALL pixels, nothing excluded: the kernels may be no further from the pinned fp32 oracle than 1e-4 plus twice
     # that oracle's own distance from the fp64 evaluation of the same formulas (on an ill-conditioned pixel neither fp32

@@ -34,9 +34,15 @@ def rmse(got, ref, norm):
 def line(what, got, ref):
     raw, raw_max, bad = rmse(got, ref, False)
     nrm, nrm_max, _ = rmse(got, ref, True)
+    # north_star's literal bound where it is meaningful: plain RMSE over the pixels whose reference is <= 1 in every channel
+    g3, r3 = got.astype(np.float64)[..., :3].reshape(-1, 3), ref.astype(np.float64)[..., :3].reshape(-1, 3)
+    low = (np.abs(r3) <= 1.0).all(axis=1) & np.isfinite(g3).all(axis=1)
+    plain_low = float(np.sqrt(((g3[low] - r3[low]) ** 2).mean(axis=0)).max()) if low.any() else 0.0
     print(f"  {what:<38} raw rmse {max(raw):.3e} (max {raw_max:.3e})   normalised rmse {max(nrm):.3e} (max {nrm_max:.3e})"
+          f"   plain rmse where |ref| <= 1: {plain_low:.3e} ({int(low.sum())} px)"
           f"   non-finite {bad}   |ref| max {np.abs(ref[np.isfinite(ref)]).max():.3g}")
-    return {"what": what, "raw_rmse": raw, "norm_rmse": nrm, "raw_max": raw_max, "norm_max": nrm_max}
+    return {"what": what, "raw_rmse": raw, "norm_rmse": nrm, "raw_max": raw_max, "norm_max": nrm_max, "plain_rmse_ref_le_1": plain_low,
+            "pixels_ref_le_1": int(low.sum())}
 
 
 _TM = None

@@ -1,12 +1,14 @@
 """glTF-in/frame-out command line of the reference, on the MI355X path.
 
 The reference's CLI (`Opt`, src/main.rs:65-91) is
-    transmission-renderer [--scale f] [--roughness-override f] [--spotlights] [--external-model] <gltf_sample_model_name>
-and renders to a window.  Here the frame goes to a file.  Scene sources:
-    <path>.gltf / <path>.glb   a glTF 2.0 file (what `--external-model` gives the reference; the Khronos sample-model
-                               checkout the reference resolves bare names against is not in this image), placed like
-                               src/main.rs:364-368: translated to (0, 2, 0), scaled by --scale; `--backdrop other.glb`
-                               puts a second scene behind it the way the reference always loads Sponza (:342-351)
+    transmission-renderer [--scale f] [--roughness-override f] [--spotlights] [--rotate-model] [--external-model] <gltf_sample_model_name>
+and renders to a window.  Here the frame goes to a file (the last of --frames N).  Scene sources:
+    <path>.gltf / <path>.glb   a glTF 2.0 file — what `--external-model` gives the reference (the flag is accepted; a path is
+                               recognised without it), placed like src/main.rs:364-368: translated to (0, 2, 0), scaled by
+                               --scale; `--backdrop other.glb` puts a second scene behind it the way the reference always
+                               loads Sponza (:342-351)
+    <Name>                     a bare sample-model name, resolved like path_for_gltf_model (src/model_loading.rs:381-390):
+                               <--sample-models-dir>/2.0/<Name>/glTF/<Name>.gltf (the Khronos checkout is not in this image)
     meshes                     the procedural mesh scene (transmission_renderer_amd/meshes.py), same pipeline
     synthetic                  a ready-made TGB-v1 G-buffer (the benchmark's input), no geometry stage
 Pipeline (every stage on the GPU through libtr_shade.so):
@@ -46,7 +48,17 @@ def main(argv=None) -> int:
     ap.add_argument("gltf_sample_model_name", help="a .gltf / .glb path, 'meshes' or 'synthetic'")
     ap.add_argument("-s", "--scale", type=float, default=1.0, help="model scale (src/main.rs:364-368)")
     ap.add_argument("--roughness-override", type=float, default=None)
-    ap.add_argument("--spotlights", action="store_true", help="add the reference's two spotlights (src/main.rs:455-476)")
+    ap.add_argument("--spotlights", action="store_true", help="add the reference's two spotlights (src/main.rs:455-476); with "
+                    "--frames N they turn by 0.01 rad per frame (:1243-1256), rewritten in place by tr_update_lights")
+    ap.add_argument("--rotate-model", action="store_true",
+                    help="the last instance of the model buffers turns about y by -0.0025 rad per frame (src/main.rs:920-921, "
+                         "1258-1282), rewritten in place by tr_update_instances: nothing is re-uploaded or re-sized")
+    ap.add_argument("--external-model", action="store_true",
+                    help="the positional argument is a path, not a sample-model name (src/main.rs:353-357)")
+    ap.add_argument("--sample-models-dir", default=os.environ.get("GLTF_SAMPLE_MODELS", "glTF-Sample-Models"),
+                    help="where bare model names are resolved (src/model_loading.rs:381-390)")
+    ap.add_argument("--frames", type=int, default=1, help="frames to record back to back (the reference's render loop); the "
+                    "last one is written")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=2, help="point lights (the reference hard-codes 2)")
@@ -73,10 +85,17 @@ def main(argv=None) -> int:
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
     name = args.gltf_sample_model_name
-    is_file = name.lower().endswith((".gltf", ".glb"))
+    is_file = args.external_model or name.lower().endswith((".gltf", ".glb"))
     if not is_file and name not in ("synthetic", "meshes"):
-        print(f"'{name}': give a .gltf / .glb path, 'meshes' or 'synthetic' (the glTF-Sample-Models checkout the "
-              "reference resolves bare names against is not available here)", file=sys.stderr)
+        # path_for_gltf_model, src/model_loading.rs:381-390
+        resolved = os.path.join(args.sample_models_dir, "2.0", name, "glTF", name + ".gltf")
+        if not os.path.exists(resolved):
+            print(f"'{name}': give a .gltf / .glb path (--external-model), 'meshes' or 'synthetic', or point --sample-models-dir at a "
+                  f"glTF-Sample-Models checkout ({resolved} does not exist)", file=sys.stderr)
+            return 2
+        name, is_file = resolved, True
+    if args.frames < 1:
+        print("--frames must be at least 1", file=sys.stderr)
         return 2
     if is_file and not os.path.exists(name):
         print(f"{name}: no such file", file=sys.stderr)
@@ -141,8 +160,27 @@ def main(argv=None) -> int:
         # one native call per frame: culling, light assignment, demultiplex, rasteriser, opaque, mips, transmissive, tonemap
         culling = wire.CullingPushConstants.new(wire.perspective_matrix_reversed(w, h), view)
         work = r.new_frame_buffers(w, h)
-        hdr, ldr = r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs, work,
-                                  lottes=lottes)
+        instances = np.ascontiguousarray(geometry["instances"], dtype=wire.INSTANCE_DTYPE).copy()
+        model_rotation, spotlight_angle = 0.0, 0.0
+        first_spot = len(scene["lights"]) - 2
+        for frame in range(args.frames):
+            # the reference's per-frame writes into its mapped buffers (src/main.rs:1243-1261, 1316-1322): sub-range updates
+            if args.spotlights and frame > 0:
+                spotlight_angle += 0.01
+                spots = scene["lights"][first_spot:]
+                for k, l in enumerate(spots):     # Light::set_spotlight_direction(Quat::from_rotation_y(angle [+ pi]) * Z)
+                    a = np.float32(spotlight_angle + (np.pi if k else 0.0))
+                    l.spotlight_direction_and_outer_angle[0] = float(np.sin(a))
+                    l.spotlight_direction_and_outer_angle[1] = 0.0
+                    l.spotlight_direction_and_outer_angle[2] = float(np.cos(a))
+                r.update_lights(first_spot, spots)
+            if args.rotate_model and frame > 0:
+                model_rotation -= 0.0025
+                half = np.float32(model_rotation) * np.float32(0.5)
+                instances["rotation"][-1] = (0.0, np.sin(half), 0.0, np.cos(half))      # Quat::from_rotation_y
+                r.update_instances(len(instances) - 1, instances[-1:])
+            hdr, ldr = r.record_frame(scene["uniforms"], scene["push"], culling, view, wire.view_rotation_inverse(view), aabbs, work,
+                                      lottes=lottes)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if args.timings and geometry is not None:
@@ -157,7 +195,8 @@ def main(argv=None) -> int:
         np.save(args.hdr_out, hdr.cpu().numpy())
     what = "clusters + " + ("" if geometry is None else "culling + rasteriser + ") + "opaque + mips + transmission + tonemap"
     extra = "" if geometry is None else f", {len(geometry['index']) // 3} triangles in {len(geometry['primitives'])} primitives"
-    print(f"{w}x{h}, sun + {len(scene['lights'])} lights{extra}: {what} in {dt * 1e3:.2f} ms (first call, includes "
+    frames = f"{args.frames} frames of " if geometry is not None and args.frames > 1 else ""
+    print(f"{w}x{h}, sun + {len(scene['lights'])} lights{extra}: {frames}{what} in {dt * 1e3:.2f} ms (first call, includes "
           f"launch overheads) -> {args.out}")
     r.close()
     return 0

@@ -1366,6 +1366,8 @@ tr_status rasterize_impl(tr_context* ctx, const void* draw_counts, const void* c
     fill_two_layers(ctx, draws, targets, two);
     // The visibility buffers are zero on entry: filled once after (re)allocation, and every resolve zeroes the words its
     // frame set (raster_resolve_body).  Per frame only the two tile coverage maps are cleared (260 KB at 4K).
+    // (the flag describes the context when the call is ENQUEUED — for a captured frame: at capture time.  133 MB at 4K is
+    //  not a clear to record unconditionally; the header says what a replay must not follow)
     if (!ctx->vis_clean) TR_HIP(ctx, zero_fill(ctx->d_vis[0], 2u * npix * 8u, stream));
     ctx->vis_clean = false;   // (until this frame's resolve is enqueued)
     if (!(fused_demux && ctx->cover_cleared))   // (the frame recorder's first launch has zeroed them for its own call)
@@ -2264,7 +2266,8 @@ tr_status record_frame(tr_context* ctx, const tr_frame_desc* f, void* stream, zo
         // against the unfused passes over many frames.  (The timed frame launches every pass on its own, below.)
         hipStream_t s_ = (hipStream_t)stream;
         TR_HIP(ctx, hipSetDevice(ctx->device));
-        if (!ctx->counts_clean) TR_HIP(ctx, zero_fill(ctx->d_instance_counts, sizeof(uint32_t) * ctx->num_primitives, s_));
+        // (a captured frame always zeroes its counts: a replay may follow a direct tr_frustum_culling that left them set)
+        if (!ctx->counts_clean || stream_is_capturing(s_)) TR_HIP(ctx, zero_fill(ctx->d_instance_counts, sizeof(uint32_t) * ctx->num_primitives, s_));
         ctx->counts_clean = false;
         tr_cull_params cp;
         cp.pc = *f->culling;

@@ -180,33 +180,55 @@ class ModelBuffers:
         }
 
 
-def make_mesh_scene(extra_instances: bool = True) -> dict:
-    """A small scene in front of the default camera (eye (0,3,1) looking down -z, pitched -15 deg): a floor, opaque
-    and transmissive spheres and boxes (one transmissive object in front of opaque ones, one behind), an
-    alpha-clipped quad, and objects outside the frustum / behind the camera for the culling pass.
-    Material ids refer to synthetic.make_materials() (16 entries); draw buffers: 0 opaque, 1 alpha clip,
-    2 transmission, 3 transmission + alpha clip."""
-    mb = ModelBuffers()
+def mesh_scene_parts(extra_instances: bool = True, room: bool = False) -> list:
+    """The primitives of make_mesh_scene as (mesh, draw_buffer_index, instances) in model-buffer order."""
     S = Similarity
     q = quat_from_axis_angle
-    mb.add_primitive(plane(8.0, 8.0, cells=4, uv_repeat=4.0), 0, [(S(np.array([0, 0.6, -3.0], f32)), 3)])
+    parts = []
+    if room:
+        # A closed room around the scene, loaded FIRST like the reference's Sponza backdrop (src/main.rs:342-351), and three
+        # partitions between its back wall and the objects, far to near: a pixel of the objects' region is covered by the
+        # back wall, up to three partitions and the object in front — depth complexity 3 to 5, later draws nearer (the order
+        # in which every fragment survives the depth comparison: the rasteriser's worst case, readme.md:74).
+        wall = plane(1.0, 1.0, cells=2, uv_repeat=4.0)
+        up, half = np.array([1.0, 0.0, 0.0], f32), np.pi / 2
+        parts.append((wall, 0, [(S(np.array([0.0, 3.0, -9.0], f32), 24.0, q(up, half)), 9),                        # back wall, facing +z
+                                (S(np.array([0.0, 9.0, -3.0], f32), 24.0, q(up, np.pi)), 11),                      # ceiling, facing down
+                                (S(np.array([-9.0, 3.0, -3.0], f32), 24.0, q([0.0, 0.0, 1.0], -half)), 12),        # left wall, facing +x
+                                (S(np.array([9.0, 3.0, -3.0], f32), 24.0, q([0.0, 0.0, 1.0], half)), 13),          # right wall, facing -x
+                                (S(np.array([0.0, 3.0, 7.0], f32), 24.0, q(up, -half)), 9)]))                      # behind the camera (culled)
+        parts.append((wall, 0, [(S(np.array([0.0, 2.6, -7.5], f32), 9.0, q(up, half)), 5),
+                                (S(np.array([0.4, 2.2, -6.5], f32), 7.0, q(up, half)), 15),
+                                (S(np.array([-0.3, 1.9, -5.6], f32), 5.0, q(up, half)), 0)]))
+    parts.append((plane(8.0, 8.0, cells=4, uv_repeat=4.0), 0, [(S(np.array([0, 0.6, -3.0], f32)), 3)]))
     sphere = uv_sphere(1.0, 20, 10)
     inst = [(S(np.array([-0.9, 1.6, -2.6], f32), 0.55), 1), (S(np.array([1.1, 1.4, -3.4], f32), 0.7, q([0, 1, 0], 0.7)), 6)]
     if extra_instances:   # culled ones: far left of the frustum, behind the camera
         inst += [(S(np.array([-30.0, 1.0, -3.0], f32), 0.5), 1), (S(np.array([0.0, 3.0, 6.0], f32), 0.8), 6)]
-    mb.add_primitive(sphere, 0, inst)
-    mb.add_primitive(box(0.5, 0.5, 0.5), 0, [(S(np.array([0.2, 1.1, -4.2], f32), 0.9, q([0.3, 1, 0.1], 0.9)), 8)])
+    parts.append((sphere, 0, inst))
+    parts.append((box(0.5, 0.5, 0.5), 0, [(S(np.array([0.2, 1.1, -4.2], f32), 0.9, q([0.3, 1, 0.1], 0.9)), 8)]))
     # transmissive: a sphere in front of the box and the far sphere, a slab intersecting the floor
     tinst = [(S(np.array([0.15, 1.7, -1.9], f32), 0.6), 4), (S(np.array([-1.6, 1.2, -3.9], f32), 0.45, q([1, 0, 0], 0.4)), 10)]
     if extra_instances:
         tinst += [(S(np.array([0.0, 40.0, -3.0], f32), 0.5), 4)]    # above the frustum
-    mb.add_primitive(uv_sphere(1.0, 24, 12), 2, tinst)
-    mb.add_primitive(box(0.7, 0.4, 0.08), 2, [(S(np.array([1.3, 1.0, -2.2], f32), 1.0, q([0, 1, 0], -0.5)), 14)])
+    parts.append((uv_sphere(1.0, 24, 12), 2, tinst))
+    parts.append((box(0.7, 0.4, 0.08), 2, [(S(np.array([1.3, 1.0, -2.2], f32), 1.0, q([0, 1, 0], -0.5)), 14)]))
     # alpha clipped (needs a textured material; ids chosen by the caller's material table)
-    mb.add_primitive(plane(1.6, 1.6, cells=1, uv_repeat=1.0), 1,
-                     [(S(np.array([-0.2, 1.5, -3.0], f32), 1.0, q([1, 0, 0], 1.2)), 2)])
-    mb.add_primitive(plane(1.2, 1.2, cells=1, uv_repeat=2.0), 3,
-                     [(S(np.array([0.9, 2.2, -2.8], f32), 1.0, q([1, 0, 0.2], 1.35)), 7)])
+    parts.append((plane(1.6, 1.6, cells=1, uv_repeat=1.0), 1, [(S(np.array([-0.2, 1.5, -3.0], f32), 1.0, q([1, 0, 0], 1.2)), 2)]))
+    parts.append((plane(1.2, 1.2, cells=1, uv_repeat=2.0), 3, [(S(np.array([0.9, 2.2, -2.8], f32), 1.0, q([1, 0, 0.2], 1.35)), 7)]))
     if extra_instances:   # a primitive whose only instance is culled: no draw at all
-        mb.add_primitive(box(0.3, 0.3, 0.3), 0, [(S(np.array([50.0, 0.0, -3.0], f32), 1.0), 5)])
+        parts.append((box(0.3, 0.3, 0.3), 0, [(S(np.array([50.0, 0.0, -3.0], f32), 1.0), 5)]))
+    return parts
+
+
+def make_mesh_scene(extra_instances: bool = True, room: bool = False) -> dict:
+    """A small scene in front of the default camera (eye (0,3,1) looking down -z, pitched -15 deg): a floor, opaque
+    and transmissive spheres and boxes (one transmissive object in front of opaque ones, one behind), an
+    alpha-clipped quad, and objects outside the frustum / behind the camera for the culling pass.
+    Material ids refer to synthetic.make_materials() (16 entries); draw buffers: 0 opaque, 1 alpha clip,
+    2 transmission, 3 transmission + alpha clip.  room=True: the same objects inside a closed room with partitions behind
+    them (mesh_scene_parts): every pixel covered, depth complexity 3 to 5 over most of the frame."""
+    mb = ModelBuffers()
+    for mesh, draw_buffer, instances in mesh_scene_parts(extra_instances, room):
+        mb.add_primitive(mesh, draw_buffer, instances)
     return mb.finish()

@@ -91,6 +91,7 @@ class Compositor:
         # device, which RCCL refuses) is staged through host memory by the fallbacks below
         self.host_staged = world > 1 and renderer is not None and str(getattr(renderer, "device", "cpu")) != "cpu" \
             and dist.get_backend(group) == "gloo"
+        self._halo_pending = []         # confirm="late": (word, collective, event, halo, margin, frame, lag) of the frames not yet judged
         self.fell_back = False          # the library's RCCL communicator was wanted and could not be made
         self.rccl_ranks = None          # what RCCL itself reports for the library's communicator (tr_comm_query)
         if (world > 1 or single_rank_comm) and renderer is not None and prefer_library and not self.host_staged:
@@ -140,7 +141,7 @@ class Compositor:
     halo_shrink_factor = 0.75  # the probe: taps checked against this fraction of the halo while the whole halo is still exchanged
     halo_clean_frames = 0
     halo_inexact_frames = 0    # confirm="late" only: composited frames whose taps turned out to have left the halo
-    _halo_pending = None       # confirm="late": (device word, collective, halo, window margin) of the frame not yet judged
+    _halo_frame = 0            # confirm="late": frames submitted so far
 
     def halo_window_margin(self, halo: int) -> int:
         """The rows around its band a rank's taps are checked against this frame: the halo, or — once in a while, after
@@ -167,19 +168,42 @@ class Compositor:
         self.halo_clean_frames += 1
         return True
 
-    def confirm_halo(self) -> bool:
-        """confirm="late": reads the previous frame's excess word — its collective was enqueued behind that frame's passes,
-        in front of its composite — and judges it.  True: that frame was exact (or there is none to judge)."""
-        if self._halo_pending is None:
-            return True
-        word, work, halo, margin = self._halo_pending
-        self._halo_pending = None
-        if work is not None:
-            work.wait()
-        ok = self.halo_verdict(int(word.item()), halo, margin)
-        if not ok:
-            self.halo_inexact_frames += 1
-        return ok
+    def confirm_halo(self, drain: bool = True) -> bool:
+        """confirm="late": judges the frames whose excess word is due.  A word that was reduced on the host (gloo, the CPU
+        tests) is due when the next frame starts.  A word on the device was copied, behind its all-reduce, into pinned host
+        memory with an event behind the copy: it is due TWO frames later — by then the copy has landed, so reading it waits
+        for nothing (round 5 read the device word one frame late with .item(): a host wait for the frame in flight, every
+        frame) — and the same frame on every rank, which the halo's size must be.  drain=True (the default: after a loop's
+        last frame) judges everything outstanding.  True: every frame judged by this call was exact (or there was none)."""
+        ok_all = True
+        while self._halo_pending and (drain or self._halo_pending[0][5] + self._halo_pending[0][6] <= self._halo_frame + 1):
+            word, work, event, halo, margin, _, _ = self._halo_pending.pop(0)
+            if work is not None:
+                work.wait()
+            if event is not None:
+                event.synchronize()
+            ok = self.halo_verdict(int(word.item()), halo, margin)
+            if not ok:
+                self.halo_inexact_frames += 1
+            ok_all = ok_all and ok
+        return ok_all
+
+    def _halo_late_submit(self, word: torch.Tensor, halo: int, margin: int) -> None:
+        """Enqueues the all-rank maximum of a frame's excess word; nothing waits (see confirm_halo)."""
+        self._halo_frame += 1
+        if self.host_staged:
+            word = word.cpu()          # (the rehearsal's host-side backend reduces host memory: this read waits for the passes)
+        work = dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group, async_op=True) if self.world > 1 else None
+        if word.is_cuda:
+            if work is not None:
+                work.wait()            # (orders the current STREAM behind the collective; the host goes on)
+            host = torch.empty(1, dtype=word.dtype, pin_memory=True)
+            host.copy_(word, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            self._halo_pending.append((host, None, event, halo, margin, self._halo_frame, 2))
+        else:
+            self._halo_pending.append((word, work, None, halo, margin, self._halo_frame, 1))
 
     def exchange_halo(self, level_rows: torch.Tensor, rows_per_rank: int, halo: int) -> None:
         """level_rows: (total_rows, W, C) contiguous, a whole pyramid level of which this rank has written its band; on
@@ -332,9 +356,10 @@ def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid,
     confirm = "now": the frame's excess word is read (a device drain and a small all-reduce) before the composite, and a
     frame whose taps left the halo is redone — every frame returned is exact.  confirm = "late" (a renderer that hands out
     the word on the device: tap_window_excess_word): the word's all-reduce is enqueued, the composite follows at once, and
-    the verdict is read when the NEXT frame starts (compositor.confirm_halo(); nothing waits): a frame whose taps left the
-    halo has then been composited as it was — compositor.halo_inexact_frames counts them — and the following frames
-    exchange more rows.  Either way a halo that has been wide enough for compositor.halo_shrink_after frames is probed:
+    the verdict is read later — a word reduced on the device two frames later, from pinned host memory behind an event, so
+    that no host call of the frame loop waits for the GPU; a word reduced on the host when the next frame starts
+    (compositor.confirm_halo) —: a frame whose taps left the halo has then been composited as it was —
+    compositor.halo_inexact_frames counts them — and the following frames exchange more rows.  Either way a halo that has been wide enough for compositor.halo_shrink_after frames is probed:
     one frame checks its taps against three quarters of it, and the exchange shrinks if they fit.
     """
     world, rank = compositor.world, compositor.rank
@@ -344,7 +369,7 @@ def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid,
     mine = rect[3] > rect[1]     # (a band can be empty when the height is far from a multiple of world * 4)
     if mine:
         renderer.shade_opaque(opaque, uniforms, push, hdr, pyramid, rect)
-    compositor.confirm_halo()      # (confirm="late": the previous frame's verdict; it may widen the halo used below)
+    compositor.confirm_halo(drain=False)   # (confirm="late": the verdicts that are due; they may widen the halo used below)
     halo = compositor.halo_rows
     use_halo = (world > 1 and exchange == "halo" and fw % 4 == 0 and fh % 4 == 0 and pyramid.levels >= 4
                 and 0 < halo and halo + rows < fh)     # (a halo that reaches every row is the gather)
@@ -373,10 +398,7 @@ def record_sharded(renderer, opaque, transmissive, uniforms, push, hdr, pyramid,
         if late:
             if word is None:
                 word = torch.zeros(1, dtype=torch.int64, device=renderer.device)
-            if compositor.host_staged:
-                word = word.cpu()          # (the rehearsal's host-side backend reduces host memory: this read waits for the passes)
-            work = dist.all_reduce(word, op=dist.ReduceOp.MAX, group=compositor.group, async_op=True) if world > 1 else None
-            compositor._halo_pending = (word, work, halo, margin)
+            compositor._halo_late_submit(word, halo, margin)
             if composite:
                 compositor.allgather_rows(hdr)
             return
