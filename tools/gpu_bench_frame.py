@@ -12,9 +12,9 @@ from transmission_renderer_amd.renderer import TransmissionRenderer
 name = sys.argv[1] if len(sys.argv) > 1 else "meshes"
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160)
 r = TransmissionRenderer(0)
-scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False, textured=(name == "meshes"))
-if name in ("meshes", "plain"):   # (plain: the same geometry with untextured materials)
-    geometry = meshes.make_mesh_scene(extra_instances=True)
+scene = synthetic.make_scene(w, h, num_point_lights=2, with_gbuffer=False, textured=(name in ("meshes", "room", "room_near_first")))
+if name in ("meshes", "plain", "room", "room_near_first"):   # (plain: the same geometry with untextured materials; room: inside a closed room)
+    geometry = meshes.make_mesh_scene(extra_instances=True, room={"room": 1, "room_near_first": 2}.get(name, False))
     scene["materials"][2].alpha_clipping_cutoff = 0.75
     scene["materials"][7].alpha_clipping_cutoff = 0.6
 else:

@@ -180,7 +180,7 @@ class ModelBuffers:
         }
 
 
-def mesh_scene_parts(extra_instances: bool = True, room: bool = False) -> list:
+def mesh_scene_parts(extra_instances: bool = True, room=False) -> list:
     """The primitives of make_mesh_scene as (mesh, draw_buffer_index, instances) in model-buffer order."""
     S = Similarity
     q = quat_from_axis_angle
@@ -218,10 +218,12 @@ def mesh_scene_parts(extra_instances: bool = True, room: bool = False) -> list:
     parts.append((plane(1.2, 1.2, cells=1, uv_repeat=2.0), 3, [(S(np.array([0.9, 2.2, -2.8], f32), 1.0, q([1, 0, 0.2], 1.35)), 7)]))
     if extra_instances:   # a primitive whose only instance is culled: no draw at all
         parts.append((box(0.3, 0.3, 0.3), 0, [(S(np.array([50.0, 0.0, -3.0], f32), 1.0), 5)]))
+    if room == 2:   # the same geometry drawn NEAR TO FAR (objects, partitions, walls): the order a depth-sorting host submits
+        parts = [(m, d, list(reversed(i))) for m, d, i in reversed(parts)]
     return parts
 
 
-def make_mesh_scene(extra_instances: bool = True, room: bool = False) -> dict:
+def make_mesh_scene(extra_instances: bool = True, room=False) -> dict:
     """A small scene in front of the default camera (eye (0,3,1) looking down -z, pitched -15 deg): a floor, opaque
     and transmissive spheres and boxes (one transmissive object in front of opaque ones, one behind), an
     alpha-clipped quad, and objects outside the frustum / behind the camera for the culling pass.
