@@ -11,7 +11,9 @@
 #define TR_PROBE_GRID(bpx)
 #endif
 #include "tr_kernels.h"
+#ifdef TR_TUNING_ENV   // tools/build_variant.py builds only: the loader / consumer variant of the plane pass (measured slower: docs/TRIED_r06.md)
 #include "tr_lc_kernels.h"
+#endif
 #include "tr_cluster_kernels.h"
 #include "tr_geometry_kernels.h"
 #include "tr_raster_kernels.h"
@@ -1747,12 +1749,14 @@ tr_status tr_shade_transmission(tr_context* ctx, const tr_gbuffer* g, const tr_u
         const bool half = format == TR_FORMAT_RGBA16F;
         if (ctx->any_textured) {
             launch_textured<true>(ctx, L, half, grid, block, stream);
+#ifdef TR_TUNING_ENV
         } else if (ctx->lc_wgs_per_cu != 0u && !L.vis && !L.tile_cover) {
             // loader / consumer workgroups (tr_lc_kernels.h): G persistent workgroups per XCD
             L.fp.j_step = std::max(1u, ctx->num_cus / 8u * ctx->lc_wgs_per_cu);
             const dim3 lc_grid(8u * L.fp.j_step), lc_block(kLcWaves * 64u);
             if (half) hipLaunchKernelGGL(shade_lc_kernel<uint2>, lc_grid, lc_block, 0, stream, L);
             else hipLaunchKernelGGL(shade_lc_kernel<float4>, lc_grid, lc_block, 0, stream, L);
+#endif
         } else {
             launch_shade<true, kTexNone>(L, half, grid, block, stream);
         }
