@@ -21,7 +21,9 @@ N = 1    (run_single) A step shades the frame as `--split P` row bands (default 
            configs.all_transmissive  every material transmission_factor 1 (what DragonAttenuation is)
          with us, Mpixels/s and the roofline fraction on 52 B/px and on SURVEY 8d's 60 B/px, and
            single_stream             one whole-frame tr_shade_transmission call per frame on one stream (rounds 1-2's step)
-           frame_pipeline            tr_record_frame (culling -> rasteriser -> opaque -> mips -> transmissive -> tonemap)
+           frame_pipeline            tr_record_frame (culling -> rasteriser -> opaque -> mips -> transmissive -> tonemap), its
+                                     launches one by one (`kernels`), and the same frame under OVERDRAW (`overdraw`: the
+                                     objects in a closed room, 3 fragments per pixel, later draws nearer)
          roofline.traffic / roofline.valu: three short child runs of this script (`--pmc-probe`) under rocprofv3 --pmc
          (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU ...: separate passes, kernel trace only).
 python bench.py --gpus N   starts by itself: with WORLD_SIZE unset and N > 1 it spawns N child processes (one per
@@ -36,6 +38,11 @@ N > 1    (run_rank) BASELINE config 4 / north_star: ONE 3840x2160 frame cut into
          single-GPU time measured in the same run and both speed-ups over it, and (`full_pipeline_8k`) the 8K frame of
          BASELINE config 5 through the sharded full pipeline — the one workload where sharding can pay.
          `--scaling weak` keeps round 1's mode (every rank shades 8.29 Mpx of a frame that grows with N).
+         The line says which backend carried the composite (`composite_backend`, `rccl_ranks` = ncclCommCount of the
+         library's communicator, `composite_fell_back`); `--require-rccl` exits with code 3 instead of measuring a
+         fallback to torch.distributed.  `--one-device` rehearses this whole path on ONE GPU: every rank on cuda:0, a gloo
+         process group, exchanges staged through host memory (RCCL refuses two ranks on one device) — the code path on
+         device buffers, not the links (tests/test_gpu_two_ranks_one_device.py).
 
 Prints ONE JSON line on rank 0.
 """
