@@ -356,6 +356,22 @@ def run_profiled(cmd, env, timeout):
     return p.returncode, err
 
 
+def measure_pattern_ceiling():
+    """roofline.pattern_ceiling: transmission_renderer_amd/pattern_ceiling --brief (tools/ubench/pattern_ceiling.hip, built by
+    __graft_entry__.build()) — a stand-alone HIP program that issues the pass's memory pattern on the pass's own tile numbering
+    with NO shading arithmetic (two plane rows, ids, four 16-byte taps per pixel, a LUT line, the store; cold inputs): what
+    this access pattern attains on this box in the same launch shapes.  None when the binary is missing or fails."""
+    exe = os.path.join(ROOT, "transmission_renderer_amd", "pattern_ceiling")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "--brief"], capture_output=True, text=True, timeout=120)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if r.returncode == 0 and line else None
+    except Exception:
+        return None
+
+
 def measure_pmc(args):
     """Counters of the transmissive kernel, measured NOW: three child runs of this script (`--pmc-probe`: PROBE_LAUNCHES
     whole-frame launches each of the headline scene, the all-transmissive scene and config 3, one stream) under
@@ -991,6 +1007,7 @@ def run_single(args) -> int:
             frame_pipeline = dict(frame_pipeline or {}, error=f"{type(e).__name__}: {e}")
 
     pmc = None if args.no_traffic else measure_pmc(args)          # child processes; the GPU is idle here
+    ceiling = None if args.no_traffic else measure_pattern_ceiling()   # (a child process too)
     achieved = pixels * ALGORITHMIC_BYTES_PER_PIXEL / (ms_per_step * 1e-3) / 1e9
     out = {
         "metric": "shaded Mpixels/sec, 4K transmissive pass (fragment_transmission over a synthetic TGB-v1 G-buffer)",
@@ -1037,6 +1054,22 @@ def run_single(args) -> int:
         "launch_sync_p50_ms": round(float(np.percentile(sync_ms, 50)), 4),
         "launch_log": launch_log,
     }
+    if ceiling is not None:
+        # the pass against what its own memory pattern attains with no arithmetic at all, same run, same launch shape
+        disp, same = ceiling["pattern_taps_displaced_48px_us"], ceiling["pattern_taps_not_displaced_us"]
+        frac_of = lambda us: round(pixels * ALGORITHMIC_BYTES_PER_PIXEL / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)   # noqa: E731
+        out["roofline"]["pattern_ceiling"] = dict(
+            ceiling, bytes_per_pixel=ALGORITHMIC_BYTES_PER_PIXEL,
+            attainable_frac_of_peak={"taps_displaced_48px": frac_of(disp["two_bands"]), "taps_not_displaced": frac_of(same["two_bands"])},
+            pass_time_over_pattern_time={"two_bands": [round(ms_per_step * 1e3 / disp["two_bands"], 3), round(ms_per_step * 1e3 / same["two_bands"], 3)],
+                                         "one_call": [round(single_ms * 1e3 / disp["one_call"], 3), round(single_ms * 1e3 / same["one_call"], 3)]},
+            note="tools/ubench/pattern_ceiling.hip --brief, run behind the timed region: an ARITHMETIC-FREE kernel issuing the pass's "
+                 "requests (two non-temporal plane rows, the id row, four gathered 16-byte texel pairs per pixel — displaced from "
+                 "the pixel by a smooth field of up to 48 px, or not at all: the scene's refraction lies between —, a LUT line, the "
+                 "8-byte store) on the pass's tile numbering, 8 waves per SIMD, cold inputs, as two bands on two streams and as one "
+                 "call per frame.  attainable_frac_of_peak = 52 B/px x pixels / its two-band time / 8 TB/s: what this access pattern "
+                 "reaches on this box with nothing to compute; pass_time_over_pattern_time [vs displaced, vs not displaced] <= 1: "
+                 "the pass, with all its arithmetic, is no slower than its own memory pattern")
     tr_ = None
     if pmc is not None:
         c = pmc["headline"]

@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
     }
 }
 
+static bool g_quiet = false;           // --brief: run() prints nothing, main() prints one JSON line
+static double g_last_us = 0.0, g_last_in_flight_kb = 0.0, g_last_wait_us = 0.0;
 template <int LDS_BYTES>
 static void run(const char* name, params p, int waves_per_simd, int sets, void** pos, void** nrm, void** ids, void** pyr, void** out, double ticks_per_us,
                 int bands = 1) {
@@ -158,6 +161,10 @@ static void run(const char* name, params p, int waves_per_simd, int sets, void**
     const double all_bytes = read_bytes + px * 8.0;
     const double lat_us = ticks / cnt / ticks_per_us;
     const double in_flight_per_cu = read_bytes / 256.0 / us * lat_us;
+    g_last_us = us;
+    g_last_in_flight_kb = in_flight_per_cu / 1024.0;
+    g_last_wait_us = lat_us;
+    if (g_quiet) return;
     if (p.taps == 0)   // (the skeleton's loads are consumed straight behind the wait: the compiler's own wait precedes the timed one)
         printf("%-34s %7.1f us  %5.2f TB/s on %.0f B/px\n", name, us, all_bytes / us / 1e6, all_bytes / px);
     else
@@ -173,7 +180,9 @@ __global__ void tick_kernel(unsigned long long* out) {
     if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; out[2] = (unsigned long long)x; }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool brief = argc > 1 && std::string(argv[1]) == "--brief";
+    g_quiet = brief;
     const uint32_t W = 3840, H = 2160;
     const size_t px = (size_t)W * H;
     const int sets = 4;
@@ -199,6 +208,25 @@ int main() {
     hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, 0, d);
     CHECK(hipMemcpy(h, d, 24, hipMemcpyDeviceToHost));
     const double ticks_per_us = (double)h[0] / ((double)h[1] / 100.0);
+    if (brief) {
+        // bench.py's roofline.pattern_ceiling: the four figures the pass is held against, one JSON line
+        double r[6], kb[2], wait[2];
+        p.fma = 0; p.tap_mode = 0;
+        p.taps = 0; p.scatter = 48;
+        run<1024>("", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2); r[0] = g_last_us;
+        run<1024>("", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 1); r[1] = g_last_us;
+        p.taps = 4;
+        run<1024>("", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2); r[2] = g_last_us; kb[0] = g_last_in_flight_kb; wait[0] = g_last_wait_us;
+        run<1024>("", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 1); r[3] = g_last_us;
+        p.scatter = 0;
+        run<1024>("", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2); r[4] = g_last_us; kb[1] = g_last_in_flight_kb; wait[1] = g_last_wait_us;
+        run<1024>("", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 1); r[5] = g_last_us;
+        printf("{\"planes_and_store_only_us\": {\"two_bands\": %.1f, \"one_call\": %.1f}, "
+               "\"pattern_taps_displaced_48px_us\": {\"two_bands\": %.1f, \"one_call\": %.1f, \"reads_in_flight_per_cu_kb\": %.1f, \"loads_outstanding_us\": %.2f}, "
+               "\"pattern_taps_not_displaced_us\": {\"two_bands\": %.1f, \"one_call\": %.1f, \"reads_in_flight_per_cu_kb\": %.1f, \"loads_outstanding_us\": %.2f}}\n",
+               r[0], r[1], r[2], r[3], kb[0], wait[0], r[4], r[5], kb[1], wait[1]);
+        return 0;
+    }
     printf("s_memtime: %.1f ticks per us\n", ticks_per_us);
 
     p.scatter = 48; p.fma = 0;
