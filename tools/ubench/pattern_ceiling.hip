@@ -30,6 +30,8 @@ struct params {
     const f4v* pos; const f4v* nrm; const uint32_t* ids; const u4v* pyr; const f4v* lut; u2v* out;
     uint32_t width, height, tiles_x, ntiles, j_step, taps, fma, scatter;   // scatter: largest tap displacement in pixels
     uint32_t tap_mode;     // 0: texel-aligned 16-byte pairs (the pass); 1: the same pairs forced to 16-byte alignment; 2: 8-byte loads, one texel each
+    uint32_t ahead;        // 1: the NEXT tile's plane rows and ids are requested before this tile's loads are waited for (two tiles of a
+                           // wave in flight: what more bytes in flight per CU are worth to the pattern itself)
     uint32_t tile_begin;   // first block tile of this launch's row band (two bands on two streams: bench.py's step)
     unsigned long long* wait_ticks; unsigned long long* waits;
 };
@@ -42,13 +44,45 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
     const uint32_t xcd = blockIdx.x & 7u, per = p.ntiles >> 3, rem = p.ntiles & 7u;
     const uint32_t band_start = xcd * per + (xcd < rem ? xcd : rem), band_len = per + (xcd < rem ? 1u : 0u);
     unsigned long long waited = 0, n = 0;
-    for (uint32_t j = blockIdx.x >> 3; j < band_len * 4u; j += p.j_step) {
-        const uint32_t tile = p.tile_begin + band_start + (j >> 2), tyi = tile / p.tiles_x, txi = (tile - tyi * p.tiles_x) * 4u + (j & 3u);
-        const uint32_t px = min(txi * 16u + lx, p.width - 1u), py = min(tyi * 4u + ly, p.height - 1u);
+    auto pixel_of = [&](uint32_t j, uint32_t& px, uint32_t& py, uint32_t& txi, uint32_t& tyi) {
+        const uint32_t tile = p.tile_begin + band_start + (j >> 2);
+        tyi = tile / p.tiles_x;
+        txi = (tile - tyi * p.tiles_x) * 4u + (j & 3u);
+        px = min(txi * 16u + lx, p.width - 1u);
+        py = min(tyi * 4u + ly, p.height - 1u);
+    };
+    f4v a_next = {0.f, 0.f, 0.f, 0.f}, b_next = {0.f, 0.f, 0.f, 0.f};
+    uint32_t id_next = 0u;
+    const uint32_t j0 = blockIdx.x >> 3;
+    if (p.ahead && j0 < band_len * 4u) {
+        uint32_t px, py, txi, tyi;
+        pixel_of(j0, px, py, txi, tyi);
         const uint32_t pix = py * p.width + px;
-        const f4v a = __builtin_nontemporal_load(p.pos + pix);
-        const f4v b = __builtin_nontemporal_load(p.nrm + pix);
-        const uint32_t id = p.ids[pix];
+        a_next = __builtin_nontemporal_load(p.pos + pix);
+        b_next = __builtin_nontemporal_load(p.nrm + pix);
+        id_next = p.ids[pix];
+    }
+    for (uint32_t j = j0; j < band_len * 4u; j += p.j_step) {
+        uint32_t px, py, txi, tyi;
+        pixel_of(j, px, py, txi, tyi);
+        const uint32_t pix = py * p.width + px;
+        f4v a, b;
+        uint32_t id;
+        if (p.ahead) {
+            a = a_next; b = b_next; id = id_next;           // (requested a tile ago)
+            if (j + p.j_step < band_len * 4u) {
+                uint32_t qx, qy, tx2, ty2;
+                pixel_of(j + p.j_step, qx, qy, tx2, ty2);
+                const uint32_t q = qy * p.width + qx;
+                a_next = __builtin_nontemporal_load(p.pos + q);
+                b_next = __builtin_nontemporal_load(p.nrm + q);
+                id_next = p.ids[q];
+            }
+        } else {
+            a = __builtin_nontemporal_load(p.pos + pix);
+            b = __builtin_nontemporal_load(p.nrm + pix);
+            id = p.ids[pix];
+        }
         // the taps: displaced from the pixel by a field that varies smoothly over the screen (neighbouring pixels refract
         // alike: adjacent lanes fetch adjacent texels, as in the pass; `scatter` is the field's amplitude in pixels) and jumps
         // at "material" borders every 96 pixels; pairs of rows like the sampler's (row, row + 1) of two levels
@@ -80,7 +114,8 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
         // the LUT line: 258 entries of 16 bytes per material, indexed by n.v — smooth over the screen like the taps
         const f4v line = taps ? p.lut[(id & 15u) * 260u + ((uint32_t)(128.0f + 120.0f * __sinf(fx * 0.011f - fy * 0.005f)) & 255u)] : f4v{0.f, 0.f, 0.f, 0.f};
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.ahead) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // (everything but the next tile's three plane loads: they are the youngest)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         waited += __builtin_amdgcn_s_memtime() - t0;
         ++n;
         float x = a.x + b.x + line.x, y = a.y + b.y + line.y, z = a.z + b.z + a.w + b.w + line.z + line.w;
@@ -165,7 +200,7 @@ static void run(const char* name, params p, int waves_per_simd, int sets, void**
     g_last_in_flight_kb = in_flight_per_cu / 1024.0;
     g_last_wait_us = lat_us;
     if (g_quiet) return;
-    if (p.taps == 0)   // (the skeleton's loads are consumed straight behind the wait: the compiler's own wait precedes the timed one)
+    if (p.taps == 0 || p.ahead)   // (the skeleton's loads are consumed straight behind the wait, and with a tile requested ahead the compiler's own counted wait precedes the timed one)
         printf("%-34s %7.1f us  %5.2f TB/s on %.0f B/px\n", name, us, all_bytes / us / 1e6, all_bytes / px);
     else
         printf("%-34s %7.1f us  %5.2f TB/s on %.0f B/px  wait %6.0f ticks = %5.2f us  reads in flight per CU %6.1f KB\n", name, us,
@@ -266,6 +301,17 @@ int main(int argc, char** argv) {
     p.scatter = 0;
     run<1024>("... tap scatter +-0 px, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
     p.scatter = 48;
+    printf("-- two tiles of a wave in flight (the next tile's plane rows requested before this tile's wait), 8 waves per SIMD\n");
+    p.ahead = 1;
+    p.taps = 0;
+    run<1024>("planes + store only, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    p.taps = 4;
+    run<1024>("the pass's pattern, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024>("the pass's pattern, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+    p.fma = 64;
+    run<1024>("... with 192 fma per pixel, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    p.fma = 0;
+    p.ahead = 0;
     printf("-- the same at 8 waves per SIMD with dependent fma per pixel behind the wait (3 chains x N)\n");
     for (uint32_t f : {16u, 32u, 64u, 96u, 128u}) {
         p.fma = f;
