@@ -943,28 +943,7 @@ tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_
     ctx->stage_alights.resize(alloc);
     std::memset(ctx->stage_lights.data(), 0, sizeof(tr_dlight) * alloc);
     std::memset(ctx->stage_alights.data(), 0, sizeof(tr_alight) * alloc);
-    for (uint32_t i = 0; i < count; ++i) {
-        const tr_light& s = lights_host[i];
-        tr_dlight& d = ctx->stage_lights[i];
-        for (int k = 0; k < 3; ++k) {
-            d.pos[k] = s.position_and_spotlight_epsilon[k];
-            d.colour[k] = s.colour_emission_and_falloff_distance_sq[k];
-            d.spot_dir[k] = s.spotlight_direction_and_outer_angle[k];
-        }
-        const float outer = s.spotlight_direction_and_outer_angle[3];
-        d.is_spot = outer != 0.0f ? 1u : 0u;  // Light::is_a_spotlight, shared-structs/src/lib.rs:125-127
-        d.cos_outer = std::cos(outer);
-        d.inv_spot_epsilon = 1.0f / s.position_and_spotlight_epsilon[3];
-        tr_alight& a = ctx->stage_alights[i];
-        for (int k = 0; k < 3; ++k) {
-            a.pos[k] = s.position_and_spotlight_epsilon[k];
-            a.spot_dir[k] = s.spotlight_direction_and_outer_angle[k];
-        }
-        a.falloff_distance_sq = s.colour_emission_and_falloff_distance_sq[3];
-        a.is_spot = d.is_spot;
-        a.cos_angle = std::cos(outer);   // ClusterAabb::cull_spotlight, shared-structs/src/lib.rs:312
-        a.sin_angle = std::sin(outer);
-    }
+    for (uint32_t i = 0; i < count; ++i) digest_light(lights_host[i], ctx->stage_lights[i], ctx->stage_alights[i]);
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_lights, ctx->stage_lights.data(), sizeof(tr_dlight) * alloc,
                                hipMemcpyHostToDevice, stream));
     TR_HIP(ctx, hipMemcpyAsync(ctx->d_alights, ctx->stage_alights.data(), sizeof(tr_alight) * alloc,
