@@ -290,8 +290,9 @@ tr_status tr_upload_lights(tr_context* ctx, const tr_light* lights_host, uint32_
 /* Rewrites lights [first, first + count) of the uploaded array in place — what the reference does per frame to its two
  * rotating spotlights through a mapped buffer (`light_buffers.lights.write_mapped`, src/main.rs:1244-1256).  Host pointer,
  * read before the call returns; the records travel inside kernel arguments (TR_UPDATE_MAX_BYTES per launch), so the call
- * allocates nothing, copies nothing from pageable memory and waits for nothing: it is ordered on `stream` like a launch.
- * The range must lie inside the last tr_upload_lights. */
+ * allocates nothing, copies nothing from pageable memory and waits for nothing: it is ordered on `stream` like a launch —
+ * and only there: a caller that shades on other streams of the same context orders them against this one itself (the full
+ * uploads wait for launches of other streams; these do not).  The range must lie inside the last tr_upload_lights. */
 #define TR_UPDATE_MAX_BYTES 3072u
 tr_status tr_update_lights(tr_context* ctx, uint32_t first, uint32_t count, const tr_light* lights_host, void* stream);
 
