@@ -122,3 +122,22 @@ def test_push_constants_project_the_gbuffer_back_onto_its_pixels():
     np.testing.assert_allclose(xs, np.broadcast_to(np.arange(w)[None, :] + 0.5, xs.shape), atol=2e-3)
     np.testing.assert_allclose(ys, np.broadcast_to(np.arange(h)[:, None] + 0.5, ys.shape), atol=2e-3)
     np.testing.assert_allclose(clip[..., 2] / clip[..., 3], g["pos_depth"][..., 3], rtol=2e-4)
+
+
+def test_the_c_host_example_compiles_and_links_without_python(tmp_path):
+    """examples/host_frame.c — the boundary driven from plain C11 — builds with gcc -Wall -Werror against include/tr_shade.h and
+    links against libtr_shade.so and the HIP runtime only (tests/test_gpu_c_host.py runs it on the GPU box)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/lib/libamdhip64.so"):
+        pytest.skip("no gcc / HIP runtime to link against")
+    from transmission_renderer_amd import _lib
+    exe = str(tmp_path / "host_frame")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "host_frame.c"), "-L" + os.path.dirname(_lib.LIB_PATH), "-ltr_shade", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    needed = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libtr_shade.so" in needed and "python" not in needed.lower() and "torch" not in needed.lower(), needed
