@@ -29,16 +29,23 @@ typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 struct params {
     const f4v* pos; const f4v* nrm; const uint32_t* ids; const u4v* pyr; const f4v* lut; u2v* out;
     uint32_t width, height, tiles_x, ntiles, j_step, taps, fma, scatter;   // scatter: largest tap displacement in pixels
-    uint32_t tap_mode;     // 0: texel-aligned 16-byte pairs (the pass); 1: the same pairs forced to 16-byte alignment; 2: 8-byte loads, one texel each
-    uint32_t ahead;        // 1: the NEXT tile's plane rows and ids are requested before this tile's loads are waited for (two tiles of a
+    // TAP_MODE (template parameter of pattern_kernel)
+    //                        0: texel-aligned 16-byte pairs (the pass); 1: the same pairs forced to 16-byte alignment; 2: 8-byte loads, one texel each;
+                           // 3: a level's taps of the whole tile as ONE coalesced load of the tile's texel window into LDS (the window from
+                           //    the corner lanes' taps, every lane checked against it; a tile that does not fit gathers as in mode 0);
+                           // 4: mode 0's requests folded onto 64 x 64 texels of each level (every tap a cache hit)
+    // AHEAD (template parameter) 1: the NEXT tile's plane rows and ids are requested before this tile's loads are waited for (two tiles of a
                            // wave in flight: what more bytes in flight per CU are worth to the pattern itself)
     uint32_t tile_begin;   // first block tile of this launch's row band (two bands on two streams: bench.py's step)
     unsigned long long* wait_ticks; unsigned long long* waits;
 };
 
-template <int LDS_BYTES>
+// TAP_MODE / AHEAD are compile-time: each variant is its own lean kernel (a first version switched on them at run time and the
+// extra live values of the window mode cost EVERY variant a wave per SIMD: 66 registers)
+template <int LDS_BYTES, int TAP_MODE = 0, int AHEAD = 0>
 __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
     __shared__ unsigned char occupy[LDS_BYTES];      // limits the waves a CU holds
+    __shared__ u4v win[TAP_MODE == 3 ? 128 : 1];      // TAP_MODE 3: the tile's texel windows of the two levels
     if (p.width == 0xFFFFFFFFu) occupy[threadIdx.x] = 1;
     const uint32_t lane = threadIdx.x, lx = lane & 15u, ly = lane >> 4;
     const uint32_t xcd = blockIdx.x & 7u, per = p.ntiles >> 3, rem = p.ntiles & 7u;
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
     f4v a_next = {0.f, 0.f, 0.f, 0.f}, b_next = {0.f, 0.f, 0.f, 0.f};
     uint32_t id_next = 0u;
     const uint32_t j0 = blockIdx.x >> 3;
-    if (p.ahead && j0 < band_len * 4u) {
+    if (AHEAD && j0 < band_len * 4u) {
         uint32_t px, py, txi, tyi;
         pixel_of(j0, px, py, txi, tyi);
         const uint32_t pix = py * p.width + px;
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
         const uint32_t pix = py * p.width + px;
         f4v a, b;
         uint32_t id;
-        if (p.ahead) {
+        if (AHEAD) {
             a = a_next; b = b_next; id = id_next;           // (requested a tile ago)
             if (j + p.j_step < band_len * 4u) {
                 uint32_t qx, qy, tx2, ty2;
@@ -86,38 +93,95 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
         // the taps: displaced from the pixel by a field that varies smoothly over the screen (neighbouring pixels refract
         // alike: adjacent lanes fetch adjacent texels, as in the pass; `scatter` is the field's amplitude in pixels) and jumps
         // at "material" borders every 96 pixels; pairs of rows like the sampler's (row, row + 1) of two levels
-        uint32_t h = pix * 2654435761u;
-        const float fx = (float)px, fy = (float)py, amp = (float)p.scatter * (0.4f + 0.6f * (float)(((px / 96u) * 7u + (py / 96u) * 3u) % 5u) * 0.25f);
-        const int sdx = (int)(amp * __sinf(fx * 0.013f + fy * 0.007f)), sdy = (int)(amp * __cosf(fx * 0.009f - fy * 0.011f));
+        // (integer arithmetic only, a handful of instructions: the addresses must not be what the kernel spends its time on — a
+        //  first version formed them with sin / cos, divisions by 96 and 64-bit products and measured ITS OWN vector work)
+        const int wob_x = (int)(((px >> 3) + (py >> 2)) & 63u) - 32, wob_y = (int)(((px >> 4) - (py >> 3)) & 63u) - 32;   // -32 .. 31, constant over 8 x 4 pixels
+        const int sdx = (wob_x * (int)p.scatter) >> 5, sdy = (wob_y * (int)p.scatter) >> 5;
         u4v t[8];
         const uint32_t taps = p.taps;
+        bool staged[2] = {false, false};
+        u4v wreg[2] = {u4v{0, 0, 0, 0}, u4v{0, 0, 0, 0}};
+        uint32_t w_at[2] = {0u, 0u}, w_pitch[2] = {0u, 0u}, w_lanes[2] = {0u, 0u};
+        if (TAP_MODE == 3 && taps == 4u) {
+            // per level: the window of texel pairs (16-byte chunks) that holds every lane's two rows of two texels, requested as
+            // ONE coalesced load (a lane per chunk) beside the plane loads; spread to the lanes through LDS behind the common wait
+#pragma unroll
+            for (uint32_t level = 0; level < 2u; ++level) {
+                const uint32_t lw = p.width >> level, lh = p.height >> level, base = level ? p.width * p.height : 0u;
+                const uint32_t tx = (uint32_t)min(max((int)(px >> level) + (sdx >> level), 0), (int)lw - 2);
+                const uint32_t ty = (uint32_t)min(max((int)(py >> level) + (sdy >> level), 0), (int)lh - 2);
+                // the corner lanes' taps bound the window when the displacement is monotone over the tile; every lane is checked
+                uint32_t cx[4], cy[4];
+                const int corner[4] = {0, 15, 48, 63};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    cx[c] = (uint32_t)__builtin_amdgcn_readlane((int)tx, corner[c]);
+                    cy[c] = (uint32_t)__builtin_amdgcn_readlane((int)ty, corner[c]);
+                }
+                const uint32_t x_lo = min(min(cx[0], cx[1]), min(cx[2], cx[3])) & ~1u, x_hi = max(max(cx[0], cx[1]), max(cx[2], cx[3])) + 1u;
+                const uint32_t y_lo = min(min(cy[0], cy[1]), min(cy[2], cy[3])), y_hi = max(max(cy[0], cy[1]), max(cy[2], cy[3])) + 1u;
+                const uint32_t chunks = ((x_hi - x_lo) >> 1) + 1u, rows = y_hi - y_lo + 1u;
+                const bool inside = tx >= x_lo && tx + 1u <= x_hi && ty >= y_lo && ty + 1u <= y_hi;
+                const bool fits = chunks * rows <= 64u && __builtin_amdgcn_ballot_w64(!inside) == 0ull;   // (wave-uniform)
+                if (fits) {
+                    if (lane < chunks * rows) {
+                        const uint32_t r = lane / chunks, c = lane - r * chunks;
+                        const uint32_t gx = min(x_lo + 2u * c, lw - 2u), gy = min(y_lo + r, lh - 1u);
+                        wreg[level] = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(p.pyr) + (base + gy * lw + gx) * 8u);
+                    }
+                    w_at[level] = (ty - y_lo) * chunks * 2u + (tx - x_lo);
+                    w_pitch[level] = chunks * 2u;
+                    w_lanes[level] = chunks * rows;
+                    staged[level] = true;
+                }
+            }
+        }
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
-            if (k < taps) {
+            if (k < taps && !staged[k >> 1]) {
                 const int dx = sdx, dy = sdy;
                 const uint32_t level = k >> 1;    // taps 0,1: level 0 rows y, y + 1; taps 2,3: level 1
                 const uint32_t lw = p.width >> level, lh = p.height >> level, base = level ? p.width * p.height : 0u;
                 const uint32_t tx = (uint32_t)min(max((int)(px >> level) + (dx >> level), 0), (int)lw - 2);
                 const uint32_t tyy = (uint32_t)min(max((int)(py >> level) + (dy >> level) + (int)(k & 1u), 0), (int)lh - 1);
-                const char* at = reinterpret_cast<const char*>(p.pyr) + ((size_t)base + (size_t)tyy * lw + (p.tap_mode == 1u ? (tx & ~1u) : tx)) * 8u;
-                if (p.tap_mode == 2u) {
+                uint32_t texel = base + tyy * lw + (TAP_MODE == 1 ? (tx & ~1u) : tx);     // (the pyramid is < 4 GB: 32-bit byte offsets)
+                if (TAP_MODE == 4)   // the same requests folded onto 64 x 64 texels of each level: every tap an L2 hit, no tap traffic from memory
+                    texel = base + (tyy & 63u) * lw + (tx & 63u);
+                const char* at = reinterpret_cast<const char*>(p.pyr) + texel * 8u;
+                if (TAP_MODE == 2) {
                     const u2v lo = *reinterpret_cast<const u2v*>(at), hi = *reinterpret_cast<const u2v*>(at + 8);
                     t[k] = u4v{lo.x, lo.y, hi.x, hi.y};
                 } else {
                     typedef u4v u4v_a8 __attribute__((aligned(8)));
                     t[k] = *reinterpret_cast<const u4v_a8*>(at);
                 }
-            } else {
+            } else if (k >= taps) {
                 t[k] = u4v{0, 0, 0, 0};
             }
         }
         // the LUT line: 258 entries of 16 bytes per material, indexed by n.v — smooth over the screen like the taps
-        const f4v line = taps ? p.lut[(id & 15u) * 260u + ((uint32_t)(128.0f + 120.0f * __sinf(fx * 0.011f - fy * 0.005f)) & 255u)] : f4v{0.f, 0.f, 0.f, 0.f};
+        const f4v line = taps ? p.lut[(id & 15u) * 260u + (((px + py) >> 1) & 255u)] : f4v{0.f, 0.f, 0.f, 0.f};
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        if (p.ahead) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // (everything but the next tile's three plane loads: they are the youngest)
+        if (AHEAD) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // (everything but the next tile's three plane loads: they are the youngest)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         waited += __builtin_amdgcn_s_memtime() - t0;
         ++n;
+        if (TAP_MODE == 3 && (staged[0] || staged[1])) {   // (wave-uniform) windows -> LDS -> every lane's two rows of two texels
+#pragma unroll
+            for (uint32_t level = 0; level < 2u; ++level)
+                if (staged[level] && lane < w_lanes[level]) win[level * 64u + lane] = wreg[level];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave per workgroup: no barrier)
+#pragma unroll
+            for (uint32_t level = 0; level < 2u; ++level)
+                if (staged[level]) {
+                    const u2v* texels = reinterpret_cast<const u2v*>(win + level * 64u);
+                    const uint32_t at = w_at[level], pitch = w_pitch[level];
+                    const u2v q00 = texels[at], q10 = texels[at + 1u], q01 = texels[at + pitch], q11 = texels[at + pitch + 1u];
+                    t[2u * level] = u4v{q00.x, q00.y, q10.x, q10.y};
+                    t[2u * level + 1u] = u4v{q01.x, q01.y, q11.x, q11.y};
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         float x = a.x + b.x + line.x, y = a.y + b.y + line.y, z = a.z + b.z + a.w + b.w + line.z + line.w;
         uint32_t fold = id;
 #pragma unroll
@@ -137,7 +201,7 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
 
 static bool g_quiet = false;           // --brief: run() prints nothing, main() prints one JSON line
 static double g_last_us = 0.0, g_last_in_flight_kb = 0.0, g_last_wait_us = 0.0;
-template <int LDS_BYTES>
+template <int LDS_BYTES, int TAP_MODE = 0, int AHEAD = 0>
 static void run(const char* name, params p, int waves_per_simd, int sets, void** pos, void** nrm, void** ids, void** pyr, void** out, double ticks_per_us,
                 int bands = 1) {
     static hipStream_t streams[2] = {nullptr, nullptr};
@@ -171,7 +235,7 @@ static void run(const char* name, params p, int waves_per_simd, int sets, void**
             q.tile_begin = r0 * p.tiles_x;
             q.ntiles = (r1 - r0) * p.tiles_x;
             q.j_step = (grid / bands) >> 3;      // (each band a grid of its own share of the wave slots' rounds)
-            hipLaunchKernelGGL(pattern_kernel<LDS_BYTES>, dim3(grid / bands), dim3(64), 0, streams[b], q);
+            hipLaunchKernelGGL((pattern_kernel<LDS_BYTES, TAP_MODE, AHEAD>), dim3(grid / bands), dim3(64), 0, streams[b], q);
         }
     }
     if (bands > 1) {
@@ -200,7 +264,7 @@ static void run(const char* name, params p, int waves_per_simd, int sets, void**
     g_last_in_flight_kb = in_flight_per_cu / 1024.0;
     g_last_wait_us = lat_us;
     if (g_quiet) return;
-    if (p.taps == 0 || p.ahead)   // (the skeleton's loads are consumed straight behind the wait, and with a tile requested ahead the compiler's own counted wait precedes the timed one)
+    if (p.taps == 0 || AHEAD)   // (the skeleton's loads are consumed straight behind the wait, and with a tile requested ahead the compiler's own counted wait precedes the timed one)
         printf("%-34s %7.1f us  %5.2f TB/s on %.0f B/px\n", name, us, all_bytes / us / 1e6, all_bytes / px);
     else
         printf("%-34s %7.1f us  %5.2f TB/s on %.0f B/px  wait %6.0f ticks = %5.2f us  reads in flight per CU %6.1f KB\n", name, us,
@@ -246,7 +310,7 @@ int main(int argc, char** argv) {
     if (brief) {
         // bench.py's roofline.pattern_ceiling: the four figures the pass is held against, one JSON line
         double r[6], kb[2], wait[2];
-        p.fma = 0; p.tap_mode = 0;
+        p.fma = 0;
         p.taps = 0; p.scatter = 48;
         run<1024>("", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2); r[0] = g_last_us;
         run<1024>("", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 1); r[1] = g_last_us;
@@ -285,11 +349,15 @@ int main(int argc, char** argv) {
     }
     p.scatter = 48;
     printf("-- what in a tap costs: 8 waves per SIMD, one launch per frame\n");
-    p.tap_mode = 1;
-    run<1024>("pairs forced to 16-byte alignment", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
-    p.tap_mode = 2;
-    run<1024>("two 8-byte loads per pair", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
-    p.tap_mode = 0;
+    run<1024, 1>("pairs forced to 16-byte alignment", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024, 2>("two 8-byte loads per pair", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024, 3>("a level's taps as ONE window load + LDS", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024, 3>("... two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+    p.scatter = 0;
+    run<1024, 3>("... taps not displaced, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+    p.scatter = 48;
+    run<1024, 4>("taps folded onto 64x64 texels (all cache hits)", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024, 4>("... two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
     p.taps = 2;
     run<1024>("level 0 taps only (2 of 4)", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
     p.taps = 4;
@@ -302,16 +370,14 @@ int main(int argc, char** argv) {
     run<1024>("... tap scatter +-0 px, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
     p.scatter = 48;
     printf("-- two tiles of a wave in flight (the next tile's plane rows requested before this tile's wait), 8 waves per SIMD\n");
-    p.ahead = 1;
     p.taps = 0;
-    run<1024>("planes + store only, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024, 0, 1>("planes + store only, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
     p.taps = 4;
-    run<1024>("the pass's pattern, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
-    run<1024>("the pass's pattern, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+    run<1024, 0, 1>("the pass's pattern, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024, 0, 1>("the pass's pattern, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
     p.fma = 64;
-    run<1024>("... with 192 fma per pixel, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+    run<1024, 0, 1>("... with 192 fma per pixel, one call", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
     p.fma = 0;
-    p.ahead = 0;
     printf("-- the same at 8 waves per SIMD with dependent fma per pixel behind the wait (3 chains x N)\n");
     for (uint32_t f : {16u, 32u, 64u, 96u, 128u}) {
         p.fma = f;
