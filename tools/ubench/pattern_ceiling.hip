@@ -37,6 +37,9 @@ struct params {
     // AHEAD (template parameter) 1: the NEXT tile's plane rows and ids are requested before this tile's loads are waited for (two tiles of a
                            // wave in flight: what more bytes in flight per CU are worth to the pattern itself)
     uint32_t tile_begin;   // first block tile of this launch's row band (two bands on two streams: bench.py's step)
+    uint32_t order;        // how an XCD walks its band of block tiles: 0 row-major (the pass); k > 0: in super-columns k block tiles wide
+                           // (row-major inside a super-column, the super-columns left to right)
+    uint32_t field;        // the displacement field's direction: 0 both, 1 x only, 2 y only
     unsigned long long* wait_ticks; unsigned long long* waits;
 };
 
@@ -52,7 +55,15 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
     const uint32_t band_start = xcd * per + (xcd < rem ? xcd : rem), band_len = per + (xcd < rem ? 1u : 0u);
     unsigned long long waited = 0, n = 0;
     auto pixel_of = [&](uint32_t j, uint32_t& px, uint32_t& py, uint32_t& txi, uint32_t& tyi) {
-        const uint32_t tile = p.tile_begin + band_start + (j >> 2);
+        uint32_t t = j >> 2;
+        if (p.order) {   // (scalar) super-columns of `order` block tiles over the band's whole tile rows; what is left of the band row-major
+            const uint32_t rows = band_len / p.tiles_x, cols = p.tiles_x / p.order, body = rows * cols * p.order;
+            if (t < body) {
+                const uint32_t per_col = rows * p.order, c = t / per_col, r = (t - c * per_col) / p.order, x = t - c * per_col - r * p.order;
+                t = r * p.tiles_x + c * p.order + x;      // (order divides tiles_x)
+            }
+        }
+        const uint32_t tile = p.tile_begin + band_start + t;
         tyi = tile / p.tiles_x;
         txi = (tile - tyi * p.tiles_x) * 4u + (j & 3u);
         px = min(txi * 16u + lx, p.width - 1u);
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
         // (integer arithmetic only, a handful of instructions: the addresses must not be what the kernel spends its time on — a
         //  first version formed them with sin / cos, divisions by 96 and 64-bit products and measured ITS OWN vector work)
         const int wob_x = (int)(((px >> 3) + (py >> 2)) & 63u) - 32, wob_y = (int)(((px >> 4) - (py >> 3)) & 63u) - 32;   // -32 .. 31, constant over 8 x 4 pixels
-        const int sdx = (wob_x * (int)p.scatter) >> 5, sdy = (wob_y * (int)p.scatter) >> 5;
+        const int sdx = p.field == 2u ? 0 : (wob_x * (int)p.scatter) >> 5, sdy = p.field == 1u ? 0 : (wob_y * (int)p.scatter) >> 5;
         u4v t[8];
         const uint32_t taps = p.taps;
         bool staged[2] = {false, false};
@@ -281,6 +292,7 @@ __global__ void tick_kernel(unsigned long long* out) {
 
 int main(int argc, char** argv) {
     const bool brief = argc > 1 && std::string(argv[1]) == "--brief";
+    const bool explore = argc > 1 && std::string(argv[1]) == "--explore";
     g_quiet = brief;
     const uint32_t W = 3840, H = 2160;
     const size_t px = (size_t)W * H;
@@ -327,6 +339,32 @@ int main(int argc, char** argv) {
         return 0;
     }
     printf("s_memtime: %.1f ticks per us\n", ticks_per_us);
+    if (explore) {
+        // where the taps' cost comes from: the direction of the displacement field, and the order an XCD walks its band in
+        p.fma = 0; p.taps = 4;
+        for (uint32_t field : {0u, 1u, 2u})
+            for (uint32_t sc : {48u, 200u, 600u}) {
+                p.field = field; p.scatter = sc;
+                char nm[96];
+                snprintf(nm, sizeof nm, "field %s, +-%u px", field == 0 ? "x and y" : field == 1 ? "x only" : "y only", sc);
+                run<1024>(nm, p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+            }
+        p.field = 0; p.scatter = 48;
+        for (uint32_t order : {0u, 1u, 2u, 4u, 6u, 10u, 15u, 30u}) {
+            if (order && p.tiles_x % order) continue;
+            p.order = order;
+            char nm[96];
+            snprintf(nm, sizeof nm, "order %u, pattern, one call", order);
+            run<1024>(nm, p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+            snprintf(nm, sizeof nm, "order %u, pattern, two bands", order);
+            run<1024>(nm, p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+            p.taps = 0;
+            snprintf(nm, sizeof nm, "order %u, planes + store only, two bands", order);
+            run<1024>(nm, p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+            p.taps = 4;
+        }
+        return 0;
+    }
 
     p.scatter = 48; p.fma = 0;
     printf("-- planes + store only (the streaming skeleton)\n");
