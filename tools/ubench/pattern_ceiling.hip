@@ -159,7 +159,12 @@ __global__ __launch_bounds__(64) void pattern_kernel(const params p) {
                 if (TAP_MODE == 4)   // the same requests folded onto 64 x 64 texels of each level: every tap an L2 hit, no tap traffic from memory
                     texel = base + (tyy & 63u) * lw + (tx & 63u);
                 const char* at = reinterpret_cast<const char*>(p.pyr) + texel * 8u;
-                if (TAP_MODE == 2) {
+                if (TAP_MODE == 5) {          // ONE texel (8 bytes) per lane and row: half the bytes through the L1, the same instructions and lines
+                    const u2v lo = *reinterpret_cast<const u2v*>(at);
+                    t[k] = u4v{lo.x, lo.y, 0u, 0u};
+                } else if (TAP_MODE == 6) {   // 4 bytes per lane and row
+                    t[k] = u4v{*reinterpret_cast<const uint32_t*>(at), 0u, 0u, 0u};
+                } else if (TAP_MODE == 2) {
                     const u2v lo = *reinterpret_cast<const u2v*>(at), hi = *reinterpret_cast<const u2v*>(at + 8);
                     t[k] = u4v{lo.x, lo.y, hi.x, hi.y};
                 } else {
@@ -350,6 +355,21 @@ int main(int argc, char** argv) {
                 run<1024>(nm, p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
             }
         p.field = 0; p.scatter = 48;
+        // is a gather's cost its bytes through the L1 (64 B/clk per CU) or its instruction?
+        for (uint32_t taps : {1u, 2u, 3u, 4u}) {
+            p.taps = taps;
+            char nm[96];
+            snprintf(nm, sizeof nm, "%u taps of 16 bytes, all cache hits", taps);
+            run<1024, 4>(nm, p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+        }
+        p.taps = 4;
+        run<1024, 0>("4 taps of 16 bytes", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+        run<1024, 5>("4 taps of 8 bytes (one texel per lane and row)", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+        run<1024, 6>("4 taps of 4 bytes", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us);
+        run<1024, 0>("4 taps of 16 bytes, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+        run<1024, 5>("4 taps of 8 bytes, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+        run<1024, 6>("4 taps of 4 bytes, two bands", p, 8, sets, pos, nrm, ids, pyr, out, ticks_per_us, 2);
+        if (argc > 2) return 0;
         for (uint32_t order : {0u, 1u, 2u, 4u, 6u, 10u, 15u, 30u}) {
             if (order && p.tiles_x % order) continue;
             p.order = order;
